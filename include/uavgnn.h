@@ -1,0 +1,105 @@
+/*
+ * uavgnn.h - C ABI of the MI355X-native hetero-GNN hot path (libuavgnn.so, gfx950 only).
+ *
+ * Drop-in boundary for the graph arithmetic that zhangxiaochen95/uav_bs_ctrl's MADRQN agent runs through DGL 0.9.0
+ * (reference: algos/madrqn/agents/gnn_agents.py).  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - All functions return 0 on success, a negative UAVGNN_E* code on argument errors, or the NEGATED hipError_t of a
+ *     failed launch.  Nothing is thrown across this boundary.
+ *   - All pointers are DEVICE pointers owned by the caller (PyTorch allocates every tensor incl. workspaces; the
+ *     library allocates nothing and keeps no mutable global state; calls on distinct streams are independent).
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Launches are asynchronous and capturable
+ *     into a hipGraph.
+ *   - Matrices are row-major fp32; `ld*` is the leading dimension in elements; offsets/indices are int32.
+ *   - Relation layout (the layout the reference's graph builder emits, algos/madrqn/utils/env_wrappers.py:69-89):
+ *     edges of `seen`/`near` are grouped by destination and src id == edge id, so a relation is x_src[E,F] plus
+ *     seg_off[N+1].  `talk` is given twice: CSC (in-edges per destination) and its transpose (out-edges per source,
+ *     with the CSC position of each edge) so that the backward is a pure gather (deterministic, no float atomics).
+ */
+#ifndef UAVGNN_H
+#define UAVGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAVGNN_VERSION 100 /* 0.1.0 */
+
+#define UAVGNN_EINVAL (-1000)      /* null pointer / non-positive size */
+#define UAVGNN_EUNSUPPORTED (-1001) /* shape outside the compiled instantiations */
+#define UAVGNN_EWORKSPACE (-1002)   /* workspace too small */
+
+typedef void* uavgnn_stream_t;
+
+int uavgnn_version(void);
+
+/* Human-readable text for a return code of this library (static storage). */
+const char* uavgnn_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K1  GATv2 relation, forward.
+ * Replaces dglnn.GATv2Conv((F_src,F_dst), D, nh, residual=True, allow_zero_in_degree=True, activation=ReLU).forward
+ * as constructed at gnn_agents.py:93-96 and called at :103-104 (and drqn/agents/gnn_agents.py:17-18,:27).
+ *   el = W_s x_u + b_s ; er = W_d x_v + b_d ; e = attn . lrelu_slope(el+er) per head ; a = softmax over in-edges ;
+ *   out[v] = ReLU( sum_u a el[u] + W_r x_v + b_r )            
+ * x_src[E,F_src], x_dst[N,F_dst], seg_off[N+1]; W_s[H,F_src] b_s[H] W_d[H,F_dst] b_d[H] attn[H] W_r[H,F_dst]
+ * b_r[H] (b_r may be NULL = zeros), H = nh*D.  out is written at out[v*ld_out + 0..H) (so two relations can share one
+ * [N,2H] buffer = the th.cat of gnn_agents.py:106).  attn_save[E,nh] (may be NULL) receives the softmax weights for
+ * the backward.  Supported: F_src in {2,4}, F_dst == 2, H <= 256, D in {8,16,32,64}.
+ */
+int uavgnn_gatv2_fwd(const float* x_src, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off, int N,
+                     const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
+                     const float* W_r, const float* b_r, int nh, int D, float slope, float* out, int ld_out,
+                     float* attn_save, uavgnn_stream_t stream);
+
+/* K1 backward: parameter gradients only (observations are leaves: the reference never needs d/dx, Appendix A.4).
+ * out / d_out are the forward output and its gradient (same ld).  Gradients are OVERWRITTEN.  Deterministic: per
+ * workgroup partials in `workspace` are combined in a fixed order by a second launch (no float atomics).
+ * workspace >= uavgnn_gatv2_bwd_workspace_bytes(F_src, nh*D). */
+size_t uavgnn_gatv2_bwd_workspace_bytes(int F_src, int H);
+int uavgnn_gatv2_bwd(const float* x_src, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off, int N,
+                     const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
+                     int nh, int D, float slope, const float* out, const float* d_out, int ld_out,
+                     const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d, float* dattn,
+                     float* dW_r, float* db_r, void* workspace, size_t workspace_bytes, uavgnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K3b  Targeted attention over the talk relation, forward.
+ * Replaces g.apply_edges(fn.u_dot_v('s','q','e')); e/key_size; edge_softmax; update_all(u_mul_e('v','a'), sum)
+ * (gnn_agents.py:261-267).   e_uv = <s_u, q_v> * scale ; a = softmax over in-edges of v ; c_v = sum_u a_uv v_u.
+ * s,q: [N,K] rows with leading dims ld_s/ld_q, v: [N,M] ld_v (they may be column slices of one projection buffer).
+ * talk_off[N+1], talk_src[E] = CSC.  c[N,M] (ld_c) is overwritten (zero for nodes without in-edges);
+ * a_save[E] receives the attention weights in CSC order.  K <= 64, M <= 256.
+ * With s == q == NULL the attention is uniform: c = mean of in-neighbour rows (the UDF reduce `mailbox.mean(1)` of
+ * BaseComm/CommNet, gnn_agents.py:130-133,:214-216).
+ */
+int uavgnn_talk_attn_fwd(const float* s, int ld_s, const float* q, int ld_q, const float* v, int ld_v, int K, int M,
+                         const int32_t* talk_off, const int32_t* talk_src, int N, float scale, float* c, int ld_c,
+                         float* a_save, uavgnn_stream_t stream);
+
+/* K3b backward.  d_c[N,M] -> d_s, d_q [N,K], d_v [N,M] (overwritten; any of d_s/d_q may be NULL in uniform mode).
+ * t_off[N+1], t_dst[E], t_pos[E]: transpose of the CSC (out-edges of each source, destination of each, and the CSC
+ * position of the edge).  de_tmp[E] is scratch. */
+int uavgnn_talk_attn_bwd(const float* s, int ld_s, const float* q, int ld_q, const float* v, int ld_v, int K, int M,
+                         const int32_t* talk_off, const int32_t* talk_src, const int32_t* t_off, const int32_t* t_dst,
+                         const int32_t* t_pos, int N, float scale, const float* a_save, const float* d_c, int ld_dc,
+                         float* d_s, int ld_ds, float* d_q, int ld_dq, float* d_v, int ld_dv, float* de_tmp,
+                         uavgnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K4  GRU cell gate math (the pointwise half of nn.GRUCell: gnn_agents.py:29,:123,:164,:208,:246,:282).
+ * gi = W_ih i + b_ih, gh = W_hh h + b_hh are [N,3H] (gate order r,z,n);  h' = (1-z) n + z h.
+ */
+int uavgnn_gru_gates_fwd(const float* gi, const float* gh, const float* h, int N, int H, float* h_out,
+                         uavgnn_stream_t stream);
+int uavgnn_gru_gates_bwd(const float* gi, const float* gh, const float* h, const float* d_hout, int N, int H,
+                         float* d_gi, float* d_gh, float* d_h, uavgnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAVGNN_H */

@@ -1,0 +1,120 @@
+"""`-m gpu` parity tests: the HIP path (through the C-ABI) against the committed golden fixtures and against the CPU
+oracle on seeded synthetic graphs.  Tolerance: north_star's 1e-5 relative fp32 (rtol = 1e-5, atol = 1e-5 max|ref|)
+for outputs; gradients (long fp32 reductions over edges) are held to 1e-4 against the float64 oracle AND must not be
+worse than 4x the float32 CPU oracle's own error against float64."""
+import pytest
+import torch as th
+
+from oracle import restatement as R
+from tests.gpu_util import agent_from_params, default_init_params, synth_graph, to_batch
+from tests.util import assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+GOLDENS = ["agent_none", "agent_tarmac", "agent_tarmac_r2", "agent_tarmac_duel", "agent_base", "agent_commnet",
+           "agent_econv", "agent_mlp_tarmac", "agent_debugmap_tarmac"]
+
+
+def _loss(q, h2, wq, wh):
+    return (q * wq).sum() + (h2 * wh).sum()
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_golden_forward_backward(name):
+    g, h, p, cfg, z = load_golden(name, dtype=th.float32)
+    obs_shape = int(g["x_flat"].shape[1]) if cfg["enc"] == "mlp" else None
+    net = agent_from_params(p, cfg, obs_shape)
+    if cfg["enc"] == "mlp":
+        g = dict(g, x_a=g["x_flat"])
+        g.pop("x_flat")
+    hb = to_batch(g)
+    hd = h.cuda().requires_grad_(True)
+    q, h2 = net(hb, hd)
+    assert_close(q, th.as_tensor(z["q"]), 1e-5, f"{name}: q")
+    assert_close(h2, th.as_tensor(z["h_out"]), 1e-5, f"{name}: h'")
+    wq, wh = (th.as_tensor(z[k], dtype=th.float32).cuda() for k in ("wq", "wh"))
+    _loss(q, h2, wq, wh).backward()
+    for k, prm in net.named_parameters():
+        ref = th.as_tensor(z["grad:" + k])
+        got = prm.grad if prm.grad is not None else th.zeros_like(prm)
+        assert_close(got, ref, 1e-4, f"{name}: grad {k}", floor=1e-7)
+    assert_close(hd.grad, th.as_tensor(z["grad:__h__"]), 1e-4, f"{name}: grad h", floor=1e-7)
+
+
+def test_golden_drqn_twin():
+    import types
+    from uav_bs_ctrl_amd.agents import REGISTRY
+    g, h, p, cfg, z = load_golden("agent_drqn", dtype=th.float32)
+    net = REGISTRY["drqn_gnn"](dict(agent=2, gt=4), cfg["n_actions"], types.SimpleNamespace(hidden_size=32, n_heads=4))
+    net.load_state_dict(p)
+    net = net.cuda()
+    hd = h.cuda().requires_grad_(True)
+    q, h2 = net(to_batch(g), hd)
+    assert_close(q, th.as_tensor(z["q"]), 1e-5, "drqn q")
+    assert_close(h2, th.as_tensor(z["h_out"]), 1e-5, "drqn h'")
+    _loss(q, h2, th.as_tensor(z["wq"], dtype=th.float32).cuda(), th.as_tensor(z["wh"], dtype=th.float32).cuda()).backward()
+    for k, prm in net.named_parameters():
+        assert_close(prm.grad, th.as_tensor(z["grad:" + k]), 1e-4, f"drqn grad {k}", floor=1e-7)
+
+
+EXP3 = dict(enc="gnn", c="tarmac", n_heads=4, key_size=16, msg_size=64, n_rounds=1, n_layers=2, dueling=False,
+            hidden_size=256, n_actions=9)
+
+
+@pytest.mark.parametrize("dist,talk,B,n,M", [("dense", "complete", 16, 8, 80), ("env", "complete", 64, 8, 80),
+                                             ("ragged", "sparse", 8, 16, 200), ("dense", "complete", 32, 4, 40)])
+def test_exp3_sizes_vs_oracle(dist, talk, B, n, M):
+    """exp3 model sizes (H=256, nh=4, msg=64, key=16) on seeded synthetic graphs; oracle in float64 and float32."""
+    p64 = default_init_params(EXP3, seed=1)
+    g = synth_graph(B, n, M, dist, seed=3, talk=talk)
+    gen = th.Generator().manual_seed(99)
+    h = 0.5 * th.randn(B * n, 256, generator=gen)
+    wq, wh = th.randn(B * n, 9, generator=gen), th.randn(B * n, 256, generator=gen) / 16
+
+    def oracle(dtype):
+        pp = {k: v.to(dtype).requires_grad_(True) for k, v in p64.items()}
+        gg = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in g.items()}
+        hh = h.to(dtype).requires_grad_(True)
+        q, h2 = R.gnn_agent_forward(gg, hh, pp, EXP3)
+        gr = th.autograd.grad(_loss(q, h2, wq.to(dtype), wh.to(dtype)), list(pp.values()) + [hh])
+        return q, h2, dict(zip(list(pp) + ["__h__"], gr))
+
+    q64, h64, g64 = oracle(th.float64)
+    q32, h32, g32 = oracle(th.float32)
+    net = agent_from_params(p64, EXP3)
+    hd = h.cuda().requires_grad_(True)
+    q, h2 = net(to_batch(g), hd)
+    assert_close(q, q64, 1e-5, "q")
+    assert_close(h2, h64, 1e-5, "h'")
+    _loss(q, h2, wq.cuda(), wh.cuda()).backward()
+    grads = {k: prm.grad for k, prm in net.named_parameters()}
+    grads["__h__"] = hd.grad
+    for k, ref in g64.items():
+        scale = float(ref.abs().max()) + 1e-30
+        err_hip = float((grads[k].double().cpu() - ref).abs().max()) / scale
+        err_cpu32 = float((g32[k].double() - ref).abs().max()) / scale
+        assert err_hip <= max(1e-4, 4 * err_cpu32), f"grad {k}: rel err {err_hip:.3e} (cpu fp32 oracle {err_cpu32:.3e})"
+
+
+def test_backward_is_deterministic():
+    p64 = default_init_params(EXP3, seed=2)
+    g = synth_graph(32, 8, 80, "ragged", seed=5)
+    net = agent_from_params(p64, EXP3)
+    hb = to_batch(g)
+    h = th.randn(256, 256, generator=th.Generator().manual_seed(1)).cuda()
+    outs = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        q, h2 = net(hb, h)
+        (q.sum() + h2.square().sum()).backward()
+        outs.append(th.cat([p.grad.flatten() for p in net.parameters()]).clone())
+    assert th.equal(outs[0], outs[1]), "two identical backward passes differ bitwise"
+
+
+def test_cpu_tensors_fail_loudly():
+    from uav_bs_ctrl_amd._lib import UavGnnError
+    g, h, p, cfg, _ = load_golden("agent_tarmac", dtype=th.float32)
+    net = agent_from_params(p, cfg, device="cpu")
+    from uav_bs_ctrl_amd import HeteroBatch
+    with pytest.raises(UavGnnError):
+        net(HeteroBatch.from_arrays(**g), h)

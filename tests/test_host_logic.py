@@ -1,0 +1,145 @@
+"""CPU tests of the host-side mirror: HeteroBatch container ops, state_dict layout, registry, loud failure."""
+import types
+
+import numpy as np
+import pytest
+import torch as th
+
+from tests.util import load_golden
+from uav_bs_ctrl_amd import REGISTRY, GnnAgent, HeteroBatch, batch, cat, from_obs_dicts, heterograph, merge
+from uav_bs_ctrl_amd._lib import UavGnnError
+
+
+def _args(c="tarmac", H=32, dueling=False):
+    return types.SimpleNamespace(hidden_size=H, c=c, n_heads=4, n_layers=2, msg_size=8, key_size=4, n_rounds=1,
+                                 dueling=dueling)
+
+
+@pytest.mark.parametrize("name,c,duel", [("agent_tarmac", "tarmac", False), ("agent_none", None, False),
+                                         ("agent_disc", "disc", False), ("agent_base", "base", False),
+                                         ("agent_commnet", "commnet", False), ("agent_econv", "econv", False),
+                                         ("agent_tarmac_duel", "tarmac", True)])
+def test_state_dict_layout_matches_reference(name, c, duel):
+    """Names, shapes and parameters() order equal the reference module's (captured in the golden fixtures)."""
+    _, _, p, cfg, z = load_golden(name)
+    net = GnnAgent(dict(agent=2, ubs=2, gt=4), cfg["n_actions"], _args(c, dueling=duel))
+    names = [k for k, _ in net.named_parameters()]
+    assert names == [str(n) for n in z["param_names"]]
+    for k, prm in net.named_parameters():
+        assert tuple(prm.shape) == tuple(p[k].shape), k
+    net.load_state_dict(p)   # strict
+
+
+def test_registry_and_errors():
+    assert REGISTRY["gnn"] is GnnAgent
+    with pytest.raises(KeyError):
+        GnnAgent(dict(agent=2, ubs=2, gt=4), 9, _args("nope"))
+    with pytest.raises(AssertionError):
+        GnnAgent(dict(agent=2, ubs=2, gt=4), 9, types.SimpleNamespace(hidden_size=30, c=None, n_heads=4, n_layers=1,
+                                                                       msg_size=8, key_size=4, n_rounds=1, dueling=False))
+    net = GnnAgent(dict(agent=2, ubs=2, gt=4), 9, _args())
+    assert net.init_hidden().shape == (1, 32) and net.init_hidden().device.type == "cpu"
+
+
+def test_missing_res_fc_bias_is_tolerated():
+    _, _, p, cfg, _ = load_golden("agent_tarmac")
+    p = {k: v for k, v in p.items() if not k.endswith("res_fc.bias")}
+    net = GnnAgent(dict(agent=2, ubs=2, gt=4), 9, _args())
+    net.load_state_dict(p)
+    assert float(net.enc.f_conv["seen"].res_fc.bias.abs().max()) == 0.0
+
+
+def test_no_cpu_fallback():
+    g, h, p, cfg, _ = load_golden("agent_tarmac", dtype=th.float32)
+    net = GnnAgent(dict(agent=2, ubs=2, gt=4), 9, _args())
+    with pytest.raises(UavGnnError):
+        net(HeteroBatch.from_arrays(**g), h)
+
+
+def _obs(rng, n, M):
+    out = []
+    for i in range(n):
+        gt = rng.uniform(-1, 1, (M, 5)).astype(np.float32)
+        gt[:, 0] = rng.uniform(size=M) < 0.5
+        ub = rng.uniform(-1, 1, (n - 1, 3)).astype(np.float32)
+        ub[:, 0] = rng.uniform(size=n - 1) < 0.6
+        out.append(dict(agent=rng.uniform(0, 1, 2).astype(np.float32), ubs=ub, gt=gt))
+    return out
+
+
+def test_from_obs_dicts_equals_reference_style_construction():
+    """Vectorised builder == per-agent heterograph + batch + merge (the reference's env_wrappers.py:65-89,:122-154)."""
+    rng = np.random.default_rng(0)
+    n, M = 5, 12
+    obs = _obs(rng, n, M)
+    d = rng.uniform(0, 2, (n, n))
+    d = (d + d.T) / 2
+    np.fill_diagonal(d, 0)
+    fast = from_obs_dicts(obs, d, r_comm=1.0)
+    # slow path, spelled like the reference
+    locs = []
+    for o in obs:
+        gi, ui = o["gt"][:, 0] == 1, o["ubs"][:, 0] == 1
+        g = heterograph({("gt", "seen", "agent"): (np.arange(gi.sum()), np.zeros(gi.sum(), dtype=np.int64)),
+                         ("ubs", "near", "agent"): (np.arange(ui.sum()), np.zeros(ui.sum(), dtype=np.int64)),
+                         ("agent", "talk", "agent"): ([], [])},
+                        num_nodes_dict={"gt": gi.sum(), "ubs": ui.sum(), "agent": 1})
+        g.ndata["feat"] = {"gt": th.as_tensor(o["gt"][gi, 1:]), "ubs": th.as_tensor(o["ubs"][ui, 1:]),
+                           "agent": th.as_tensor(o["agent"]).unsqueeze(0)}
+        locs.append(g)
+    u, v = [], []
+    for i in range(n):
+        for j in range(n):
+            if d[i, j] <= 1.0:
+                u.append(i), v.append(j)
+    comm = heterograph({("gt", "seen", "agent"): ([], []), ("ubs", "near", "agent"): ([], []),
+                        ("agent", "talk", "agent"): (u, v)}, num_nodes_dict={"gt": 0, "ubs": 0, "agent": n})
+    slow = merge([batch(locs), comm])
+    for et in ("seen", "near"):
+        xs, offs = slow.relation_segments(et)
+        xf, offf = fast.relation_segments(et)
+        assert th.equal(offs, offf) and th.equal(xs, xf)
+    assert all(th.equal(a, b) for a, b in zip(slow.talk_csc(), fast.talk_csc()))
+    assert th.equal(slow.talk_eid(), fast.talk_eid())
+    assert th.equal(slow.agent_feat(), fast.agent_feat())
+    # transpose is consistent: position t_pos[k] of the CSC holds an edge whose source is the segment owner
+    t_off, t_dst, t_pos = fast.talk_transpose()
+    off, src = fast.talk_csc()
+    owner = th.repeat_interleave(th.arange(n), (t_off[1:] - t_off[:-1]).long())
+    assert th.equal(src[t_pos.long()].long(), owner)
+    from uav_bs_ctrl_amd.graph import seg_ids
+    assert th.equal(seg_ids(off)[t_pos.long()], t_dst.long())
+
+
+def test_batch_offsets_and_cat():
+    rng = np.random.default_rng(1)
+    gs = []
+    for k in range(3):
+        n = 3 + k
+        d = np.zeros((n, n))
+        gs.append(from_obs_dicts(_obs(rng, n, 7), d, r_comm=1.0))
+    b = cat(gs)
+    assert b.num_nodes("agent") == 3 + 4 + 5
+    assert b.graph_off.tolist() == [0, 3, 7, 12]
+    off, src = b.talk_csc()
+    assert int(off[-1]) == 9 + 16 + 25 and int(src.max()) == 11
+    # talk edges never cross environments
+    from uav_bs_ctrl_amd.graph import seg_ids
+    dst = seg_ids(off)
+    env_of = th.repeat_interleave(th.arange(3), th.tensor([3, 4, 5]))
+    assert th.equal(env_of[src.long()], env_of[dst])
+    xs, so = b.relation_segments("seen")
+    assert xs.shape[0] == int(so[-1]) and so.numel() == 13
+    assert th.equal(cat([th.ones(2, 3), th.zeros(1, 3)]), th.cat([th.ones(2, 3), th.zeros(1, 3)]))
+    with pytest.raises(TypeError):
+        cat([1, 2])
+
+
+def test_general_unsorted_relation_is_gathered_into_segments():
+    g = heterograph({("gt", "seen", "agent"): ([2, 0, 1, 3], [1, 0, 1, 0]), ("ubs", "near", "agent"): ([], []),
+                     ("agent", "talk", "agent"): ([0, 1], [1, 0])}, num_nodes_dict={"gt": 4, "ubs": 0, "agent": 2})
+    feat = th.arange(16, dtype=th.float32).view(4, 4)
+    g.ndata["feat"] = {"gt": feat, "agent": th.zeros(2, 2), "ubs": th.zeros(0, 2)}
+    xs, off = g.relation_segments("seen")
+    assert off.tolist() == [0, 2, 4]
+    assert th.equal(xs, feat[[0, 3, 2, 1]])

@@ -1,0 +1,92 @@
+"""ctypes binding of ``libuavgnn.so`` - the C-ABI declared in ``include/uavgnn.h``.
+
+PyTorch only supplies device memory and the current HIP stream; every call passes raw pointers and sizes.
+There is NO CPU fallback: if the shared library is missing, or a tensor is not on the GPU, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch as th  # imported first on purpose: libuavgnn must bind to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libuavgnn.so")
+
+_c_fp = ctypes.c_void_p   # const float* / float*
+_c_ip = ctypes.c_void_p   # const int32_t*
+_c_int = ctypes.c_int
+_c_f32 = ctypes.c_float
+_c_st = ctypes.c_void_p   # hipStream_t
+
+# name -> (restype, argtypes); mirrors include/uavgnn.h one to one (checked by tests/test_cabi_symbols.py)
+SIGNATURES = {
+    "uavgnn_version": (_c_int, []),
+    "uavgnn_strerror": (ctypes.c_char_p, [_c_int]),
+    "uavgnn_gatv2_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
+                                  _c_fp, _c_fp, _c_int, _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_st]),
+    "uavgnn_gatv2_bwd_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
+    "uavgnn_gatv2_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
+                                  _c_int, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
+                                  _c_fp, _c_fp, _c_fp, ctypes.c_void_p, ctypes.c_size_t, _c_st]),
+    "uavgnn_talk_attn_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip,
+                                      _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_st]),
+    "uavgnn_talk_attn_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip,
+                                      _c_ip, _c_ip, _c_ip, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_int,
+                                      _c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_st]),
+    "uavgnn_gru_gates_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_st]),
+    "uavgnn_gru_gates_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_st]),
+}
+
+_LIB = None
+
+
+class UavGnnError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Loads libuavgnn.so once.  Fails loudly when it has not been built (``__graft_entry__.build()``)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise UavGnnError(f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; "
+                              f"g.build()'`.  uav_bs_ctrl_amd has no CPU / eager fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = handle
+    return _LIB
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().uavgnn_strerror(code).decode()
+        raise UavGnnError(f"{what} failed with code {code}: {msg}")
+
+
+def ptr(t: th.Tensor | None):
+    """Raw device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    """The HIP stream PyTorch is currently recording on (so launches order with torch ops and graph capture works)."""
+    return th.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors: th.Tensor) -> None:
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise UavGnnError("uav_bs_ctrl_amd ops run on the MI355X only: got a CPU tensor (no CPU fallback exists; "
+                              "move the module and the graph to 'cuda').")
+
+
+def f32c(t: th.Tensor) -> th.Tensor:
+    """float32 + contiguous view of t (no copy when already so)."""
+    if t.dtype != th.float32:
+        raise UavGnnError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()

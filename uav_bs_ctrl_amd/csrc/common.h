@@ -1,0 +1,45 @@
+// Shared device helpers for libuavgnn (gfx950 / CDNA4 only: 64-lane wavefronts are hard-coded).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "uavgnn.h"
+
+namespace uavgnn {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Orders LDS traffic between the lanes of ONE wavefront (LDS operations of a wave retire in issue order; this only
+// stops the compiler from moving accesses across the point).
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -static_cast<int>(e);
+}
+
+// Memory-bound grids: enough workgroups to fill 256 CUs x 8, grid-stride the rest (guide: Guideline 11).
+inline int capped_grid(long long work_items, int per_block, int cap = 2048) {
+  long long b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return static_cast<int>(b);
+}
+
+}  // namespace uavgnn

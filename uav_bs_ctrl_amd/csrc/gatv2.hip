@@ -1,0 +1,544 @@
+// K1: fused GATv2 relation (forward / backward) for the segment layout of the reference's observation graphs.
+//
+// Replaces dglnn.GATv2Conv.forward as used at /root/reference/algos/madrqn/agents/gnn_agents.py:93-96,:103-104
+// (math: SURVEY Appendix A.1/A.4).  Nothing of size [E, H] is ever materialised in HBM:
+//   * one wavefront owns one destination node at a time (grid-stride), so every softmax/aggregate is a
+//     wave-level segmented reduction;
+//   * edge phase: lane <-> edge.  z[u,n] = W_s[n,:] x_u + (b_s + W_d x_v + b_d)[n] is recomputed on the fly from the
+//     2..4 input floats held in registers; W_s / attn sit in LDS (broadcast reads), the destination term in a
+//     per-wave LDS row;
+//   * the aggregate is taken in INPUT space (Appendix A.3 ii): sum_u a_uv el[u] = W_s (sum_u a_uv x_u) + b_s, so only
+//     nh*F floats per destination are reduced across lanes;
+//   * channel phase: lane <-> output channel, coalesced row stores of out[v, 0..H).
+// Backward produces parameter gradients only (observations are leaves), accumulates them in registers per wave
+// (lane <-> channel), folds the 4 waves of a workgroup in fixed order through LDS and leaves one partial row per
+// workgroup; a second launch sums the rows in fixed order (deterministic, no float atomics).
+#include "common.h"
+
+namespace uavgnn {
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kThreads = kWave * kWavesPerBlock;
+
+template <int FS>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&x)[FS]);
+template <>
+__device__ __forceinline__ void load_row<4>(const float* __restrict__ p, float (&x)[4]) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+}
+template <>
+__device__ __forceinline__ void load_row<2>(const float* __restrict__ p, float (&x)[2]) {
+  const float2 t = *reinterpret_cast<const float2*>(p);
+  x[0] = t.x; x[1] = t.y;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int FS, int NH, int D>
+__global__ __launch_bounds__(kThreads) void gatv2_fwd_kernel(
+    const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off, int N,
+    const float* __restrict__ W_s, const float* __restrict__ b_s, const float* __restrict__ W_d,
+    const float* __restrict__ b_d, const float* __restrict__ attn, const float* __restrict__ W_r,
+    const float* __restrict__ b_r, float slope, float* __restrict__ out, int ld_out, float* __restrict__ a_save) {
+  constexpr int H = NH * D;
+  constexpr int J = (H + kWave - 1) / kWave;
+  __shared__ float sW[H * FS];
+  __shared__ float sAttn[H];
+  __shared__ float sC[kWavesPerBlock][H];
+  __shared__ float sS[kWavesPerBlock][NH * FS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  for (int i = tid; i < H * FS; i += kThreads) sW[i] = W_s[i];
+  for (int i = tid; i < H; i += kThreads) sAttn[i] = attn[i];
+
+  float wd0[J], wd1[J], bc[J], wr0[J], wr1[J], br[J], bs[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int n = lane + kWave * j;
+    const bool ok = n < H;
+    wd0[j] = ok ? W_d[n * 2 + 0] : 0.f;
+    wd1[j] = ok ? W_d[n * 2 + 1] : 0.f;
+    bs[j] = ok ? b_s[n] : 0.f;
+    bc[j] = ok ? b_d[n] + bs[j] : 0.f;
+    wr0[j] = ok ? W_r[n * 2 + 0] : 0.f;
+    wr1[j] = ok ? W_r[n * 2 + 1] : 0.f;
+    br[j] = (ok && b_r != nullptr) ? b_r[n] : 0.f;
+  }
+  __syncthreads();
+
+  float* __restrict__ cw = sC[wave];
+  float* __restrict__ sw = sS[wave];
+
+  for (int v = blockIdx.x * kWavesPerBlock + wave; v < N; v += gridDim.x * kWavesPerBlock) {
+    const float xv0 = x_dst[2 * v], xv1 = x_dst[2 * v + 1];
+    const int e0 = seg_off[v];
+    const int deg = seg_off[v + 1] - e0;
+
+    float res[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int n = lane + kWave * j;
+      res[j] = fmaf(wr1[j], xv1, fmaf(wr0[j], xv0, br[j]));
+      if (n < H) cw[n] = fmaf(wd1[j], xv1, fmaf(wd0[j], xv0, bc[j]));
+    }
+    float* __restrict__ orow = out + static_cast<size_t>(v) * ld_out;
+    if (deg == 0) {  // allow_zero_in_degree: aggregate is 0, only residual + ReLU (KAT 1)
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int n = lane + kWave * j;
+        if (n < H) orow[n] = fmaxf(res[j], 0.f);
+      }
+      continue;
+    }
+    wave_sync();
+
+    // ---- edge phase: lane-local online softmax state per head -----------------------------------------------
+    float m[NH], den[NH], s[NH][FS];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      m[k] = -INFINITY;
+      den[k] = 0.f;
+#pragma unroll
+      for (int f = 0; f < FS; ++f) s[k][f] = 0.f;
+    }
+    for (int base = 0; base < deg; base += kWave) {
+      const bool valid = base + lane < deg;
+      const int u = e0 + base + lane;
+      float x[FS];
+      if (valid) {
+        load_row<FS>(x_src + static_cast<size_t>(u) * FS, x);
+      } else {
+#pragma unroll
+        for (int f = 0; f < FS; ++f) x[f] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) {
+          const int n = k * D + d;
+          float z = cw[n];
+#pragma unroll
+          for (int f = 0; f < FS; ++f) z = fmaf(sW[n * FS + f], x[f], z);
+          const float lz = z > 0.f ? z : slope * z;
+          acc = fmaf(sAttn[n], lz, acc);
+        }
+        if (valid) {
+          if (a_save != nullptr) a_save[static_cast<size_t>(u) * NH + k] = acc;  // raw score, normalised below
+          const float mn = fmaxf(m[k], acc);
+          const float sc = expf(m[k] - mn);  // exp(-inf) = 0 on the first edge
+          const float p = expf(acc - mn);
+          den[k] = fmaf(den[k], sc, p);
+#pragma unroll
+          for (int f = 0; f < FS; ++f) s[k][f] = fmaf(s[k][f], sc, p * x[f]);
+          m[k] = mn;
+        }
+      }
+    }
+    // ---- combine lanes: segment softmax + input-space aggregate --------------------------------------------
+    float mx[NH], inv[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      mx[k] = wave_max(m[k]);
+      const float sc = (m[k] == -INFINITY) ? 0.f : expf(m[k] - mx[k]);
+      const float dn = wave_sum(den[k] * sc);
+      inv[k] = 1.f / dn;
+#pragma unroll
+      for (int f = 0; f < FS; ++f) {
+        const float t = wave_sum(s[k][f] * sc);
+        if (lane == 0) sw[k * FS + f] = t * inv[k];
+      }
+    }
+    if (a_save != nullptr) {
+      for (int base = 0; base < deg; base += kWave) {
+        if (base + lane < deg) {
+          float* ap = a_save + static_cast<size_t>(e0 + base + lane) * NH;
+#pragma unroll
+          for (int k = 0; k < NH; ++k) ap[k] = expf(ap[k] - mx[k]) * inv[k];
+        }
+      }
+    }
+    wave_sync();
+    // ---- channel phase: project the aggregate once per destination, add residual, ReLU -----------------------
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int n = lane + kWave * j;
+      if (n < H) {
+        const int k = n / D;
+        float agg = bs[j];
+#pragma unroll
+        for (int f = 0; f < FS; ++f) agg = fmaf(sW[n * FS + f], sw[k * FS + f], agg);
+        orow[n] = fmaxf(agg + res[j], 0.f);
+      }
+    }
+    wave_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Partial-gradient row layout (floats): dW_s[H*FS] | db_s[H] | dW_d[2H] | db_d[H] | dattn[H] | dW_r[2H] | db_r[H]
+template <int FS>
+__host__ __device__ constexpr int partial_len(int H) { return H * (FS + 8); }
+
+template <int FS, int NH, int D>
+__global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
+    const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off, int N,
+    const float* __restrict__ W_s, const float* __restrict__ b_s, const float* __restrict__ W_d,
+    const float* __restrict__ b_d, const float* __restrict__ attn, float slope, const float* __restrict__ out,
+    const float* __restrict__ d_out, int ld_out, const float* __restrict__ a_save, float* __restrict__ partial) {
+  constexpr int H = NH * D;
+  constexpr int J = (H + kWave - 1) / kWave;
+  constexpr int KF = NH * FS;
+  static_assert(KF <= kWave && (kWave % KF) == 0, "nh*F_src must divide 64");
+  constexpr int PARTS = kWave / KF;
+  constexpr int P = partial_len<FS>(H);
+  constexpr int ES = FS + NH;  // staged floats per edge: x[FS], de[NH]
+
+  __shared__ float sW[H * FS];
+  __shared__ float sG[kWavesPerBlock][H];
+  __shared__ float sGk[kWavesPerBlock][KF];
+  __shared__ float sSb[kWavesPerBlock][KF];
+  __shared__ float sE[kWavesPerBlock][kWave * ES];
+  __shared__ float sRed[P];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  for (int i = tid; i < H * FS; i += kThreads) sW[i] = W_s[i];
+
+  float Ws[J][FS], att[J], wd0[J], wd1[J], bc[J];
+  int kj[J];
+  float aWs[J][FS], abs_[J], aWd0[J], aWd1[J], abd[J], aatt[J], aWr0[J], aWr1[J], abr[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int n = lane + kWave * j;
+    const bool ok = n < H;
+    kj[j] = ok ? n / D : 0;
+#pragma unroll
+    for (int f = 0; f < FS; ++f) {
+      Ws[j][f] = ok ? W_s[n * FS + f] : 0.f;
+      aWs[j][f] = 0.f;
+    }
+    att[j] = ok ? attn[n] : 0.f;
+    wd0[j] = ok ? W_d[n * 2 + 0] : 0.f;
+    wd1[j] = ok ? W_d[n * 2 + 1] : 0.f;
+    bc[j] = ok ? b_d[n] + b_s[n] : 0.f;
+    abs_[j] = aWd0[j] = aWd1[j] = abd[j] = aatt[j] = aWr0[j] = aWr1[j] = abr[j] = 0.f;
+  }
+  __syncthreads();
+
+  float* __restrict__ gw = sG[wave];
+  float* __restrict__ gk = sGk[wave];
+  float* __restrict__ sb = sSb[wave];
+  float* __restrict__ ew = sE[wave];
+
+  for (int v = blockIdx.x * kWavesPerBlock + wave; v < N; v += gridDim.x * kWavesPerBlock) {
+    const float xv0 = x_dst[2 * v], xv1 = x_dst[2 * v + 1];
+    const int e0 = seg_off[v];
+    const int deg = seg_off[v + 1] - e0;
+    const float* __restrict__ orow = out + static_cast<size_t>(v) * ld_out;
+    const float* __restrict__ grow = d_out + static_cast<size_t>(v) * ld_out;
+
+    float g[J], c[J], der[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int n = lane + kWave * j;
+      g[j] = (n < H && orow[n] > 0.f) ? grow[n] : 0.f;  // ReLU mask
+      aWr0[j] = fmaf(g[j], xv0, aWr0[j]);
+      aWr1[j] = fmaf(g[j], xv1, aWr1[j]);
+      abr[j] += g[j];
+      c[j] = fmaf(wd1[j], xv1, fmaf(wd0[j], xv0, bc[j]));
+      der[j] = 0.f;
+    }
+    if (deg == 0) continue;
+
+    // G[k][f] = sum_d g[k,d] W_s[k,d,f]   (d a_uv = G[k].x_u up to a per-destination constant that cancels)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int n = lane + kWave * j;
+      if (n < H) gw[n] = g[j];
+    }
+    wave_sync();
+    {
+      const int kf = lane / PARTS, part = lane % PARTS;
+      const int k = kf / FS, f = kf % FS;
+      float gp = 0.f;
+      for (int d = part; d < D; d += PARTS) {
+        const int n = k * D + d;
+        gp = fmaf(gw[n], sW[n * FS + f], gp);
+      }
+#pragma unroll
+      for (int o = PARTS / 2; o > 0; o >>= 1) gp += __shfl_xor(gp, o);
+      if (part == 0) gk[kf] = gp;
+    }
+    // sbar[k][f] = sum_u a_uv x_u[f]
+    {
+      float acc[NH][FS];
+#pragma unroll
+      for (int k = 0; k < NH; ++k)
+#pragma unroll
+        for (int f = 0; f < FS; ++f) acc[k][f] = 0.f;
+      for (int base = 0; base < deg; base += kWave) {
+        if (base + lane < deg) {
+          const int u = e0 + base + lane;
+          float x[FS];
+          load_row<FS>(x_src + static_cast<size_t>(u) * FS, x);
+#pragma unroll
+          for (int k = 0; k < NH; ++k) {
+            const float a = a_save[static_cast<size_t>(u) * NH + k];
+#pragma unroll
+            for (int f = 0; f < FS; ++f) acc[k][f] = fmaf(a, x[f], acc[k][f]);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NH; ++k)
+#pragma unroll
+        for (int f = 0; f < FS; ++f) {
+          const float t = wave_sum(acc[k][f]);
+          if (lane == 0) sb[k * FS + f] = t;
+        }
+    }
+    wave_sync();
+
+    for (int base = 0; base < deg; base += kWave) {
+      // stage x_u and de[u,k] = a_uv (G[k].(x_u - sbar[k])) of up to 64 edges in LDS (lane <-> edge)
+      {
+        const bool valid = base + lane < deg;
+        const int u = e0 + base + lane;
+        float x[FS];
+        float de[NH];
+        if (valid) {
+          load_row<FS>(x_src + static_cast<size_t>(u) * FS, x);
+#pragma unroll
+          for (int k = 0; k < NH; ++k) {
+            float dot = 0.f;
+#pragma unroll
+            for (int f = 0; f < FS; ++f) dot = fmaf(gk[k * FS + f], x[f] - sb[k * FS + f], dot);
+            de[k] = a_save[static_cast<size_t>(u) * NH + k] * dot;
+          }
+        } else {
+#pragma unroll
+          for (int f = 0; f < FS; ++f) x[f] = 0.f;
+#pragma unroll
+          for (int k = 0; k < NH; ++k) de[k] = 0.f;
+        }
+#pragma unroll
+        for (int f = 0; f < FS; ++f) ew[lane * ES + f] = x[f];
+#pragma unroll
+        for (int k = 0; k < NH; ++k) ew[lane * ES + FS + k] = de[k];
+      }
+      wave_sync();
+      const int cnt = min(kWave, deg - base);
+      for (int i = 0; i < cnt; ++i) {  // lane <-> channel, edge data is a broadcast LDS read
+        float xe[FS];
+#pragma unroll
+        for (int f = 0; f < FS; ++f) xe[f] = ew[i * ES + f];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const float dek = ew[i * ES + FS + kj[j]];
+          float z = c[j];
+#pragma unroll
+          for (int f = 0; f < FS; ++f) z = fmaf(Ws[j][f], xe[f], z);
+          const bool pos = z > 0.f;
+          const float lz = pos ? z : slope * z;
+          aatt[j] = fmaf(dek, lz, aatt[j]);
+          const float dz = dek * att[j] * (pos ? 1.f : slope);
+          der[j] += dz;
+#pragma unroll
+          for (int f = 0; f < FS; ++f) aWs[j][f] = fmaf(dz, xe[f], aWs[j][f]);
+        }
+      }
+      wave_sync();
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      // aggregate path: d el[u] += a_uv g  ->  dW_s += g (x) sbar[k], db_s += g (sum_u a_uv = 1)
+#pragma unroll
+      for (int f = 0; f < FS; ++f) aWs[j][f] = fmaf(g[j], sb[kj[j] * FS + f], aWs[j][f]);
+      abs_[j] += g[j] + der[j];
+      abd[j] += der[j];
+      aWd0[j] = fmaf(der[j], xv0, aWd0[j]);
+      aWd1[j] = fmaf(der[j], xv1, aWd1[j]);
+    }
+    wave_sync();
+  }
+
+  // fold the 4 waves in fixed order through LDS, then one partial row per workgroup
+  for (int w = 0; w < kWavesPerBlock; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int n = lane + kWave * j;
+        if (n < H) {
+          auto put = [&](int idx, float val) { sRed[idx] = (w == 0) ? val : sRed[idx] + val; };
+#pragma unroll
+          for (int f = 0; f < FS; ++f) put(n * FS + f, aWs[j][f]);
+          int o = H * FS;
+          put(o + n, abs_[j]);
+          o += H;
+          put(o + 2 * n, aWd0[j]);
+          put(o + 2 * n + 1, aWd1[j]);
+          o += 2 * H;
+          put(o + n, abd[j]);
+          o += H;
+          put(o + n, aatt[j]);
+          o += H;
+          put(o + 2 * n, aWr0[j]);
+          put(o + 2 * n + 1, aWr1[j]);
+          o += 2 * H;
+          put(o + n, abr[j]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* __restrict__ prow = partial + static_cast<size_t>(blockIdx.x) * P;
+  for (int i = tid; i < P; i += kThreads) prow[i] = sRed[i];
+}
+
+// Sums `rows` partial rows of length P in a fixed order: block = 64 columns x 16 row-groups.
+struct GradPtrs {
+  float* p[7];
+  int off[8];
+};
+
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, int rows, int P,
+                                                               GradPtrs gp) {
+  __shared__ float sm[16][kWave];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * kWave + lane;
+  float acc = 0.f;
+  if (col < P) {
+    int r = wave;
+    for (; r + 48 < rows; r += 64) {
+      const float a0 = partial[static_cast<size_t>(r) * P + col];
+      const float a1 = partial[static_cast<size_t>(r + 16) * P + col];
+      const float a2 = partial[static_cast<size_t>(r + 32) * P + col];
+      const float a3 = partial[static_cast<size_t>(r + 48) * P + col];
+      acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; r < rows; r += 16) acc += partial[static_cast<size_t>(r) * P + col];
+  }
+  sm[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col < P) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += sm[w][lane];
+    int seg = 0;
+#pragma unroll
+    for (int i = 1; i < 7; ++i) seg += (col >= gp.off[i]) ? 1 : 0;
+    gp.p[seg][col - gp.off[seg]] = t;
+  }
+}
+
+constexpr int kMaxBwdBlocks = 1024;
+
+inline int bwd_blocks(int N) { return capped_grid(N, kWavesPerBlock, kMaxBwdBlocks); }
+
+template <int FS, int NH, int D>
+int launch_fwd(const float* x_src, const float* x_dst, const int32_t* seg_off, int N, const float* W_s,
+               const float* b_s, const float* W_d, const float* b_d, const float* attn, const float* W_r,
+               const float* b_r, float slope, float* out, int ld_out, float* a_save, hipStream_t st) {
+  const int grid = capped_grid(N, kWavesPerBlock, 4096);
+  hipLaunchKernelGGL((gatv2_fwd_kernel<FS, NH, D>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, N, W_s,
+                     b_s, W_d, b_d, attn, W_r, b_r, slope, out, ld_out, a_save);
+  return launch_status();
+}
+
+template <int FS, int NH, int D>
+int launch_bwd(const float* x_src, const float* x_dst, const int32_t* seg_off, int N, const float* W_s,
+               const float* b_s, const float* W_d, const float* b_d, const float* attn, float slope, const float* out,
+               const float* d_out, int ld_out, const float* a_save, const GradPtrs& gp, float* ws, hipStream_t st) {
+  constexpr int H = NH * D;
+  constexpr int P = partial_len<FS>(H);
+  const int grid = bwd_blocks(N);
+  hipLaunchKernelGGL((gatv2_bwd_kernel<FS, NH, D>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, N, W_s,
+                     b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws);
+  int rc = launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + kWave - 1) / kWave), dim3(1024), 0, st, ws, grid, P, gp);
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace uavgnn
+
+using namespace uavgnn;
+
+#define UAVGNN_DISPATCH(FSV, NHV, DV, CALL)                         \
+  if (F_src == FSV && nh == NHV && D == DV) {                       \
+    constexpr int FS_ = FSV, NH_ = NHV, D_ = DV;                    \
+    (void)FS_; (void)NH_; (void)D_;                                 \
+    return CALL;                                                    \
+  }
+
+#define UAVGNN_DISPATCH_ALL(CALL)    \
+  UAVGNN_DISPATCH(4, 4, 64, CALL)    \
+  UAVGNN_DISPATCH(2, 4, 64, CALL)    \
+  UAVGNN_DISPATCH(4, 4, 16, CALL)    \
+  UAVGNN_DISPATCH(2, 4, 16, CALL)    \
+  UAVGNN_DISPATCH(4, 4, 8, CALL)     \
+  UAVGNN_DISPATCH(2, 4, 8, CALL)     \
+  UAVGNN_DISPATCH(4, 4, 32, CALL)    \
+  UAVGNN_DISPATCH(2, 4, 32, CALL)    \
+  UAVGNN_DISPATCH(4, 8, 32, CALL)    \
+  UAVGNN_DISPATCH(2, 8, 32, CALL)    \
+  UAVGNN_DISPATCH(4, 2, 64, CALL)    \
+  UAVGNN_DISPATCH(2, 2, 64, CALL)    \
+  UAVGNN_DISPATCH(4, 1, 64, CALL)    \
+  UAVGNN_DISPATCH(2, 1, 64, CALL)
+
+extern "C" int uavgnn_gatv2_fwd(const float* x_src, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
+                                int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d,
+                                const float* attn, const float* W_r, const float* b_r, int nh, int D, float slope,
+                                float* out, int ld_out, float* attn_save, uavgnn_stream_t stream) {
+  if (N < 0 || !seg_off || !x_dst || !W_s || !b_s || !W_d || !b_d || !attn || !W_r || !out || ld_out < nh * D)
+    return UAVGNN_EINVAL;
+  if (F_dst != 2) return UAVGNN_EUNSUPPORTED;
+  if (N == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  UAVGNN_DISPATCH_ALL((launch_fwd<FS_, NH_, D_>(x_src, x_dst, seg_off, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope,
+                                                 out, ld_out, attn_save, st)))
+  return UAVGNN_EUNSUPPORTED;
+}
+
+extern "C" size_t uavgnn_gatv2_bwd_workspace_bytes(int F_src, int H) {
+  return static_cast<size_t>(kMaxBwdBlocks) * static_cast<size_t>(H) * (F_src + 8) * sizeof(float);
+}
+
+extern "C" int uavgnn_gatv2_bwd(const float* x_src, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
+                                int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d,
+                                const float* attn, int nh, int D, float slope, const float* out, const float* d_out,
+                                int ld_out, const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d,
+                                float* dattn, float* dW_r, float* db_r, void* workspace, size_t workspace_bytes,
+                                uavgnn_stream_t stream) {
+  if (N <= 0 || !seg_off || !x_dst || !W_s || !b_s || !W_d || !b_d || !attn || !out || !d_out || !attn_save ||
+      !dW_s || !db_s || !dW_d || !db_d || !dattn || !dW_r || !db_r || !workspace)
+    return UAVGNN_EINVAL;
+  if (F_dst != 2) return UAVGNN_EUNSUPPORTED;
+  const int H = nh * D;
+  if (workspace_bytes < uavgnn_gatv2_bwd_workspace_bytes(F_src, H)) return UAVGNN_EWORKSPACE;
+  GradPtrs gp;
+  gp.p[0] = dW_s; gp.p[1] = db_s; gp.p[2] = dW_d; gp.p[3] = db_d; gp.p[4] = dattn; gp.p[5] = dW_r; gp.p[6] = db_r;
+  gp.off[0] = 0;
+  gp.off[1] = H * F_src;
+  gp.off[2] = gp.off[1] + H;
+  gp.off[3] = gp.off[2] + 2 * H;
+  gp.off[4] = gp.off[3] + H;
+  gp.off[5] = gp.off[4] + H;
+  gp.off[6] = gp.off[5] + 2 * H;
+  gp.off[7] = gp.off[6] + H;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* ws = static_cast<float*>(workspace);
+  UAVGNN_DISPATCH_ALL((launch_bwd<FS_, NH_, D_>(x_src, x_dst, seg_off, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out,
+                                                 ld_out, attn_save, gp, ws, st)))
+  return UAVGNN_EUNSUPPORTED;
+}

@@ -1,0 +1,387 @@
+"""``HeteroBatch``: the observation graph of the MADRQN agent as flat HBM-resident arrays.
+
+This is the input contract of the hot path.  It mirrors the part of the DGL graph API the reference touches
+ so that code written against the reference keeps working:
+
+    reference (DGL)                                     here
+    ------------------------------------------------    ------------------------------------------------
+    dgl.heterograph(data_dict, num_nodes_dict)          heterograph(data_dict, num_nodes_dict)
+    g.ndata['feat'] = {...} / g.ndata['feat']           same (dict per node type)
+    g.nodes['agent'].data['feat'] (= ...)               same
+    dgl.batch([...]) (algos/common.py:45)               batch([...])
+    dgl.merge([local_obs, comm_graph]) (env_wr.:137)    merge([...])
+    g.num_nodes('agent'), g['talk'], g.to(device)       same
+
+Layout (derived from the invariants of algos/madrqn/utils/env_wrappers.py:69-89,:139-154):
+every `gt`/`ubs` source has out-degree 1 and the edges are grouped by destination, so `seen`/`near` are ragged
+segments: ``x_gt [E_seen, 4]`` + ``seen_off [N_a + 1]`` (int32), ``x_ubs [E_near, 2]`` + ``near_off``.  Only `talk`
+is a real graph; it is kept in CSC (``talk_off``, ``talk_src``: in-edges per destination) together with its transpose
+(``t_off``, ``t_dst``, ``t_pos``) for the gather-only backward.  ``talk_eid`` maps a CSC position back to the edge id
+the reference would have used (needed only to inject per-edge Gumbel noise reproducibly).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch as th
+
+SEEN = ("gt", "seen", "agent")
+NEAR = ("ubs", "near", "agent")
+TALK = ("agent", "talk", "agent")
+SEEN_BY = ("gt", "seen-by", "agent")  # DRQN twin (algos/drqn/utils/env_wrappers.py:66)
+_REL_OF_NAME = {"seen": SEEN, "near": NEAR, "talk": TALK, "seen-by": SEEN_BY}
+_SRC_KEY = {"seen": "gt", "near": "ubs", "seen-by": "gt"}
+
+
+def _i32(x, device=None) -> th.Tensor:
+    t = x if isinstance(x, th.Tensor) else th.as_tensor(np.asarray(x))
+    t = t.to(th.int32)
+    return t.to(device) if device is not None else t
+
+
+def _offsets_from_dst(dst: th.Tensor, n: int) -> th.Tensor:
+    deg = th.bincount(dst.long(), minlength=n)
+    off = th.zeros(n + 1, dtype=th.int32, device=dst.device)
+    off[1:] = th.cumsum(deg, 0).to(th.int32)
+    return off
+
+
+def seg_ids(off: th.Tensor) -> th.Tensor:
+    n = off.numel() - 1
+    deg = (off[1:] - off[:-1]).long()
+    return th.repeat_interleave(th.arange(n, device=off.device), deg)
+
+
+class _Relation:
+    """One relation in destination-grouped (CSC) form.  ``src`` is None when src id == edge id."""
+
+    __slots__ = ("off", "src", "eid")
+
+    def __init__(self, off: th.Tensor, src: Optional[th.Tensor] = None, eid: Optional[th.Tensor] = None):
+        self.off, self.src, self.eid = off, src, eid
+
+    @property
+    def num_edges(self) -> int:
+        return int(self.off[-1]) if self.off.numel() else 0
+
+    def to(self, device):
+        mv = lambda t: None if t is None else t.to(device, non_blocking=True)  # noqa: E731
+        return _Relation(mv(self.off), mv(self.src), mv(self.eid))
+
+
+class _NodeFrames:
+    """``g.nodes[ntype].data`` accessor."""
+
+    def __init__(self, g):
+        self._g = g
+
+    def __getitem__(self, ntype):
+        g = self._g
+
+        class _V:
+            data = g._feat.setdefault(ntype, {})
+        return _V
+
+
+class _NData:
+    """``g.ndata[key]`` <-> {ntype: tensor}."""
+
+    def __init__(self, g):
+        self._g = g
+
+    def __getitem__(self, key):
+        return {nt: fr[key] for nt, fr in self._g._feat.items() if key in fr}
+
+    def __setitem__(self, key, val: Dict[str, th.Tensor]):
+        for nt, t in val.items():
+            t = th.as_tensor(t)
+            if t.shape[0] != self._g._num_nodes.get(nt, 0):
+                raise ValueError(f"feature rows ({t.shape[0]}) != number of '{nt}' nodes ({self._g._num_nodes.get(nt)})")
+            self._g._feat.setdefault(nt, {})[key] = t
+        self._g._cache.clear()
+
+
+class RelationView:
+    """``g['talk']`` - a relation slice sharing the parent's node data (what the comm blocks receive)."""
+
+    def __init__(self, parent: "HeteroBatch", etype: str):
+        self.parent, self.etype = parent, etype
+
+    def number_of_edges(self) -> int:
+        return self.parent.number_of_edges(self.etype)
+
+    num_edges = number_of_edges
+
+
+class HeteroBatch:
+    def __init__(self, num_nodes: Dict[str, int], rels: Dict[tuple, _Relation],
+                 feat: Optional[Dict[str, Dict[str, th.Tensor]]] = None, graph_off: Optional[th.Tensor] = None):
+        self._num_nodes = dict(num_nodes)
+        self._rels = dict(rels)
+        self._feat = feat if feat is not None else {}
+        self.graph_off = graph_off          # [B+1] agent-node offsets of the batched env graphs (int32) or None
+        self._cache: Dict[str, object] = {}
+
+    # ---- constructors -------------------------------------------------------------------------------------------
+    @classmethod
+    def from_arrays(cls, x_a, x_gt=None, seen_off=None, x_ubs=None, near_off=None, talk_off=None, talk_src=None,
+                    talk_eid=None, graph_off=None, x_flat=None, device=None) -> "HeteroBatch":
+        """Direct construction from segment-layout arrays (tests, benchmarks, device-side producers)."""
+        f = lambda t: None if t is None else th.as_tensor(t, dtype=th.float32).to(device)  # noqa: E731
+        x_a = f(x_a)
+        n = x_a.shape[0]
+        num_nodes, rels, feat = {"agent": n}, {}, {"agent": {"feat": x_a if x_flat is None else f(x_flat)}}
+        if seen_off is not None:
+            so = _i32(seen_off, device)
+            rels[SEEN] = _Relation(so)
+            feat["gt"] = {"feat": f(x_gt)}
+            num_nodes["gt"] = feat["gt"]["feat"].shape[0]
+        if near_off is not None:
+            no = _i32(near_off, device)
+            rels[NEAR] = _Relation(no)
+            feat["ubs"] = {"feat": f(x_ubs)}
+            num_nodes["ubs"] = feat["ubs"]["feat"].shape[0]
+        if talk_off is not None:
+            rels[TALK] = _Relation(_i32(talk_off, device), _i32(talk_src, device),
+                                   None if talk_eid is None else _i32(talk_eid, device))
+        go = None if graph_off is None else _i32(graph_off, device)
+        return cls(num_nodes, rels, feat, go)
+
+    # ---- DGL-like surface ---------------------------------------------------------------------------------------
+    @property
+    def ntypes(self):
+        return list(self._num_nodes)
+
+    @property
+    def canonical_etypes(self):
+        return list(self._rels)
+
+    def num_nodes(self, ntype: Optional[str] = None) -> int:
+        return sum(self._num_nodes.values()) if ntype is None else self._num_nodes[ntype]
+
+    number_of_nodes = num_nodes
+
+    def _canon(self, etype):
+        if isinstance(etype, tuple):
+            return etype
+        for c in self._rels:
+            if c[1] == etype:
+                return c
+        raise KeyError(etype)
+
+    def number_of_edges(self, etype=None) -> int:
+        if etype is None:
+            return sum(r.num_edges for r in self._rels.values())
+        return self._rels[self._canon(etype)].num_edges
+
+    num_edges = number_of_edges
+
+    def has_relation(self, etype: str) -> bool:
+        return any(c[1] == etype for c in self._rels)
+
+    def __getitem__(self, etype) -> RelationView:
+        self._canon(etype)
+        return RelationView(self, etype if isinstance(etype, str) else etype[1])
+
+    @property
+    def ndata(self) -> _NData:
+        return _NData(self)
+
+    @property
+    def nodes(self) -> _NodeFrames:
+        return _NodeFrames(self)
+
+    @property
+    def device(self):
+        return self._feat["agent"]["feat"].device
+
+    def to(self, device, non_blocking: bool = True) -> "HeteroBatch":
+        device = th.device(device)
+        if self.device == device:
+            return self
+        feat = {nt: {k: v.to(device, non_blocking=non_blocking) for k, v in fr.items()}
+                for nt, fr in self._feat.items()}
+        rels = {c: r.to(device) for c, r in self._rels.items()}
+        go = None if self.graph_off is None else self.graph_off.to(device)
+        return HeteroBatch(self._num_nodes, rels, feat, go)
+
+    def pin_memory(self) -> "HeteroBatch":
+        for fr in self._feat.values():
+            for k in fr:
+                fr[k] = fr[k].pin_memory()
+        return self
+
+    # ---- kernel-facing accessors --------------------------------------------------------------------------------
+    def agent_feat(self) -> th.Tensor:
+        return self._feat["agent"]["feat"]
+
+    def relation_segments(self, etype: str):
+        """(x_src in segment order [E,F] float32, seg_off [N+1] int32) of `seen` / `near` / `seen-by`."""
+        key = "seg:" + etype
+        if key not in self._cache:
+            c = self._canon(etype)
+            r = self._rels[c]
+            x = self._feat.get(c[0], {}).get("feat")
+            if x is None:
+                raise KeyError(f"no 'feat' on node type {c[0]}")
+            if r.src is not None:                      # general graphs: gather once into segment order
+                x = x.index_select(0, r.src.long())
+            self._cache[key] = (x.float().contiguous(), r.off)
+        return self._cache[key]
+
+    def talk_csc(self):
+        r = self._rels[TALK]
+        src = r.src if r.src is not None else th.arange(r.num_edges, dtype=th.int32, device=r.off.device)
+        return r.off, src
+
+    def talk_eid(self) -> Optional[th.Tensor]:
+        return self._rels[TALK].eid
+
+    def talk_transpose(self):
+        """(t_off [N+1], t_dst [E], t_pos [E]): out-edges per source, their destination and CSC position."""
+        if "talkT" not in self._cache:
+            off, src = self.talk_csc()
+            n = self._num_nodes["agent"]
+            dst = seg_ids(off)
+            order = th.sort(src.long(), stable=True)[1]
+            self._cache["talkT"] = (_offsets_from_dst(src, n), dst[order].to(th.int32).contiguous(),
+                                    order.to(th.int32).contiguous())
+        return self._cache["talkT"]
+
+    def __repr__(self):
+        e = {c[1]: r.num_edges for c, r in self._rels.items()}
+        return f"HeteroBatch(num_nodes={self._num_nodes}, num_edges={e}, device={self.device})"
+
+
+DGLGraph = HeteroBatch  # so that `isinstance(x, DGLGraph)` style dispatch (algos/common.py:44) has a target
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def heterograph(data_dict, num_nodes_dict=None) -> HeteroBatch:
+    """Counterpart of ``dgl.heterograph`` for the three relations of the reference (env_wrappers.py:75-81,:146-153)."""
+    num_nodes: Dict[str, int] = {}
+    coo = {}
+    for c, (u, v) in data_dict.items():
+        u, v = th.as_tensor(np.asarray(u), dtype=th.int64).reshape(-1), th.as_tensor(np.asarray(v), dtype=th.int64).reshape(-1)
+        coo[c] = (u, v)
+        for nt, ids in ((c[0], u), (c[2], v)):
+            num_nodes[nt] = max(num_nodes.get(nt, 0), int(ids.max()) + 1 if ids.numel() else 0)
+    if num_nodes_dict is not None:
+        for nt, k in num_nodes_dict.items():
+            num_nodes[nt] = int(k)
+    rels = {}
+    for c, (u, v) in coo.items():
+        n_dst = num_nodes[c[2]]
+        order = th.sort(v, stable=True)[1]
+        su = u[order]
+        off = _offsets_from_dst(v, n_dst)
+        ident = bool(th.equal(su, th.arange(su.numel())))
+        if c == TALK:
+            rels[c] = _Relation(off, su.to(th.int32), order.to(th.int32))
+        else:
+            rels[c] = _Relation(off, None if ident else su.to(th.int32))
+    return HeteroBatch(num_nodes, rels, {})
+
+
+def batch(graphs: Sequence[HeteroBatch]) -> HeteroBatch:
+    """Counterpart of ``dgl.batch`` (algos/common.py:45, env_wrappers.py:67): disjoint union.  Pure concatenation plus
+    a running offset, because every array is already grouped by destination."""
+    g0 = graphs[0]
+    ntypes = list(g0._num_nodes)
+    num_nodes = {nt: sum(g._num_nodes.get(nt, 0) for g in graphs) for nt in ntypes}
+    feat: Dict[str, Dict[str, th.Tensor]] = {}
+    for nt in ntypes:
+        keys = set()
+        for g in graphs:
+            keys |= set(g._feat.get(nt, {}).keys())
+        feat[nt] = {k: th.cat([g._feat[nt][k] for g in graphs if k in g._feat.get(nt, {})], 0) for k in keys}
+    rels = {}
+    for c in g0._rels:
+        offs, srcs, eids = [], [], []
+        e_base = 0
+        s_base = 0
+        need_src = any(g._rels[c].src is not None for g in graphs)
+        has_eid = all(g._rels[c].eid is not None for g in graphs)
+        for i, g in enumerate(graphs):
+            r = g._rels[c]
+            offs.append((r.off if i == 0 else r.off[1:]) + e_base)
+            if need_src:
+                s = r.src if r.src is not None else th.arange(r.num_edges, dtype=th.int32, device=r.off.device)
+                srcs.append(s + s_base)
+            if has_eid:
+                eids.append(r.eid + e_base)
+            e_base += r.num_edges
+            s_base += g._num_nodes.get(c[0], 0)
+        rels[c] = _Relation(th.cat(offs).to(th.int32), th.cat(srcs).to(th.int32) if need_src else None,
+                            th.cat(eids).to(th.int32) if has_eid and eids else None)
+    counts = []
+    for g in graphs:
+        if g.graph_off is not None:
+            counts += (g.graph_off[1:] - g.graph_off[:-1]).tolist()
+        else:
+            counts.append(g._num_nodes.get("agent", 0))
+    go = th.zeros(len(counts) + 1, dtype=th.int32)
+    go[1:] = th.cumsum(th.as_tensor(counts, dtype=th.int64), 0).to(th.int32)
+    return HeteroBatch(num_nodes, rels, feat, go.to(g0.device) if g0._feat.get("agent") else go)
+
+
+def merge(graphs: Sequence[HeteroBatch]) -> HeteroBatch:
+    """Counterpart of ``dgl.merge([local_obs, comm_graph])`` (env_wrappers.py:137): union of the edge sets over a
+    shared node set.  Each relation is taken from the graph that carries its edges (the reference never merges two
+    non-empty copies of one relation)."""
+    ntypes = list(graphs[0]._num_nodes)
+    num_nodes = {nt: max(g._num_nodes.get(nt, 0) for g in graphs) for nt in ntypes}
+    rels = {}
+    for c in graphs[0]._rels:
+        holders = [g for g in graphs if c in g._rels and g._rels[c].num_edges > 0]
+        if len(holders) > 1:
+            raise NotImplementedError("merge of two non-empty copies of one relation")
+        if holders:
+            rels[c] = holders[0]._rels[c]
+        else:
+            n_dst = num_nodes[c[2]]
+            rels[c] = _Relation(th.zeros(n_dst + 1, dtype=th.int32),
+                                th.zeros(0, dtype=th.int32) if c == TALK else None,
+                                th.zeros(0, dtype=th.int32) if c == TALK else None)
+    feat: Dict[str, Dict[str, th.Tensor]] = {nt: {} for nt in ntypes}
+    for g in graphs:
+        for nt in ntypes:
+            if g._num_nodes.get(nt, 0) == num_nodes[nt]:
+                for k, v in g._feat.get(nt, {}).items():
+                    feat[nt].setdefault(k, v)
+    return HeteroBatch(num_nodes, rels, feat)
+
+
+def cat(data_list: List):
+    """Counterpart of ``algos.common.cat`` (common.py:40-47)."""
+    if isinstance(data_list[0], th.Tensor):
+        return th.cat(data_list)
+    if isinstance(data_list[0], HeteroBatch):
+        return batch(data_list)
+    raise TypeError("Unrecognised observation type.")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def from_obs_dicts(obs: Sequence[dict], d_u2u=None, r_comm: float = np.inf, with_comm: bool = True) -> HeteroBatch:
+    """One env step -> HeteroBatch, vectorised counterpart of ``GraphObservation.local_observation`` +
+    ``MultiUbsCoverageWrapper.build_comm_graph`` + ``dgl.merge`` (env_wrappers.py:65-89,:122-154).
+
+    obs: per-agent dicts {agent [2], ubs [n-1,3], gt [M,5]} with column 0 = visibility flag (mubs_cov.py:215-242).
+    talk edges i->j exist iff d_u2u[i,j] <= r_comm, self loops included (env_wrappers.py:140-144)."""
+    n = len(obs)
+    gt = np.stack([np.asarray(o["gt"], dtype=np.float32) for o in obs])       # [n, M, 5]
+    ub = np.stack([np.asarray(o["ubs"], dtype=np.float32) for o in obs])      # [n, n-1, 3]
+    xa = np.stack([np.asarray(o["agent"], dtype=np.float32) for o in obs])
+    mg, mu = gt[:, :, 0] == 1, ub[:, :, 0] == 1
+    seen_off = np.concatenate([[0], np.cumsum(mg.sum(1))]).astype(np.int32)
+    near_off = np.concatenate([[0], np.cumsum(mu.sum(1))]).astype(np.int32)
+    kw = dict(x_a=xa, x_gt=gt[mg][:, 1:], seen_off=seen_off, x_ubs=ub[mu][:, 1:], near_off=near_off,
+              graph_off=[0, n])
+    if with_comm:
+        adj = np.asarray(d_u2u) <= r_comm                                    # adj[i, j]: edge i -> j
+        eid_of = np.cumsum(adj.reshape(-1)).reshape(n, n) - 1                 # reference edge id (i-major order)
+        src, dst = np.nonzero(adj.T)[1], np.nonzero(adj.T)[0]                 # grouped by destination j
+        kw.update(talk_off=np.concatenate([[0], np.cumsum(adj.sum(0))]).astype(np.int32),
+                  talk_src=src.astype(np.int32), talk_eid=eid_of[src, dst].astype(np.int32))
+    return HeteroBatch.from_arrays(**kw)

@@ -1,0 +1,176 @@
+"""``torch.autograd.Function`` wrappers over the C-ABI kernels (include/uavgnn.h).
+
+Each op checks dtype / contiguity / device, takes PyTorch's current HIP stream and calls ``libuavgnn.so`` through
+ctypes.  No op has a CPU or eager-PyTorch fallback: CPU tensors raise ``UavGnnError``.
+"""
+from __future__ import annotations
+
+import torch as th
+
+from . import _lib as L
+
+NEG_SLOPE = 0.2  # DGL GATv2Conv default, not overridden at gnn_agents.py:93-96
+
+
+class _HeteroGATv2(th.autograd.Function):
+    """K1 over R relations that share the destination nodes.  Returns [N, R*H]: relation i owns columns [i*H, (i+1)*H)
+    (so the th.cat of gnn_agents.py:106 never happens).  Per relation the flat argument list carries
+    x_src, seg_off, attn, W_s, b_s, W_d, b_d, W_r, b_r  (b_r may be None)."""
+
+    PER_REL = 9
+
+    @staticmethod
+    def forward(ctx, x_dst, nh, *rel_args):
+        R = len(rel_args) // _HeteroGATv2.PER_REL
+        L.require_gpu(x_dst, *[t for t in rel_args if isinstance(t, th.Tensor)])
+        x_dst = L.f32c(x_dst)
+        N = x_dst.shape[0]
+        H = rel_args[3].shape[0]
+        D = H // nh
+        out = th.empty((N, R * H), dtype=th.float32, device=x_dst.device)
+        saved, meta = [x_dst], []
+        for i in range(R):
+            x_src, seg_off, attn, W_s, b_s, W_d, b_d, W_r, b_r = rel_args[i * 9:(i + 1) * 9]
+            x_src = L.f32c(x_src)
+            FS = W_s.shape[1]
+            if W_s.shape[0] != H or x_src.shape[0] and x_src.shape[1] != FS:
+                raise L.UavGnnError("hetero_gatv2: inconsistent relation shapes")
+            p = [L.f32c(t.detach()) for t in (W_s, b_s, W_d, b_d, attn, W_r)]
+            b_r_c = None if b_r is None else L.f32c(b_r.detach())
+            need = any(ctx.needs_input_grad[2 + i * 9 + 2: 2 + i * 9 + 9])
+            a_save = th.empty((max(x_src.shape[0], 1), nh), dtype=th.float32, device=x_dst.device) if need else None
+            rc = L.lib().uavgnn_gatv2_fwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off), N,
+                                          *[L.ptr(t) for t in p], L.ptr(b_r_c), nh, D, NEG_SLOPE,
+                                          out.data_ptr() + 4 * i * H, R * H, L.ptr(a_save), L.stream())
+            L.check(rc, "uavgnn_gatv2_fwd")
+            saved += [x_src, seg_off, *p, a_save if a_save is not None else x_dst]
+            meta.append((FS, need, b_r is not None))
+        ctx.nh, ctx.meta, ctx.H = nh, meta, H
+        ctx.save_for_backward(*saved, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        saved = ctx.saved_tensors
+        x_dst, out = saved[0], saved[-1]
+        nh, H = ctx.nh, ctx.H
+        R = len(ctx.meta)
+        N, dev = x_dst.shape[0], x_dst.device
+        d_out = L.f32c(d_out)
+        grads = [None, None]
+        for i, (FS, need, has_br) in enumerate(ctx.meta):
+            x_src, seg_off, W_s, b_s, W_d, b_d, attn, W_r, a_save = saved[1 + i * 9: 1 + (i + 1) * 9]
+            if not need or N == 0:
+                grads += [None] * 9
+                continue
+            g = [th.empty_like(W_s), th.empty_like(b_s), th.empty_like(W_d), th.empty_like(b_d),
+                 th.empty_like(attn), th.empty_like(W_r), th.empty(H, dtype=th.float32, device=dev)]
+            ws_bytes = L.lib().uavgnn_gatv2_bwd_workspace_bytes(FS, H)
+            ws = th.empty(ws_bytes // 4, dtype=th.float32, device=dev)
+            rc = L.lib().uavgnn_gatv2_bwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off), N,
+                                          L.ptr(W_s), L.ptr(b_s), L.ptr(W_d), L.ptr(b_d), L.ptr(attn), nh, H // nh,
+                                          NEG_SLOPE, out.data_ptr() + 4 * i * H, d_out.data_ptr() + 4 * i * H, R * H,
+                                          L.ptr(a_save), *[L.ptr(t) for t in g], ws.data_ptr(), ws_bytes, L.stream())
+            L.check(rc, "uavgnn_gatv2_bwd")
+            dW_s, db_s, dW_d, db_d, dattn, dW_r, db_r = g
+            grads += [None, None, dattn, dW_s, db_s, dW_d, db_d, dW_r, db_r if has_br else None]
+        return tuple(grads)
+
+
+def hetero_gatv2(x_dst, nh, relations):
+    """relations: list of (x_src [E,F], seg_off [N+1] int32, conv) with conv exposing attn, fc_src, fc_dst, res_fc."""
+    flat = []
+    for x_src, seg_off, conv in relations:
+        flat += [x_src, seg_off, conv.attn, conv.fc_src.weight, conv.fc_src.bias, conv.fc_dst.weight,
+                 conv.fc_dst.bias, conv.res_fc.weight, conv.res_fc.bias]
+    return _HeteroGATv2.apply(x_dst, nh, *flat)
+
+
+class _TalkAttention(th.autograd.Function):
+    """K3b.  c_v = sum_u softmax_u(<s_u, q_v> * scale) v_u over the talk relation; s = q = None -> mean."""
+
+    @staticmethod
+    def forward(ctx, s, q, v, talk_off, talk_src, t_off, t_dst, t_pos, scale):
+        L.require_gpu(v, talk_off, talk_src, s, q)
+        N, M = v.shape
+        K = 0 if s is None else s.shape[1]
+        for t in (s, q, v):
+            if t is not None and (t.dtype != th.float32 or t.stride(1) != 1):
+                raise L.UavGnnError("talk_attention: float32 row-major inputs required")
+        E = talk_src.shape[0]
+        c = th.empty((N, M), dtype=th.float32, device=v.device)
+        a_save = th.empty(max(E, 1), dtype=th.float32, device=v.device)
+        rc = L.lib().uavgnn_talk_attn_fwd(L.ptr(s), 0 if s is None else s.stride(0), L.ptr(q),
+                                          0 if q is None else q.stride(0), L.ptr(v), v.stride(0), K, M,
+                                          L.ptr(talk_off), L.ptr(talk_src), N, float(scale), c.data_ptr(), c.stride(0),
+                                          a_save.data_ptr(), L.stream())
+        L.check(rc, "uavgnn_talk_attn_fwd")
+        ctx.scale, ctx.uniform = float(scale), s is None
+        ctx.save_for_backward(*(t for t in (s, q) if t is not None), v, talk_off, talk_src, t_off, t_dst, t_pos, a_save)
+        return c
+
+    @staticmethod
+    def backward(ctx, d_c):
+        if ctx.uniform:
+            v, talk_off, talk_src, t_off, t_dst, t_pos, a_save = ctx.saved_tensors
+            s = q = None
+        else:
+            s, q, v, talk_off, talk_src, t_off, t_dst, t_pos, a_save = ctx.saved_tensors
+        N, M = v.shape
+        K = 0 if s is None else s.shape[1]
+        d_c = d_c.contiguous()
+        d_v = th.empty((N, M), dtype=th.float32, device=v.device)
+        d_s = d_q = de = None
+        if not ctx.uniform:
+            d_s = th.empty((N, K), dtype=th.float32, device=v.device)
+            d_q = th.empty((N, K), dtype=th.float32, device=v.device)
+            de = th.empty_like(a_save)
+        rc = L.lib().uavgnn_talk_attn_bwd(L.ptr(s), 0 if s is None else s.stride(0), L.ptr(q),
+                                          0 if q is None else q.stride(0), L.ptr(v), v.stride(0), K, M,
+                                          L.ptr(talk_off), L.ptr(talk_src), L.ptr(t_off), L.ptr(t_dst), L.ptr(t_pos), N,
+                                          ctx.scale, a_save.data_ptr(), d_c.data_ptr(), d_c.stride(0), L.ptr(d_s),
+                                          K, L.ptr(d_q), K, d_v.data_ptr(), M, L.ptr(de), L.stream())
+        L.check(rc, "uavgnn_talk_attn_bwd")
+        return d_s, d_q, d_v, None, None, None, None, None, None
+
+
+def talk_attention(s, q, v, g, scale=1.0):
+    """g: HeteroBatch carrying the talk relation."""
+    off, src = g.talk_csc()
+    t_off, t_dst, t_pos = g.talk_transpose()
+    return _TalkAttention.apply(s, q, v, off, src, t_off, t_dst, t_pos, scale)
+
+
+class _GruGates(th.autograd.Function):
+    """K4 pointwise half: h' from the two [N,3H] pre-activation blocks of a GRU cell."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, h):
+        L.require_gpu(gi, gh, h)
+        gi, gh, h = L.f32c(gi), L.f32c(gh), L.f32c(h)
+        N, H = h.shape
+        h_out = th.empty_like(h)
+        L.check(L.lib().uavgnn_gru_gates_fwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), N, H, h_out.data_ptr(),
+                                             L.stream()), "uavgnn_gru_gates_fwd")
+        ctx.save_for_backward(gi, gh, h)
+        return h_out
+
+    @staticmethod
+    def backward(ctx, d_hout):
+        gi, gh, h = ctx.saved_tensors
+        N, H = h.shape
+        d_hout = L.f32c(d_hout)
+        d_gi, d_gh, d_h = th.empty_like(gi), th.empty_like(gh), th.empty_like(h)
+        L.check(L.lib().uavgnn_gru_gates_bwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), d_hout.data_ptr(), N, H,
+                                             d_gi.data_ptr(), d_gh.data_ptr(), d_h.data_ptr(), L.stream()),
+                "uavgnn_gru_gates_bwd")
+        return d_gi, d_gh, d_h
+
+
+def gru_gates(gi, gh, h):
+    return _GruGates.apply(gi, gh, h)
+
+
+def disc_comm_aggregate(logits, gumbel, g, tau=0.5):
+    """Hard Gumbel-softmax messages + OR aggregation of DiscreteComm (gnn_agents.py:166-178)."""
+    raise NotImplementedError("DiscreteComm kernel (SURVEY 8f row f4) is not built yet")
