@@ -72,9 +72,9 @@ def test_exp3_sizes_vs_oracle(dist, talk, B, n, M):
     wq, wh = th.randn(B * n, 9, generator=gen), th.randn(B * n, 256, generator=gen) / 16
 
     def oracle(dtype):
-        pp = {k: v.to(dtype).requires_grad_(True) for k, v in p64.items()}
+        pp = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in p64.items()}
         gg = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in g.items()}
-        hh = h.to(dtype).requires_grad_(True)
+        hh = h.detach().clone().to(dtype).requires_grad_(True)
         q, h2 = R.gnn_agent_forward(gg, hh, pp, EXP3)
         gr = th.autograd.grad(_loss(q, h2, wq.to(dtype), wh.to(dtype)), list(pp.values()) + [hh])
         return q, h2, dict(zip(list(pp) + ["__h__"], gr))

@@ -11,8 +11,16 @@ from oracle import restatement as R
 from oracle.closed_form import closed_form_tensor as cf
 from tests.util import assert_close
 
-th.set_default_dtype(th.float64)
 NH, D, FS = 4, 8, 4
+
+
+@pytest.fixture(autouse=True)
+def _float64_default():
+    """float64 for this module only (a process-wide default would leak into the GPU tests collected alongside)."""
+    old = th.get_default_dtype()
+    th.set_default_dtype(th.float64)
+    yield
+    th.set_default_dtype(old)
 
 
 def gat_params(fs=FS, nh=NH, d=D, seed=0.0):
