@@ -1,0 +1,185 @@
+"""Batched, device-resident counterpart of the reference's ``MultiAgentQLearner`` (algos/madrqn/learner.py:14-201).
+
+The reference's learner is a Python host harness around one env and a deque of DGLGraphs; it is not shipped.  This is
+the build's own caller of the hot path, reproducing the same call pattern and numerics so that the fixtures captured
+from the reference's ``update()`` pin it:
+
+  * ``act``    - ``policy_net(obs, h)`` under ``no_grad`` -> argmax, epsilon-greedy with ONE draw per team
+                 (learner.py:69-80), vectorised over B environments and without a device->host sync;
+  * ``update`` - the 2T+1-forward BPTT pattern with stored-state initialisation (learner.py:110-128), gather of
+                 Q(s,a), double-Q target, MSE over [T, B, n] (learner.py:134-154), ``clip_grad_value_(.., 1)``,
+                 AdamW, polyak averaging of the target net (learner.py:157-166).
+
+Data parallelism: one process per GPU, independent env batches per rank, replicated parameters; the ONLY
+exchange is one all-reduce (RCCL over xGMI; ``nccl`` backend) of the Q-network gradients, kept in ONE flat buffer
+(632 425 floats = 2.53 MB for exp3-TarMAC) so it is a single collective call, averaged BEFORE the element-wise clip
+(so the result equals the single-GPU step on the concatenated batch).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch as th
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .agents import REGISTRY as agent_REGISTRY
+
+
+class FlatGradBuffer:
+    """All gradients of a module as views into one contiguous fp32 buffer (one collective instead of one per tensor;
+    the reference's unused helper all-reduces per parameter: utils/mpi_pytorch.py:19-26)."""
+
+    def __init__(self, params: List[th.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = th.zeros(n, dtype=th.float32, device=dev)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+        o = 0
+        for p in self.params:   # re-attach (an optimizer's zero_grad(set_to_none=True) would detach the views)
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def all_reduce_mean_(self, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(dist.get_world_size(group))
+
+
+def broadcast_parameters(module: th.nn.Module, src: int = 0, group=None) -> None:
+    """Start-up sync (counterpart of the reference's unused ``sync_params``, utils/mpi_pytorch.py:29-35): one broadcast
+    of a flat copy of every parameter and buffer."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    tensors = [t.data for t in list(module.parameters()) + list(module.buffers())]
+    flat = th.cat([t.reshape(-1) for t in tensors])
+    dist.broadcast(flat, src=src, group=group)
+    o = 0
+    for t in tensors:
+        t.copy_(flat[o:o + t.numel()].view_as(t))
+        o += t.numel()
+
+
+class MultiAgentQLearner:
+    def __init__(self, env_info: dict, args, process_group=None):
+        self.args = args
+        self.device = th.device(args.device)
+        self.obs_shape = env_info["obs_shape"]
+        self.n_actions = env_info["n_actions"]
+        self.n_agents = env_info["n_agents"]
+        self.group = process_group
+
+        self.policy_net = self._build_agent().to(self.device)
+        self.target_net = self._build_agent().to(self.device)
+        broadcast_parameters(self.policy_net, 0, process_group)
+        self.target_net.load_state_dict(self.policy_net.state_dict())
+        self.target_net.eval()
+        for p in self.target_net.parameters():
+            p.requires_grad_(False)
+        self.params = list(self.policy_net.parameters())
+        if getattr(args, "mixer", False):
+            raise NotImplementedError("QMixer is outside the hot path (SURVEY 2 row 5); every launcher sets mixer=False")
+
+        ep_limit = env_info.get("episode_limit")
+        self.max_seq_len = args.max_seq_len if getattr(args, "max_seq_len", None) is not None else ep_limit
+        self.gamma, self.polyak = args.gamma, args.polyak
+        self.batch_size = getattr(args, "batch_size", None)
+        self.double_q = args.double_q
+        self.optimizer = th.optim.AdamW(self.params, lr=args.lr)
+        self.grads = FlatGradBuffer(self.params)
+        self._gen = th.Generator(device=self.device)
+        self._gen.manual_seed(int(getattr(args, "seed", 0)) + 7919 * (dist.get_rank() if dist.is_initialized() else 0))
+
+    def _build_agent(self):
+        return agent_REGISTRY["gnn"](self.obs_shape, self.n_actions, self.args)   # learner.py:62-67 ('gnn' arm)
+
+    def init_hidden(self, batch_size: int = 1) -> th.Tensor:
+        return self.policy_net.init_hidden().expand(self.n_agents * batch_size, -1).to(self.device)
+
+    # ---- rollout --------------------------------------------------------------------------------------------------
+    @th.no_grad()
+    def act(self, obs, h: th.Tensor, eps_thres: float):
+        """obs: HeteroBatch of B envs (B*n agents).  Returns (acts [B*n] int64 on device, h').  One epsilon draw per
+        team, as in learner.py:75-78."""
+        obs, h = obs.to(self.device), h.to(self.device)
+        logits, h = self.policy_net(obs, h)
+        greedy = logits.argmax(1)
+        B = greedy.shape[0] // self.n_agents
+        explore = th.rand(B, device=self.device, generator=self._gen) <= eps_thres
+        rand = th.randint(self.n_actions, greedy.shape, device=self.device, generator=self._gen)
+        acts = th.where(explore.repeat_interleave(self.n_agents), rand, greedy)
+        return acts, h
+
+    # ---- training -------------------------------------------------------------------------------------------------
+    def loss(self, batch: Dict) -> tuple:
+        """Forward part of ``update`` (learner.py:110-154).  batch: obs (list of T+1 HeteroBatch of B envs each),
+        h0 / h1 [B*n, H] (stored hidden states of the first two steps), acts [T, B*n, 1] int64,
+        rews [T, B, n or 1], dones [T, B, 1]."""
+        obs = batch["obs"]
+        T = len(obs) - 1
+        h, h_targ = batch["h0"], batch["h1"]
+        agent_out, target_out = [], []
+        for t in range(T):
+            logits, h = self.policy_net(obs[t], h)
+            agent_out.append(logits)
+            with th.no_grad():
+                nxt, h_targ = self.target_net(obs[t + 1], h_targ)
+                target_out.append(nxt)
+        logits, h = self.policy_net(obs[T], h)
+        agent_out.append(logits)
+        agent_out, target_out = th.stack(agent_out), th.stack(target_out)
+
+        qvals = agent_out[:-1].gather(2, batch["acts"])
+        if self.double_q:
+            next_acts = agent_out[1:].detach().argmax(2, keepdim=True)
+            next_vals = target_out.gather(2, next_acts)
+        else:
+            next_vals = target_out.max(2, keepdim=True)[0]
+        B = batch["rews"].shape[1]
+        qvals = qvals.view(T, B, self.n_agents)
+        next_vals = next_vals.view(T, B, self.n_agents)
+        rews, dones = batch["rews"].expand_as(next_vals), batch["dones"].expand_as(next_vals)
+        target = rews + self.gamma * (1 - dones) * next_vals
+        return F.mse_loss(qvals, target), agent_out, target_out
+
+    def update(self, batch: Dict) -> Dict:
+        self.grads.zero_()
+        loss, agent_out, _ = self.loss(batch)
+        loss.backward()
+        self.grads.all_reduce_mean_(self.group)           # the only collective of the data path
+        self.grads.flat.clamp_(-1.0, 1.0)                 # == nn.utils.clip_grad_value_(.., 1) (learner.py:159)
+        self.optimizer.step()
+        with th.no_grad():                                # polyak (learner.py:163-166)
+            pt = list(self.target_net.parameters())
+            th._foreach_mul_(pt, self.polyak)
+            th._foreach_add_(pt, self.params, alpha=1 - self.polyak)
+        return dict(LossQ=loss.detach(), QVals=agent_out.detach())
+
+    # ---- checkpoints (same keys as learner.py:175-201) -------------------------------------------------------------
+    def save_checkpoint(self, path: str, stamp: dict) -> None:
+        ck = dict(stamp)
+        ck["model_state_dict"] = self.policy_net.state_dict()
+        ck["optimizer_state_dict"] = self.optimizer.state_dict()
+        th.save(ck, path)
+
+    def load_checkpoint(self, path: str) -> dict:
+        ck = th.load(path, map_location=self.device)
+        self.policy_net.load_state_dict(ck["model_state_dict"])
+        self.target_net.load_state_dict(self.policy_net.state_dict())
+        if "optimizer_state_dict" in ck:
+            self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        return dict(epoch=ck.get("epoch"), t=ck.get("t"))
+
+
+def params_checksum(module: th.nn.Module) -> th.Tensor:
+    """Cheap replica-consistency probe for DP runs: sum and sum of squares of all parameters (float64)."""
+    flat = th.cat([p.detach().double().reshape(-1) for p in module.parameters()])
+    return th.stack([flat.sum(), flat.square().sum()])

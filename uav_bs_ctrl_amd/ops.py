@@ -12,6 +12,50 @@ from . import _lib as L
 NEG_SLOPE = 0.2  # DGL GATv2Conv default, not overridden at gnn_agents.py:93-96
 
 
+class _KernelTimer:
+    """Optional HIP-event timing of the C-ABI launches (bench.py's live roofline measurement).  Events are recorded
+    on PyTorch's current stream, which is the stream every launch is issued on."""
+
+    def __init__(self):
+        self.enabled = False
+        self._spans = {}
+
+    def reset(self, enabled=True):
+        self._spans = {}
+        self.enabled = enabled
+
+    class _Span:
+        def __init__(self, timer, name):
+            self.t, self.name = timer, name
+
+        def __enter__(self):
+            if self.t.enabled:
+                self.e0 = th.cuda.Event(enable_timing=True)
+                self.e1 = th.cuda.Event(enable_timing=True)
+                self.e0.record()
+            return self
+
+        def __exit__(self, *exc):
+            if self.t.enabled:
+                self.e1.record()
+                self.t._spans.setdefault(self.name, []).append((self.e0, self.e1))
+            return False
+
+    def span(self, name):
+        return _KernelTimer._Span(self, name)
+
+    def summary(self):
+        th.cuda.synchronize()
+        out = {}
+        for name, pairs in self._spans.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = dict(count=len(ms), avg_ms=sum(ms) / len(ms), total_ms=sum(ms))
+        return out
+
+
+KERNEL_TIMER = _KernelTimer()
+
+
 class _HeteroGATv2(th.autograd.Function):
     """K1 over R relations that share the destination nodes.  Returns [N, R*H]: relation i owns columns [i*H, (i+1)*H)
     (so the th.cat of gnn_agents.py:106 never happens).  Per relation the flat argument list carries
@@ -39,9 +83,10 @@ class _HeteroGATv2(th.autograd.Function):
             b_r_c = None if b_r is None else L.f32c(b_r.detach())
             need = any(ctx.needs_input_grad[2 + i * 9 + 2: 2 + i * 9 + 9])
             a_save = th.empty((max(x_src.shape[0], 1), nh), dtype=th.float32, device=x_dst.device) if need else None
-            rc = L.lib().uavgnn_gatv2_fwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off), N,
-                                          *[L.ptr(t) for t in p], L.ptr(b_r_c), nh, D, NEG_SLOPE,
-                                          out.data_ptr() + 4 * i * H, R * H, L.ptr(a_save), L.stream())
+            with KERNEL_TIMER.span(f"gatv2_fwd[F={FS}]"):
+                rc = L.lib().uavgnn_gatv2_fwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off), N,
+                                              *[L.ptr(t) for t in p], L.ptr(b_r_c), nh, D, NEG_SLOPE,
+                                              out.data_ptr() + 4 * i * H, R * H, L.ptr(a_save), L.stream())
             L.check(rc, "uavgnn_gatv2_fwd")
             saved += [x_src, seg_off, *p, a_save if a_save is not None else x_dst]
             meta.append((FS, need, b_r is not None))
@@ -67,10 +112,12 @@ class _HeteroGATv2(th.autograd.Function):
                  th.empty_like(attn), th.empty_like(W_r), th.empty(H, dtype=th.float32, device=dev)]
             ws_bytes = L.lib().uavgnn_gatv2_bwd_workspace_bytes(FS, H)
             ws = th.empty(ws_bytes // 4, dtype=th.float32, device=dev)
-            rc = L.lib().uavgnn_gatv2_bwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off), N,
-                                          L.ptr(W_s), L.ptr(b_s), L.ptr(W_d), L.ptr(b_d), L.ptr(attn), nh, H // nh,
-                                          NEG_SLOPE, out.data_ptr() + 4 * i * H, d_out.data_ptr() + 4 * i * H, R * H,
-                                          L.ptr(a_save), *[L.ptr(t) for t in g], ws.data_ptr(), ws_bytes, L.stream())
+            with KERNEL_TIMER.span(f"gatv2_bwd[F={FS}]"):
+                rc = L.lib().uavgnn_gatv2_bwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off), N,
+                                              L.ptr(W_s), L.ptr(b_s), L.ptr(W_d), L.ptr(b_d), L.ptr(attn), nh, H // nh,
+                                              NEG_SLOPE, out.data_ptr() + 4 * i * H, d_out.data_ptr() + 4 * i * H,
+                                              R * H, L.ptr(a_save), *[L.ptr(t) for t in g], ws.data_ptr(), ws_bytes,
+                                              L.stream())
             L.check(rc, "uavgnn_gatv2_bwd")
             dW_s, db_s, dW_d, db_d, dattn, dW_r, db_r = g
             grads += [None, None, dattn, dW_s, db_s, dW_d, db_d, dW_r, db_r if has_br else None]
@@ -100,10 +147,11 @@ class _TalkAttention(th.autograd.Function):
         E = talk_src.shape[0]
         c = th.empty((N, M), dtype=th.float32, device=v.device)
         a_save = th.empty(max(E, 1), dtype=th.float32, device=v.device)
-        rc = L.lib().uavgnn_talk_attn_fwd(L.ptr(s), 0 if s is None else s.stride(0), L.ptr(q),
-                                          0 if q is None else q.stride(0), L.ptr(v), v.stride(0), K, M,
-                                          L.ptr(talk_off), L.ptr(talk_src), N, float(scale), c.data_ptr(), c.stride(0),
-                                          a_save.data_ptr(), L.stream())
+        with KERNEL_TIMER.span("talk_attn_fwd"):
+            rc = L.lib().uavgnn_talk_attn_fwd(L.ptr(s), 0 if s is None else s.stride(0), L.ptr(q),
+                                              0 if q is None else q.stride(0), L.ptr(v), v.stride(0), K, M,
+                                              L.ptr(talk_off), L.ptr(talk_src), N, float(scale), c.data_ptr(),
+                                              c.stride(0), a_save.data_ptr(), L.stream())
         L.check(rc, "uavgnn_talk_attn_fwd")
         ctx.scale, ctx.uniform = float(scale), s is None
         ctx.save_for_backward(*(t for t in (s, q) if t is not None), v, talk_off, talk_src, t_off, t_dst, t_pos, a_save)
@@ -125,11 +173,13 @@ class _TalkAttention(th.autograd.Function):
             d_s = th.empty((N, K), dtype=th.float32, device=v.device)
             d_q = th.empty((N, K), dtype=th.float32, device=v.device)
             de = th.empty_like(a_save)
-        rc = L.lib().uavgnn_talk_attn_bwd(L.ptr(s), 0 if s is None else s.stride(0), L.ptr(q),
-                                          0 if q is None else q.stride(0), L.ptr(v), v.stride(0), K, M,
-                                          L.ptr(talk_off), L.ptr(talk_src), L.ptr(t_off), L.ptr(t_dst), L.ptr(t_pos), N,
-                                          ctx.scale, a_save.data_ptr(), d_c.data_ptr(), d_c.stride(0), L.ptr(d_s),
-                                          K, L.ptr(d_q), K, d_v.data_ptr(), M, L.ptr(de), L.stream())
+        with KERNEL_TIMER.span("talk_attn_bwd"):
+            rc = L.lib().uavgnn_talk_attn_bwd(L.ptr(s), 0 if s is None else s.stride(0), L.ptr(q),
+                                              0 if q is None else q.stride(0), L.ptr(v), v.stride(0), K, M,
+                                              L.ptr(talk_off), L.ptr(talk_src), L.ptr(t_off), L.ptr(t_dst),
+                                              L.ptr(t_pos), N, ctx.scale, a_save.data_ptr(), d_c.data_ptr(),
+                                              d_c.stride(0), L.ptr(d_s), K, L.ptr(d_q), K, d_v.data_ptr(), M,
+                                              L.ptr(de), L.stream())
         L.check(rc, "uavgnn_talk_attn_bwd")
         return d_s, d_q, d_v, None, None, None, None, None, None
 
@@ -150,8 +200,10 @@ class _GruGates(th.autograd.Function):
         gi, gh, h = L.f32c(gi), L.f32c(gh), L.f32c(h)
         N, H = h.shape
         h_out = th.empty_like(h)
-        L.check(L.lib().uavgnn_gru_gates_fwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), N, H, h_out.data_ptr(),
-                                             L.stream()), "uavgnn_gru_gates_fwd")
+        with KERNEL_TIMER.span("gru_gates_fwd"):
+            rc = L.lib().uavgnn_gru_gates_fwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), N, H, h_out.data_ptr(),
+                                              L.stream())
+        L.check(rc, "uavgnn_gru_gates_fwd")
         ctx.save_for_backward(gi, gh, h)
         return h_out
 
@@ -161,9 +213,10 @@ class _GruGates(th.autograd.Function):
         N, H = h.shape
         d_hout = L.f32c(d_hout)
         d_gi, d_gh, d_h = th.empty_like(gi), th.empty_like(gh), th.empty_like(h)
-        L.check(L.lib().uavgnn_gru_gates_bwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), d_hout.data_ptr(), N, H,
-                                             d_gi.data_ptr(), d_gh.data_ptr(), d_h.data_ptr(), L.stream()),
-                "uavgnn_gru_gates_bwd")
+        with KERNEL_TIMER.span("gru_gates_bwd"):
+            rc = L.lib().uavgnn_gru_gates_bwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), d_hout.data_ptr(), N, H,
+                                              d_gi.data_ptr(), d_gh.data_ptr(), d_h.data_ptr(), L.stream())
+        L.check(rc, "uavgnn_gru_gates_bwd")
         return d_gi, d_gh, d_h
 
 
