@@ -56,6 +56,13 @@ int uavgnn_gatv2_fwd(const float* x_src, int F_src, const float* x_dst, int F_ds
                      const float* W_r, const float* b_r, int nh, int D, float slope, float* out, int ld_out,
                      float* attn_save, uavgnn_stream_t stream);
 
+/* Same contract, always the plain-VALU kernel (every (nh, D) instantiation; uavgnn_gatv2_fwd prefers the fp32-MFMA
+ * kernel when nh == 4 and D in {16,32,64}).  Kept exported as the in-library A/B reference of the MFMA kernel. */
+int uavgnn_gatv2_fwd_valu(const float* x_src, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off, int N,
+                          const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
+                          const float* W_r, const float* b_r, int nh, int D, float slope, float* out, int ld_out,
+                          float* attn_save, uavgnn_stream_t stream);
+
 /* K1 backward: parameter gradients only (observations are leaves: the reference never needs d/dx, Appendix A.4).
  * out / d_out are the forward output and its gradient (same ld).  Gradients are OVERWRITTEN.  Deterministic: per
  * workgroup partials in `workspace` are combined in a fixed order by a second launch (no float atomics).
