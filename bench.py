@@ -80,6 +80,7 @@ def make_sequence(B, n, M, T, dist_name, device, seed, distinct):
     graphs = [synth_batch_gpu(B, n, M, dist_name, device, gen) for _ in range(distinct)]
     for g in graphs:
         g.talk_transpose()   # built once per graph, part of graph construction, not of the hot path
+        g.relation_order("seen"), g.relation_order("near")
     obs = [graphs[t % distinct] for t in range(T + 1)]
     N = B * n
     batch = dict(obs=obs,

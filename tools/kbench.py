@@ -33,6 +33,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--B", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--M", type=int, default=80)
+    ap.add_argument("--order", type=int, default=1)
+    ap.add_argument("--dists", default="dense,env")
     a = ap.parse_args()
     dev = th.device("cuda")
     gen = th.Generator(device=dev)
@@ -41,12 +44,13 @@ def main():
     lib = L.lib()
     st = L.stream()
     print(f"{'case':34s} {'ms':>8s} {'alg GB/s':>9s} {'%HBM':>6s} {'TFLOP/s':>8s} {'%fp32':>6s}")
-    for dist in ("dense", "env"):
-        hb = synth_batch_gpu(a.B, 8, 80, dist, dev, gen)
+    for dist in a.dists.split(","):
+        hb = synth_batch_gpu(a.B, 8, a.M, dist, dev, gen)
         x_a = hb.agent_feat()
         N = x_a.shape[0]
         for et, FS in (("seen", 4), ("near", 2)):
             x_src, off = hb.relation_segments(et)
+            ORDER = hb.relation_order(et).data_ptr() if a.order else None
             E = x_src.shape[0]
             conv = GATv2Conv((FS, 2), 64, 4).to(dev)
             with th.no_grad():
@@ -60,7 +64,7 @@ def main():
             a_save2 = th.empty(max(E, 1), 4, device=dev)
 
             def call(fn, o, sv):
-                rc = fn(x_src.data_ptr(), FS, x_a.data_ptr(), 2, off.data_ptr(), N, *[t.data_ptr() for t in p], 4, 64,
+                rc = fn(x_src.data_ptr(), FS, x_a.data_ptr(), 2, off.data_ptr(), ORDER, N, *[t.data_ptr() for t in p], 4, 64,
                         0.2, o.data_ptr(), 256, sv, st)
                 assert rc == 0, rc
 
@@ -85,7 +89,7 @@ def main():
             ws = th.empty(wsb // 4, device=dev)
 
             def bwd():
-                rc = lib.uavgnn_gatv2_bwd(x_src.data_ptr(), FS, x_a.data_ptr(), 2, off.data_ptr(), N,
+                rc = lib.uavgnn_gatv2_bwd(x_src.data_ptr(), FS, x_a.data_ptr(), 2, off.data_ptr(), ORDER, N,
                                           *[t.data_ptr() for t in p[:5]], 4, 64, 0.2, out.data_ptr(), d_out.data_ptr(),
                                           256, a_save.data_ptr(), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
                                           g[3].data_ptr(), g[4].data_ptr(), g[5].data_ptr(), g[6].data_ptr(),

@@ -51,9 +51,9 @@ class GATv2Conv(nn.Module):
             state_dict[key] = th.zeros_like(self.res_fc.bias)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def forward(self, x_src, seg_off, x_dst):
+    def forward(self, x_src, seg_off, x_dst, order=None):
         """Single relation: [N_dst, nh, D] (used by the DRQN twin)."""
-        out = ops.hetero_gatv2(x_dst, self._num_heads, [(x_src, seg_off, self)])
+        out = ops.hetero_gatv2(x_dst, self._num_heads, [(x_src, seg_off, order, self)])
         return out.view(x_dst.shape[0], self._num_heads, self._out_feats)
 
 
@@ -79,7 +79,7 @@ class GraphObservationEncoder(nn.Module):
         rels = []
         for et in ("seen", "near"):
             x_src, off = g.relation_segments(et)
-            rels.append((x_src, off, self.f_conv[et]))
+            rels.append((x_src, off, g.relation_order(et), self.f_conv[et]))
         x_cat = ops.hetero_gatv2(x_a, self._n_heads, rels)                  # [N_a, 2H]
         lin = self.f_aggr[0]
         return F.relu(F.linear(x_cat, lin.weight, lin.bias))
@@ -303,7 +303,7 @@ class DrqnGnnAgent(nn.Module):
     def forward(self, g: HeteroBatch, h):
         et = "seen-by" if g.has_relation("seen-by") else "seen"
         x_src, off = g.relation_segments(et)
-        x = self.enc(x_src, off, g.agent_feat()).flatten(start_dim=1)
+        x = self.enc(x_src, off, g.agent_feat(), g.relation_order(et)).flatten(start_dim=1)
         h = _gru(self.rnn, (x,), h.contiguous())
         return F.linear(h, self.f_out.weight, self.f_out.bias), h
 

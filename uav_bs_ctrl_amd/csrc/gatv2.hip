@@ -37,7 +37,8 @@ __device__ __forceinline__ void load_row<2>(const float* __restrict__ p, float (
 // ---------------------------------------------------------------------------------------------------------------
 template <int FS, int NH, int D>
 __global__ __launch_bounds__(kThreads) void gatv2_fwd_kernel(
-    const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off, int N,
+    const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off,
+    const int32_t* __restrict__ dst_order, int N,
     const float* __restrict__ W_s, const float* __restrict__ b_s, const float* __restrict__ W_d,
     const float* __restrict__ b_d, const float* __restrict__ attn, const float* __restrict__ W_r,
     const float* __restrict__ b_r, float slope, float* __restrict__ out, int ld_out, float* __restrict__ a_save) {
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(kThreads) void gatv2_fwd_kernel(
   float* __restrict__ cw = sC[wave];
   float* __restrict__ sw = sS[wave];
 
-  for (int v = blockIdx.x * kWavesPerBlock + wave; v < N; v += gridDim.x * kWavesPerBlock) {
+  for (int it = blockIdx.x * kWavesPerBlock + wave; it < N; it += gridDim.x * kWavesPerBlock) {
+    const int v = dst_order ? dst_order[it] : it;
     const float xv0 = x_dst[2 * v], xv1 = x_dst[2 * v + 1];
     const int e0 = seg_off[v];
     const int deg = seg_off[v + 1] - e0;
@@ -186,7 +188,8 @@ __host__ __device__ constexpr int partial_len(int H) { return H * (FS + 8); }
 
 template <int FS, int NH, int D>
 __global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
-    const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off, int N,
+    const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off,
+    const int32_t* __restrict__ dst_order, int N,
     const float* __restrict__ W_s, const float* __restrict__ b_s, const float* __restrict__ W_d,
     const float* __restrict__ b_d, const float* __restrict__ attn, float slope, const float* __restrict__ out,
     const float* __restrict__ d_out, int ld_out, const float* __restrict__ a_save, float* __restrict__ partial) {
@@ -237,7 +240,8 @@ __global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
   float* __restrict__ sb = sSb[wave];
   float* __restrict__ ew = sE[wave];
 
-  for (int v = blockIdx.x * kWavesPerBlock + wave; v < N; v += gridDim.x * kWavesPerBlock) {
+  for (int it = blockIdx.x * kWavesPerBlock + wave; it < N; it += gridDim.x * kWavesPerBlock) {
+    const int v = dst_order ? dst_order[it] : it;
     const float xv0 = x_dst[2 * v], xv1 = x_dst[2 * v + 1];
     const int e0 = seg_off[v];
     const int deg = seg_off[v + 1] - e0;
@@ -444,24 +448,26 @@ constexpr int kMaxBwdBlocks = 1024;
 inline int bwd_blocks(int N) { return capped_grid(N, kWavesPerBlock, kMaxBwdBlocks); }
 
 template <int FS, int NH, int D>
-int launch_fwd(const float* x_src, const float* x_dst, const int32_t* seg_off, int N, const float* W_s,
+int launch_fwd(const float* x_src, const float* x_dst, const int32_t* seg_off, const int32_t* dst_order, int N,
+               const float* W_s,
                const float* b_s, const float* W_d, const float* b_d, const float* attn, const float* W_r,
                const float* b_r, float slope, float* out, int ld_out, float* a_save, hipStream_t st) {
   const int grid = capped_grid(N, kWavesPerBlock, 4096);
-  hipLaunchKernelGGL((gatv2_fwd_kernel<FS, NH, D>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, N, W_s,
-                     b_s, W_d, b_d, attn, W_r, b_r, slope, out, ld_out, a_save);
+  hipLaunchKernelGGL((gatv2_fwd_kernel<FS, NH, D>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, dst_order,
+                     N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope, out, ld_out, a_save);
   return launch_status();
 }
 
 template <int FS, int NH, int D>
-int launch_bwd(const float* x_src, const float* x_dst, const int32_t* seg_off, int N, const float* W_s,
+int launch_bwd(const float* x_src, const float* x_dst, const int32_t* seg_off, const int32_t* dst_order, int N,
+               const float* W_s,
                const float* b_s, const float* W_d, const float* b_d, const float* attn, float slope, const float* out,
                const float* d_out, int ld_out, const float* a_save, const GradPtrs& gp, float* ws, hipStream_t st) {
   constexpr int H = NH * D;
   constexpr int P = partial_len<FS>(H);
   const int grid = bwd_blocks(N);
-  hipLaunchKernelGGL((gatv2_bwd_kernel<FS, NH, D>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, N, W_s,
-                     b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws);
+  hipLaunchKernelGGL((gatv2_bwd_kernel<FS, NH, D>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, dst_order,
+                     N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws);
   int rc = launch_status();
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + kWave - 1) / kWave), dim3(1024), 0, st, ws, grid, P, gp);
@@ -497,7 +503,7 @@ using namespace uavgnn;
   UAVGNN_DISPATCH(2, 1, 64, CALL)
 
 static int gatv2_fwd_checked(bool allow_mfma, const float* x_src, int F_src, const float* x_dst, int F_dst,
-                             const int32_t* seg_off, int N, const float* W_s, const float* b_s, const float* W_d,
+                             const int32_t* seg_off, const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d,
                              const float* b_d, const float* attn, const float* W_r, const float* b_r, int nh, int D,
                              float slope, float* out, int ld_out, float* attn_save, uavgnn_stream_t stream) {
   if (N < 0 || !seg_off || !x_dst || !W_s || !b_s || !W_d || !b_d || !attn || !W_r || !out || ld_out < nh * D)
@@ -506,29 +512,29 @@ static int gatv2_fwd_checked(bool allow_mfma, const float* x_src, int F_src, con
   if (N == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (allow_mfma) {
-    const int rc = gatv2_fwd_mfma(F_src, nh, D, x_src, x_dst, seg_off, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope,
+    const int rc = gatv2_fwd_mfma(F_src, nh, D, x_src, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope,
                                   out, ld_out, attn_save, st);
     if (rc != UAVGNN_EUNSUPPORTED) return rc;
   }
-  UAVGNN_DISPATCH_ALL((launch_fwd<FS_, NH_, D_>(x_src, x_dst, seg_off, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope,
+  UAVGNN_DISPATCH_ALL((launch_fwd<FS_, NH_, D_>(x_src, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope,
                                                  out, ld_out, attn_save, st)))
   return UAVGNN_EUNSUPPORTED;
 }
 
 extern "C" int uavgnn_gatv2_fwd(const float* x_src, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
-                                int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d,
+                                const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d,
                                 const float* attn, const float* W_r, const float* b_r, int nh, int D, float slope,
                                 float* out, int ld_out, float* attn_save, uavgnn_stream_t stream) {
-  return gatv2_fwd_checked(true, x_src, F_src, x_dst, F_dst, seg_off, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
+  return gatv2_fwd_checked(true, x_src, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
                            slope, out, ld_out, attn_save, stream);
 }
 
 extern "C" int uavgnn_gatv2_fwd_valu(const float* x_src, int F_src, const float* x_dst, int F_dst,
-                                     const int32_t* seg_off, int N, const float* W_s, const float* b_s,
+                                     const int32_t* seg_off, const int32_t* dst_order, int N, const float* W_s, const float* b_s,
                                      const float* W_d, const float* b_d, const float* attn, const float* W_r,
                                      const float* b_r, int nh, int D, float slope, float* out, int ld_out,
                                      float* attn_save, uavgnn_stream_t stream) {
-  return gatv2_fwd_checked(false, x_src, F_src, x_dst, F_dst, seg_off, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
+  return gatv2_fwd_checked(false, x_src, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
                            slope, out, ld_out, attn_save, stream);
 }
 
@@ -537,7 +543,7 @@ extern "C" size_t uavgnn_gatv2_bwd_workspace_bytes(int F_src, int H) {
 }
 
 extern "C" int uavgnn_gatv2_bwd(const float* x_src, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
-                                int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d,
+                                const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d,
                                 const float* attn, int nh, int D, float slope, const float* out, const float* d_out,
                                 int ld_out, const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d,
                                 float* dattn, float* dW_r, float* db_r, void* workspace, size_t workspace_bytes,
@@ -560,7 +566,7 @@ extern "C" int uavgnn_gatv2_bwd(const float* x_src, int F_src, const float* x_ds
   gp.off[7] = gp.off[6] + H;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
-  UAVGNN_DISPATCH_ALL((launch_bwd<FS_, NH_, D_>(x_src, x_dst, seg_off, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out,
+  UAVGNN_DISPATCH_ALL((launch_bwd<FS_, NH_, D_>(x_src, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out,
                                                  ld_out, attn_save, gp, ws, st)))
   return UAVGNN_EUNSUPPORTED;
 }

@@ -73,24 +73,15 @@ __device__ __forceinline__ void load_xrow(const float* __restrict__ p, bool vali
   }
 }
 
-// this lane's MFMA B operand (feature g of edge j) picked out of the edge's row
-template <int FS>
-__device__ __forceinline__ float pick_feature(const float (&x)[FS], int g) {
-  if constexpr (FS == 4) {
-    return g == 0 ? x[0] : (g == 1 ? x[1] : (g == 2 ? x[2] : x[3]));
-  } else {
-    return g == 0 ? x[0] : (g == 1 ? x[1] : 0.f);
-  }
-}
-
 constexpr float kLog2e = 1.4426950408889634f;
 
 template <int FS, int D>
 __global__ __launch_bounds__(kThreads, 2) void gatv2_fwd_mfma_kernel(
-    const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off, int N,
-    const float* __restrict__ W_s, const float* __restrict__ b_s, const float* __restrict__ W_d,
-    const float* __restrict__ b_d, const float* __restrict__ attn, const float* __restrict__ W_r,
-    const float* __restrict__ b_r, float slope, float* __restrict__ out, int ld_out, float* __restrict__ a_save) {
+    const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off,
+    const int32_t* __restrict__ dst_order, int N, const float* __restrict__ W_s, const float* __restrict__ b_s,
+    const float* __restrict__ W_d, const float* __restrict__ b_d, const float* __restrict__ attn,
+    const float* __restrict__ W_r, const float* __restrict__ b_r, float slope, float* __restrict__ out, int ld_out,
+    float* __restrict__ a_save) {
   constexpr int H = NH * D;
   constexpr int CT = H / 16;        // channel tiles
   constexpr int TPH = D / 16;       // channel tiles per head
@@ -153,35 +144,33 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_fwd_mfma_kernel(
   float* __restrict__ sw = sS[wave];
 
   const int stride = gridDim.x * kWavesPerBlock;
-  int v = blockIdx.x * kWavesPerBlock + wave;
-  if (v >= N) return;
-  // destination scalars are fetched one iteration ahead
-  float xv0 = x_dst[2 * v], xv1 = x_dst[2 * v + 1];
-  int e0 = seg_off[v];
-  int deg = seg_off[v + 1] - e0;
+  int it = blockIdx.x * kWavesPerBlock + wave;       // position in the hand-out order
+  if (it >= N) return;
+  // destination scalars are fetched one iteration ahead (raw values: nothing derived from them until next iteration)
+  int nv = dst_order ? dst_order[it] : it;
+  float2 nxv = *reinterpret_cast<const float2*>(x_dst + 2 * nv);
+  int ne0 = seg_off[nv], ne1 = seg_off[nv + 1];
+  int nnv = dst_order ? dst_order[min(it + stride, N - 1)] : min(it + stride, N - 1);
 
-  for (; v < N; v += stride) {
-    const float cxv0 = xv0, cxv1 = xv1;
-    const int ce0 = e0, cdeg = deg;
-    // first row tile of this destination: issue the load before anything else
+  for (; it < N; it += stride) {
+    const int v = nv;
+    const float cxv0 = nxv.x, cxv1 = nxv.y;
+    const int ce0 = ne0, cdeg = ne1 - ne0;
+    // first row tile of this destination: issue the loads before anything else
     float xr[FS];
     load_xrow<FS>(x_src + static_cast<size_t>(ce0 + j) * FS, j < cdeg, xr);
-    {
-      const int vn = v + stride;
-      if (vn < N) {
-        xv0 = x_dst[2 * vn];
-        xv1 = x_dst[2 * vn + 1];
-        e0 = seg_off[vn];
-        deg = seg_off[vn + 1] - e0;
-      }
+    float xBn = (j < cdeg && g < FS) ? x_src[static_cast<size_t>(ce0 + j) * FS + g] : 0.f;
+    {  // clamped look-ahead: always legal addresses, unused after the last iteration
+      nv = nnv;
+      nxv = *reinterpret_cast<const float2*>(x_dst + 2 * nv);
+      ne0 = seg_off[nv];
+      ne1 = seg_off[nv + 1];
+      const int it2 = min(it + 2 * stride, N - 1);
+      nnv = dst_order ? dst_order[it2] : it2;
     }
     float res[J];
 #pragma unroll
-    for (int jj = 0; jj < J; ++jj) {
-      const int n = lane + kWave * jj;
-      res[jj] = fmaf(wr1[jj], cxv1, fmaf(wr0[jj], cxv0, br[jj]));
-      if (n < H) cw[n] = fmaf(wd1[jj], cxv1, fmaf(wd0[jj], cxv0, bc[jj]));
-    }
+    for (int jj = 0; jj < J; ++jj) res[jj] = fmaf(wr1[jj], cxv1, fmaf(wr0[jj], cxv0, br[jj]));
     float* __restrict__ orow = out + static_cast<size_t>(v) * ld_out;
     if (cdeg == 0) {
 #pragma unroll
@@ -191,7 +180,12 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_fwd_mfma_kernel(
       }
       continue;
     }
-    wave_sync();
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      const int n = lane + kWave * jj;
+      if (n < H) cw[n] = fmaf(wd1[jj], cxv1, fmaf(wd0[jj], cxv0, bc[jj]));
+    }
+    wave_sync_lds();
     f32x4 cinit[CT];   // C operand: destination term for channels ct*16 + 4g + r
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) cinit[ct] = *reinterpret_cast<const f32x4*>(cw + ct * 16 + 4 * g);
@@ -206,9 +200,11 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_fwd_mfma_kernel(
       float xc[FS];
 #pragma unroll
       for (int f = 0; f < FS; ++f) xc[f] = xr[f];
+      const float xB = xBn;
       // next row tile's inputs are in flight while this tile computes
-      load_xrow<FS>(x_src + (u + 16) * FS, base + 16 + j < cdeg, xr);
-      const float xB = pick_feature<FS>(xc, g);
+      const bool nvalid = base + 16 + j < cdeg;
+      load_xrow<FS>(x_src + (u + 16) * FS, nvalid, xr);
+      xBn = (nvalid && g < FS) ? x_src[(u + 16) * FS + g] : 0.f;
       float pe[NH][2];
 #pragma unroll
       for (int k = 0; k < NH; ++k) {
@@ -240,7 +236,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_fwd_mfma_kernel(
     // ---- combine the 16 lanes of each head ------------------------------------------------------------------
     const float mx = row16_max(m);
     const float scl = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mx);
-    const float inv = 1.f / row16_sum(den * scl);
+    const float inv = __builtin_amdgcn_rcpf(row16_sum(den * scl));
 #pragma unroll
     for (int f = 0; f < FS; ++f) {
       const float t = row16_sum(s[f] * scl);
@@ -254,7 +250,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_fwd_mfma_kernel(
         }
       }
     }
-    wave_sync();
+    wave_sync_lds();
     // ---- epilogue: lane <-> channel --------------------------------------------------------------------------
 #pragma unroll
     for (int jj = 0; jj < J; ++jj) {
@@ -267,30 +263,32 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_fwd_mfma_kernel(
         orow[n] = fmaxf(agg + res[jj], 0.f);
       }
     }
-    wave_sync();
+    wave_sync_lds();
   }
 }
 
 template <int FS, int D>
-int launch(const float* x_src, const float* x_dst, const int32_t* seg_off, int N, const float* W_s, const float* b_s,
+int launch(const float* x_src, const float* x_dst, const int32_t* seg_off, const int32_t* dst_order, int N,
+           const float* W_s, const float* b_s,
            const float* W_d, const float* b_d, const float* attn, const float* W_r, const float* b_r, float slope,
            float* out, int ld_out, float* a_save, hipStream_t st) {
   const int grid = capped_grid(N, kWavesPerBlock, 512);  // persistent: 2 workgroups per CU, constants loaded once
-  hipLaunchKernelGGL((gatv2_fwd_mfma_kernel<FS, D>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, N, W_s,
-                     b_s, W_d, b_d, attn, W_r, b_r, slope, out, ld_out, a_save);
+  hipLaunchKernelGGL((gatv2_fwd_mfma_kernel<FS, D>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, dst_order,
+                     N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope, out, ld_out, a_save);
   return launch_status();
 }
 
 }  // namespace
 
-int gatv2_fwd_mfma(int F_src, int nh, int D, const float* x_src, const float* x_dst, const int32_t* seg_off, int N,
+int gatv2_fwd_mfma(int F_src, int nh, int D, const float* x_src, const float* x_dst, const int32_t* seg_off,
+                   const int32_t* dst_order, int N,
                    const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
                    const float* W_r, const float* b_r, float slope, float* out, int ld_out, float* a_save,
                    hipStream_t st) {
   if (nh != NH) return UAVGNN_EUNSUPPORTED;
 #define UAVGNN_MFMA_CASE(FSV, DV)                                                                                  \
   if (F_src == FSV && D == DV)                                                                                     \
-    return launch<FSV, DV>(x_src, x_dst, seg_off, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope, out, ld_out, a_save, st);
+    return launch<FSV, DV>(x_src, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope, out, ld_out, a_save, st);
   UAVGNN_MFMA_CASE(4, 64)
   UAVGNN_MFMA_CASE(2, 64)
   UAVGNN_MFMA_CASE(4, 32)

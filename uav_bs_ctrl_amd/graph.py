@@ -230,6 +230,16 @@ class HeteroBatch:
             self._cache[key] = (x.float().contiguous(), r.off)
         return self._cache[key]
 
+    def relation_order(self, etype: str) -> th.Tensor:
+        """Destinations of a relation sorted by decreasing in-degree (int32 [N]): the hand-out order that balances
+        ragged batches over the persistent wavefronts of K1 (scheduling hint only; built once per graph)."""
+        key = "ord:" + etype
+        if key not in self._cache:
+            off = self._rels[self._canon(etype)].off
+            deg = (off[1:] - off[:-1])
+            self._cache[key] = th.sort(deg, descending=True, stable=True)[1].to(th.int32).contiguous()
+        return self._cache[key]
+
     def talk_csc(self):
         r = self._rels[TALK]
         src = r.src if r.src is not None else th.arange(r.num_edges, dtype=th.int32, device=r.off.device)

@@ -59,9 +59,9 @@ KERNEL_TIMER = _KernelTimer()
 class _HeteroGATv2(th.autograd.Function):
     """K1 over R relations that share the destination nodes.  Returns [N, R*H]: relation i owns columns [i*H, (i+1)*H)
     (so the th.cat of gnn_agents.py:106 never happens).  Per relation the flat argument list carries
-    x_src, seg_off, attn, W_s, b_s, W_d, b_d, W_r, b_r  (b_r may be None)."""
+    x_src, seg_off, dst_order, attn, W_s, b_s, W_d, b_d, W_r, b_r  (b_r and dst_order may be None)."""
 
-    PER_REL = 9
+    PER_REL = 10
 
     @staticmethod
     def forward(ctx, x_dst, nh, *rel_args):
@@ -69,27 +69,29 @@ class _HeteroGATv2(th.autograd.Function):
         L.require_gpu(x_dst, *[t for t in rel_args if isinstance(t, th.Tensor)])
         x_dst = L.f32c(x_dst)
         N = x_dst.shape[0]
-        H = rel_args[3].shape[0]
+        H = rel_args[4].shape[0]
         D = H // nh
         out = th.empty((N, R * H), dtype=th.float32, device=x_dst.device)
-        saved, meta = [x_dst], []
+        saved, meta, has_order = [x_dst], [], []
         for i in range(R):
-            x_src, seg_off, attn, W_s, b_s, W_d, b_d, W_r, b_r = rel_args[i * 9:(i + 1) * 9]
+            x_src, seg_off, order, attn, W_s, b_s, W_d, b_d, W_r, b_r = rel_args[i * 10:(i + 1) * 10]
             x_src = L.f32c(x_src)
             FS = W_s.shape[1]
             if W_s.shape[0] != H or x_src.shape[0] and x_src.shape[1] != FS:
                 raise L.UavGnnError("hetero_gatv2: inconsistent relation shapes")
             p = [L.f32c(t.detach()) for t in (W_s, b_s, W_d, b_d, attn, W_r)]
             b_r_c = None if b_r is None else L.f32c(b_r.detach())
-            need = any(ctx.needs_input_grad[2 + i * 9 + 2: 2 + i * 9 + 9])
+            need = any(ctx.needs_input_grad[2 + i * 10 + 3: 2 + i * 10 + 10])
             a_save = th.empty((max(x_src.shape[0], 1), nh), dtype=th.float32, device=x_dst.device) if need else None
             with KERNEL_TIMER.span(f"gatv2_fwd[F={FS}]"):
-                rc = L.lib().uavgnn_gatv2_fwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off), N,
-                                              *[L.ptr(t) for t in p], L.ptr(b_r_c), nh, D, NEG_SLOPE,
+                rc = L.lib().uavgnn_gatv2_fwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off),
+                                              L.ptr(order), N, *[L.ptr(t) for t in p], L.ptr(b_r_c), nh, D, NEG_SLOPE,
                                               out.data_ptr() + 4 * i * H, R * H, L.ptr(a_save), L.stream())
             L.check(rc, "uavgnn_gatv2_fwd")
-            saved += [x_src, seg_off, *p, a_save if a_save is not None else x_dst]
-            meta.append((FS, need, b_r is not None))
+            saved += [x_src, seg_off, order if order is not None else seg_off, *p,
+                      a_save if a_save is not None else x_dst]
+            has_order.append(order is not None)
+            meta.append((FS, need, b_r is not None, has_order[-1]))
         ctx.nh, ctx.meta, ctx.H = nh, meta, H
         ctx.save_for_backward(*saved, out)
         return out
@@ -103,32 +105,33 @@ class _HeteroGATv2(th.autograd.Function):
         N, dev = x_dst.shape[0], x_dst.device
         d_out = L.f32c(d_out)
         grads = [None, None]
-        for i, (FS, need, has_br) in enumerate(ctx.meta):
-            x_src, seg_off, W_s, b_s, W_d, b_d, attn, W_r, a_save = saved[1 + i * 9: 1 + (i + 1) * 9]
+        for i, (FS, need, has_br, has_ord) in enumerate(ctx.meta):
+            x_src, seg_off, order, W_s, b_s, W_d, b_d, attn, W_r, a_save = saved[1 + i * 10: 1 + (i + 1) * 10]
             if not need or N == 0:
-                grads += [None] * 9
+                grads += [None] * 10
                 continue
             g = [th.empty_like(W_s), th.empty_like(b_s), th.empty_like(W_d), th.empty_like(b_d),
                  th.empty_like(attn), th.empty_like(W_r), th.empty(H, dtype=th.float32, device=dev)]
             ws_bytes = L.lib().uavgnn_gatv2_bwd_workspace_bytes(FS, H)
             ws = th.empty(ws_bytes // 4, dtype=th.float32, device=dev)
             with KERNEL_TIMER.span(f"gatv2_bwd[F={FS}]"):
-                rc = L.lib().uavgnn_gatv2_bwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off), N,
-                                              L.ptr(W_s), L.ptr(b_s), L.ptr(W_d), L.ptr(b_d), L.ptr(attn), nh, H // nh,
+                rc = L.lib().uavgnn_gatv2_bwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off),
+                                              L.ptr(order) if has_ord else None, N, L.ptr(W_s), L.ptr(b_s), L.ptr(W_d), L.ptr(b_d), L.ptr(attn), nh, H // nh,
                                               NEG_SLOPE, out.data_ptr() + 4 * i * H, d_out.data_ptr() + 4 * i * H,
                                               R * H, L.ptr(a_save), *[L.ptr(t) for t in g], ws.data_ptr(), ws_bytes,
                                               L.stream())
             L.check(rc, "uavgnn_gatv2_bwd")
             dW_s, db_s, dW_d, db_d, dattn, dW_r, db_r = g
-            grads += [None, None, dattn, dW_s, db_s, dW_d, db_d, dW_r, db_r if has_br else None]
+            grads += [None, None, None, dattn, dW_s, db_s, dW_d, db_d, dW_r, db_r if has_br else None]
         return tuple(grads)
 
 
 def hetero_gatv2(x_dst, nh, relations):
-    """relations: list of (x_src [E,F], seg_off [N+1] int32, conv) with conv exposing attn, fc_src, fc_dst, res_fc."""
+    """relations: list of (x_src [E,F], seg_off [N+1] int32, dst_order [N] int32 or None, conv) with conv exposing attn,
+    fc_src, fc_dst, res_fc."""
     flat = []
-    for x_src, seg_off, conv in relations:
-        flat += [x_src, seg_off, conv.attn, conv.fc_src.weight, conv.fc_src.bias, conv.fc_dst.weight,
+    for x_src, seg_off, order, conv in relations:
+        flat += [x_src, seg_off, order, conv.attn, conv.fc_src.weight, conv.fc_src.bias, conv.fc_dst.weight,
                  conv.fc_dst.bias, conv.res_fc.weight, conv.res_fc.bias]
     return _HeteroGATv2.apply(x_dst, nh, *flat)
 
