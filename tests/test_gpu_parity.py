@@ -37,8 +37,8 @@ def test_golden_forward_backward(name):
     for k, prm in net.named_parameters():
         ref = th.as_tensor(z["grad:" + k])
         got = prm.grad if prm.grad is not None else th.zeros_like(prm)
-        assert_close(got, ref, 1e-4, f"{name}: grad {k}", floor=1e-7)
-    assert_close(hd.grad, th.as_tensor(z["grad:__h__"]), 1e-4, f"{name}: grad h", floor=1e-7)
+        assert_close(got, ref, 1e-4, f"{name}: grad {k}", floor=2e-6)
+    assert_close(hd.grad, th.as_tensor(z["grad:__h__"]), 1e-4, f"{name}: grad h", floor=2e-6)
 
 
 def test_golden_drqn_twin():
@@ -54,7 +54,7 @@ def test_golden_drqn_twin():
     assert_close(h2, th.as_tensor(z["h_out"]), 1e-5, "drqn h'")
     _loss(q, h2, th.as_tensor(z["wq"], dtype=th.float32).cuda(), th.as_tensor(z["wh"], dtype=th.float32).cuda()).backward()
     for k, prm in net.named_parameters():
-        assert_close(prm.grad, th.as_tensor(z["grad:" + k]), 1e-4, f"drqn grad {k}", floor=1e-7)
+        assert_close(prm.grad, th.as_tensor(z["grad:" + k]), 1e-4, f"drqn grad {k}", floor=2e-6)
 
 
 EXP3 = dict(enc="gnn", c="tarmac", n_heads=4, key_size=16, msg_size=64, n_rounds=1, n_layers=2, dueling=False,

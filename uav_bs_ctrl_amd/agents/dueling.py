@@ -1,6 +1,6 @@
 """Dueling Q head (reference: algos/madrqn/agents/dueling.py:4-16).  q = V + (A - mean_a A)."""
 import torch.nn as nn
-import torch.nn.functional as F
+from .. import ops
 
 
 class DuelingLayer(nn.Module):
@@ -10,6 +10,6 @@ class DuelingLayer(nn.Module):
         self.v_head = nn.Linear(in_feats, 1)
 
     def forward(self, x):
-        adv = F.linear(x, self.adv_head.weight, self.adv_head.bias)
-        val = F.linear(x, self.v_head.weight, self.v_head.bias)
+        adv = ops.linear(x, self.adv_head.weight, self.adv_head.bias)
+        val = ops.linear(x, self.v_head.weight, self.v_head.bias)
         return val + adv - adv.mean(-1, keepdim=True)
