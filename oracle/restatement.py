@@ -155,7 +155,7 @@ def segment_mean(m, dst, n):
     return s / deg.clamp(min=1).unsqueeze(1)
 
 
-def segment_max_first(m, dst, n):
+def segment_max_first(m, dst, n, key=None):
     """UDF reduce ``nodes.mailbox['m'].max(1)[0]`` (gnn_agents.py:177).  torch.max(dim) routes the gradient to ONE
     index - the first maximal entry in mailbox order (= edge-id order within the in-edges of the node, which the
     stable CSC sort preserves) - so ties, which are the norm for one-hot messages, must not be split."""
@@ -163,7 +163,7 @@ def segment_max_first(m, dst, n):
     if E == 0:
         return th.zeros(n, Fm, dtype=m.dtype, device=m.device)
     idxe = dst.view(-1, 1).expand(E, Fm)
-    md = m.detach()
+    md = m.detach() if key is None else key.detach()   # `key` decides the winner, `m` supplies the value
     mx = th.zeros(n, Fm, dtype=m.dtype, device=m.device).scatter_reduce(0, idxe, md, reduce="amax", include_self=False)
     pos = th.arange(E, device=m.device).view(-1, 1).expand(E, Fm)
     cand = th.where(md == mx.index_select(0, dst), pos, th.full_like(pos, E))
@@ -206,7 +206,11 @@ def edge_conv(g: dict, x, h, p: dict, n_rounds: int = 1):
 # a5: DiscreteComm.forward (gnn_agents.py:180-193).  ``gumbel`` is the per-edge Gumbel(0,1) noise
 # [E, msg, 2] that F.gumbel_softmax draws internally (gnn_agents.py:172); it is an explicit input here so that
 # results are reproducible.  tau=0.5, hard=True, straight-through estimator.
-def disc_comm(g: dict, x, h, p: dict, msg_size: int, gumbel):
+def disc_comm(g: dict, x, h, p: dict, msg_size: int, gumbel, exact_ties: bool = False):
+    """exact_ties=False reproduces the reference literally: the max (and hence the edge that receives the gradient)
+    is taken over the floating-point values (y_hard - y_soft) + y_soft, so ties between several "1" bits are broken by
+    rounding noise.  exact_ties=True is the exact-arithmetic rule the HIP kernel implements: the first in-edge whose
+    hard bit is set (else the first in-edge) owns the channel."""
     src, dst = talk_edges(g)
     n = x.shape[0]
     logits = F.linear(th.cat((x, h.detach()), 1), p["f_enc.weight"], p["f_enc.bias"]).index_select(0, src)
@@ -214,7 +218,10 @@ def disc_comm(g: dict, x, h, p: dict, msg_size: int, gumbel):
     idx = y_soft.max(-1, keepdim=True)[1]
     y_hard = th.zeros_like(y_soft).scatter_(-1, idx, 1.0)
     m = (y_hard - y_soft.detach() + y_soft).flatten(1)               # [E, 2*msg]
-    c = segment_max_first(m, dst, n)                                  # mailbox.max(1)[0]; zero-deg stays 0
+    if exact_ties:
+        c = segment_max_first(m, dst, n, key=y_hard.flatten(1))
+    else:
+        c = segment_max_first(m, dst, n)                              # mailbox.max(1)[0]; zero-deg stays 0
     c = F.linear(c, p["f_dec.weight"], p["f_dec.bias"])
     return gru_cell(th.cat((x, c), 1), h, sub(p, "f_udt"))
 
@@ -245,7 +252,7 @@ def gnn_agent_forward(g: dict, h, p: dict, cfg: dict, gumbel=None):
     elif c == "tarmac":
         h = tarmac(g, x, h, sub(p, "f_comm"), cfg["key_size"], cfg.get("n_rounds", 1))
     elif c == "disc":
-        h = disc_comm(g, x, h, sub(p, "f_comm"), cfg["msg_size"], gumbel)
+        h = disc_comm(g, x, h, sub(p, "f_comm"), cfg["msg_size"], gumbel, cfg.get("exact_ties", False))
     elif c == "base":
         h = base_comm(g, x, h, sub(p, "f_comm"))
     elif c == "commnet":

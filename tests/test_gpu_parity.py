@@ -11,8 +11,8 @@ from tests.util import assert_close, load_golden
 
 pytestmark = pytest.mark.gpu
 
-GOLDENS = ["agent_none", "agent_tarmac", "agent_tarmac_r2", "agent_tarmac_duel", "agent_base", "agent_commnet",
-           "agent_econv", "agent_mlp_tarmac", "agent_debugmap_tarmac"]
+GOLDENS = ["agent_none", "agent_tarmac", "agent_tarmac_r2", "agent_tarmac_duel", "agent_disc", "agent_base",
+           "agent_commnet", "agent_econv", "agent_mlp_tarmac", "agent_debugmap_tarmac"]
 
 
 def _loss(q, h2, wq, wh):
@@ -29,6 +29,8 @@ def test_golden_forward_backward(name):
         g.pop("x_flat")
     hb = to_batch(g)
     hd = h.cuda().requires_grad_(True)
+    if "gumbel" in z.files:    # DiscreteComm: inject the per-edge Gumbel noise the reference drew (CSC order)
+        net.f_comm.gumbel = th.as_tensor(z["gumbel"], dtype=th.float32).cuda()
     q, h2 = net(hb, hd)
     assert_close(q, th.as_tensor(z["q"]), 1e-5, f"{name}: q")
     assert_close(h2, th.as_tensor(z["h_out"]), 1e-5, f"{name}: h'")
@@ -94,6 +96,38 @@ def test_exp3_sizes_vs_oracle(dist, talk, B, n, M):
         err_hip = float((grads[k].double().cpu() - ref).abs().max()) / scale
         err_cpu32 = float((g32[k].double() - ref).abs().max()) / scale
         assert err_hip <= max(1e-4, 4 * err_cpu32), f"grad {k}: rel err {err_hip:.3e} (cpu fp32 oracle {err_cpu32:.3e})"
+
+
+def test_exp3_disc_comm_vs_oracle():
+    """DiscreteComm at exp3 sizes (msg = 64 bit pairs) with injected noise, oracle in exact-tie mode (the rule K5
+    implements; identical to the literal rule whenever (1 - s) + s rounds to exactly 1)."""
+    cfg = dict(EXP3, c="disc", exact_ties=True)
+    p64 = default_init_params(cfg, seed=4)
+    B, n = 24, 8
+    g = synth_graph(B, n, 80, "env", seed=8, talk="sparse")
+    gen = th.Generator().manual_seed(17)
+    N, E = B * n, g["talk_src"].numel()
+    h = 0.5 * th.randn(N, 256, generator=gen)
+    gum = -th.empty(E, 64, 2).exponential_(generator=gen).log()
+    wq, wh = th.randn(N, 9, generator=gen), th.randn(N, 256, generator=gen) / 16
+    pp = {k: v.detach().clone().requires_grad_(True) for k, v in p64.items()}
+    gg = {k: (v.double() if v.is_floating_point() else v) for k, v in g.items()}
+    hh = h.double().requires_grad_(True)
+    q64, h64 = R.gnn_agent_forward(gg, hh, pp, cfg, gumbel=gum.double())
+    g64 = th.autograd.grad(_loss(q64, h64, wq.double(), wh.double()), list(pp.values()) + [hh])
+    net = agent_from_params(p64, cfg)
+    net.f_comm.gumbel = gum.cuda()
+    hd = h.cuda().requires_grad_(True)
+    q, h2 = net(to_batch(g), hd)
+    assert_close(q, q64, 1e-5, "disc q")
+    assert_close(h2, h64, 1e-5, "disc h'")
+    _loss(q, h2, wq.cuda(), wh.cuda()).backward()
+    got = [prm.grad for prm in net.parameters()] + [hd.grad]
+    for (k, _), a, b in zip(list(pp.items()) + [("__h__", None)], got, g64):
+        assert_close(a, b, 1e-4, f"disc grad {k}", floor=2e-6)
+    # without injected noise the module draws its own on the device
+    q2, _ = net(to_batch(g), h.cuda())
+    assert th.isfinite(q2).all()
 
 
 def test_backward_is_deterministic():

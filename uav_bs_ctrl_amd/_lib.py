@@ -36,6 +36,10 @@ SIGNATURES = {
     "uavgnn_talk_attn_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip,
                                       _c_ip, _c_ip, _c_ip, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_int,
                                       _c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_st]),
+    "uavgnn_disc_comm_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_f32, _c_fp, _c_int, _c_fp,
+                                      _c_ip, _c_st]),
+    "uavgnn_disc_comm_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_ip, _c_int, _c_ip, _c_ip, _c_ip, _c_int, _c_f32, _c_fp,
+                                      _c_int, _c_st]),
     "uavgnn_gru_gates_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_st]),
     "uavgnn_gru_gates_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_st]),
 }

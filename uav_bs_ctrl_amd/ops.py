@@ -267,6 +267,47 @@ def linear(x, W, b=None):
     return _LinearSplitK.apply(x, W, b)
 
 
+class _DiscComm(th.autograd.Function):
+    """K5.  Hard Gumbel-softmax messages (straight-through) + OR (max) aggregation of DiscreteComm."""
+
+    @staticmethod
+    def forward(ctx, logits, gumbel, talk_off, talk_src, t_off, t_dst, t_pos, inv_tau):
+        L.require_gpu(logits, gumbel, talk_off, talk_src)
+        logits, gumbel = L.f32c(logits), L.f32c(gumbel)
+        N, M2 = logits.shape
+        M = M2 // 2
+        E = talk_src.shape[0]
+        if gumbel.numel() != E * M2:
+            raise L.UavGnnError(f"disc_comm: gumbel noise must be [E={E}, msg={M}, 2]")
+        c = th.empty((N, M2), dtype=th.float32, device=logits.device)
+        y0 = th.empty((max(E, 1), M), dtype=th.float32, device=logits.device)
+        sel = th.empty((N, M2), dtype=th.int32, device=logits.device)
+        with KERNEL_TIMER.span("disc_comm_fwd"):
+            rc = L.lib().uavgnn_disc_comm_fwd(logits.data_ptr(), M2, gumbel.data_ptr(), M, L.ptr(talk_off),
+                                              L.ptr(talk_src), N, float(inv_tau), c.data_ptr(), M2, y0.data_ptr(),
+                                              sel.data_ptr(), L.stream())
+        L.check(rc, "uavgnn_disc_comm_fwd")
+        ctx.inv_tau, ctx.M = float(inv_tau), M
+        ctx.save_for_backward(y0, sel, t_off, t_dst, t_pos)
+        return c
+
+    @staticmethod
+    def backward(ctx, d_c):
+        y0, sel, t_off, t_dst, t_pos = ctx.saved_tensors
+        d_c = L.f32c(d_c)
+        N = d_c.shape[0]
+        d_logits = th.empty_like(d_c)
+        with KERNEL_TIMER.span("disc_comm_bwd"):
+            rc = L.lib().uavgnn_disc_comm_bwd(d_c.data_ptr(), d_c.stride(0), y0.data_ptr(), sel.data_ptr(), ctx.M,
+                                              L.ptr(t_off), L.ptr(t_dst), L.ptr(t_pos), N, ctx.inv_tau,
+                                              d_logits.data_ptr(), d_logits.stride(0), L.stream())
+        L.check(rc, "uavgnn_disc_comm_bwd")
+        return d_logits, None, None, None, None, None, None, None
+
+
 def disc_comm_aggregate(logits, gumbel, g, tau=0.5):
-    """Hard Gumbel-softmax messages + OR aggregation of DiscreteComm (gnn_agents.py:166-178)."""
-    raise NotImplementedError("DiscreteComm kernel (SURVEY 8f row f4) is not built yet")
+    """Hard Gumbel-softmax messages + OR aggregation of DiscreteComm (gnn_agents.py:166-178).  logits [N, 2*msg] per
+    source node, gumbel [E, msg, 2] in CSC order."""
+    off, src = g.talk_csc()
+    t_off, t_dst, t_pos = g.talk_transpose()
+    return _DiscComm.apply(logits, gumbel, off, src, t_off, t_dst, t_pos, 1.0 / tau)
