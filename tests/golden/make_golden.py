@@ -223,6 +223,79 @@ def main():
                hidden_size=32, n_actions=env.n_actions)
     run_and_save("agent_debugmap_tarmac", net, g, h, arrays, cfg)
 
+    make_learner_golden()
+
+
+def make_learner_golden():
+    """E. Row L: the reference's own MultiAgentQLearner (algos/madrqn/learner.py) - act / cache / update - on the Debug
+    map (3 UBS x 4 GT), H=32, T=5, B=4, anneal_lr=False (LambdaLR(verbose=True) is a TypeError on torch 2.10).  Stores
+    the sampled batch (segment arrays per time step), initial hidden states, actions, rewards, dones and what update()
+    produced: loss, Q-values, clipped gradients, post-step policy parameters and polyak-averaged target parameters."""
+    import random
+
+    from algos.madrqn.learner import MultiAgentQLearner
+    from envs.mubs_cov.mubs_cov import MultiUbsCoverageEnv
+
+    T, B = 5, 4
+    args = types.SimpleNamespace(device="cpu", o="gnn", c="tarmac", hidden_size=32, n_heads=4, n_layers=2, msg_size=8,
+                                 key_size=4, n_rounds=1, dueling=False, mixer=False, max_seq_len=T, gamma=0.99,
+                                 polyak=0.995, batch_size=B, replay_size=100, lr=5e-4, anneal_lr=False, double_q=True,
+                                 share_reward=False, norm_r=False)
+    np.random.seed(11), random.seed(11), th.manual_seed(11)
+    env = MultiUbsCoverageWrapper(MultiUbsCoverageEnv("debug", record=False), args)
+
+    def to_double(g):
+        for fr in g._nframes.values():
+            for k in list(fr):
+                fr[k] = fr[k].double()
+        return g
+
+    learner = MultiAgentQLearner(env.get_env_info(), args)
+    fill_closed_form(learner.policy_net)
+    learner.target_net.load_state_dict(learner.policy_net.state_dict())
+    (o, s), h = env.reset(), learner.init_hidden()
+    o = to_double(o)
+    t = 0
+    while len(learner.buffer) < B:
+        a, h2 = learner.act(o, h, 0.5)
+        o2, s2, r, d, info = env.step(a)
+        o2 = to_double(o2)
+        learner.cache(o, h, s, a, r, o2, h2, s2, d, info.get("BadMask"))
+        o, s, h = o2, s2, h2
+        t += 1
+        if d:
+            (o, s), h = env.reset(), learner.init_hidden()
+            o = to_double(o)
+    samples = list(learner.buffer.memory)[:B]
+    learner.buffer.sample = lambda n: samples
+    out = {}
+    for tt in range(T + 1):
+        g = ref_cat([samples[i]["obs"][tt] for i in range(B)])
+        for k, v in graph_to_arrays(g).items():
+            out[f"t{tt}:{k}"] = v
+    out["h0"] = th.cat([samples[i]["h"][0] for i in range(B)]).numpy()
+    out["h1"] = th.cat([samples[i]["h"][1] for i in range(B)]).numpy()
+    out["acts"] = th.stack([th.cat([samples[i]["act"][tt] for i in range(B)]) for tt in range(T)]).numpy()
+    out["rews"] = th.stack([th.cat([samples[i]["rew"][tt] for i in range(B)]) for tt in range(T)]).double().numpy()
+    out["dones"] = th.stack([th.cat([samples[i]["done"][tt] for i in range(B)]) for tt in range(T)]).double().numpy()
+    res = learner.update()
+    out["loss"] = np.array(res["LossQ"])
+    out["qvals"] = res["QVals"]
+    names = [k for k, _ in learner.policy_net.named_parameters()]
+    for k, p in learner.policy_net.named_parameters():
+        out["grad_clipped:" + k] = p.grad.detach().numpy()
+        out["policy_after:" + k] = p.detach().numpy()
+    for k, p in learner.target_net.named_parameters():
+        out["target_after:" + k] = p.detach().numpy()
+    out["param_names"] = np.array(names)
+    out["param_shapes"] = np.array([repr(tuple(p.shape)) for p in learner.policy_net.parameters()])
+    out["cfg"] = np.array(repr(dict(enc="gnn", c="tarmac", n_heads=4, key_size=4, msg_size=8, n_rounds=1, n_layers=2,
+                                    dueling=False, hidden_size=32, n_actions=env.n_actions, n_agents=env.n_agents, T=T,
+                                    B=B, gamma=0.99, polyak=0.995, lr=5e-4, double_q=True)))
+    path = os.path.join(HERE, "learner_update_tarmac.npz")
+    np.savez_compressed(path, **out)
+    print(f"learner_update_tarmac: loss={float(out['loss']):.6f} dones={out['dones'].sum():.0f} -> {os.path.getsize(path)} B")
+
 
 if __name__ == "__main__":
     main()

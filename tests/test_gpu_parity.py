@@ -7,7 +7,7 @@ import torch as th
 
 from oracle import restatement as R
 from tests.gpu_util import agent_from_params, default_init_params, synth_graph, to_batch
-from tests.util import assert_close, load_golden
+from tests.util import assert_close, load_golden, load_learner_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -152,3 +152,43 @@ def test_cpu_tensors_fail_loudly():
     from uav_bs_ctrl_amd import HeteroBatch
     with pytest.raises(UavGnnError):
         net(HeteroBatch.from_arrays(**g), h)
+
+
+def test_learner_update_reproduces_reference_update():
+    """Row L on the GPU: uav_bs_ctrl_amd.learner.MultiAgentQLearner.update (HIP forward/backward, flat-buffer clip,
+    AdamW, polyak) against the state the reference's learner reached after ONE update from the same parameters/batch."""
+    import types
+    from uav_bs_ctrl_amd import HeteroBatch
+    from uav_bs_ctrl_amd.learner import MultiAgentQLearner
+    batch, p, cfg, z = load_learner_golden(dtype=th.float32)
+    args = types.SimpleNamespace(device="cuda", hidden_size=32, c="tarmac", n_heads=4, n_layers=2, msg_size=8, key_size=4,
+                                 n_rounds=1, dueling=False, mixer=False, double_q=True, lr=cfg["lr"], gamma=cfg["gamma"],
+                                 polyak=cfg["polyak"], max_seq_len=cfg["T"], seed=0)
+    env_info = dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=cfg["n_actions"], n_agents=cfg["n_agents"],
+                    episode_limit=10)
+    L = MultiAgentQLearner(env_info, args)
+    L.policy_net.load_state_dict(p)
+    L.target_net.load_state_dict(p)
+    dev = th.device("cuda")
+    b = dict(obs=[HeteroBatch.from_arrays(**g).to(dev) for g in batch["obs"]], h0=batch["h0"].to(dev),
+             h1=batch["h1"].to(dev), acts=batch["acts"].to(dev), rews=batch["rews"].to(dev), dones=batch["dones"].to(dev))
+    out = L.update(b)
+    assert_close(out["LossQ"], th.as_tensor(z["loss"]).double(), 1e-5, "LossQ")
+    qv = out["QVals"][:-1].gather(2, b["acts"]).view(cfg["T"], cfg["B"], cfg["n_agents"])
+    assert_close(qv, th.as_tensor(z["qvals"]), 1e-5, "QVals")
+    for k, prm in L.policy_net.named_parameters():
+        g_ref = th.as_tensor(z["grad_clipped:" + k])
+        assert_close(prm.grad, g_ref, 1e-4, f"clipped grad {k}", floor=2e-6)
+        # Adam's first step is lr * sign-like(g): only meaningful where the gradient is well above rounding noise
+        sure = g_ref.abs() > 1e-4
+        after = th.as_tensor(z["policy_after:" + k])
+        assert float(((prm.detach().cpu().double() - after).abs() * sure).max()) < 2e-6, f"policy param {k}"
+    for k, prm in L.target_net.named_parameters():
+        assert float((prm.detach().cpu().double() - th.as_tensor(z["target_after:" + k])).abs().max()) < 1e-6, k
+    # rollout: one epsilon draw per team, greedy == argmax of the policy logits when eps = 0
+    acts, h2 = L.act(b["obs"][0], b["h0"], 0.0)
+    with th.no_grad():
+        logits, _ = L.policy_net(b["obs"][0], b["h0"])
+    assert th.equal(acts, logits.argmax(1)) and h2.shape == b["h0"].shape
+    acts_r, _ = L.act(b["obs"][0], b["h0"], 1.0)
+    assert int(acts_r.min()) >= 0 and int(acts_r.max()) < cfg["n_actions"]

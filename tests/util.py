@@ -48,3 +48,27 @@ def assert_close(actual, ref, rel=1e-5, what="", floor=0.0):
         raise AssertionError(f"{what}: {int(bad.sum())}/{ref.numel()} out of tolerance (rel={rel}); worst err "
                              f"{float(err.flatten()[i]):.3e} at flat {i}: got {float(actual.flatten()[i]):.8e} "
                              f"ref {float(ref.flatten()[i]):.8e}; max|ref|={float(ref.abs().max()):.3e}")
+
+
+def load_learner_golden(name="learner_update_tarmac", dtype=th.float64, device="cpu"):
+    """-> (batch dict with obs as list of segment-array dicts, closed-form params, cfg, npz)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = ast.literal_eval(str(z["cfg"]))
+    obs = []
+    for t in range(cfg["T"] + 1):
+        g = {}
+        for k in GRAPH_KEYS:
+            key = f"t{t}:{k}"
+            if key in z.files:
+                a = th.as_tensor(z[key])
+                g[k] = (a.to(dtype) if a.is_floating_point() else a).to(device)
+        obs.append(g)
+    params = {}
+    for i, (n, s) in enumerate(zip(z["param_names"], z["param_shapes"])):
+        shape = ast.literal_eval(str(s))
+        amp = 0.1 if len(shape) == 1 else 0.25
+        params[str(n)] = closed_form_tensor(shape, 1.0 + i * math.pi / 7, amp, th.float64).to(dtype).to(device)
+    f = lambda k: th.as_tensor(z[k]).to(dtype).to(device)  # noqa: E731
+    batch = dict(obs=obs, h0=f("h0"), h1=f("h1"), acts=th.as_tensor(z["acts"]).long().to(device), rews=f("rews"),
+                 dones=f("dones"))
+    return batch, params, cfg, z
