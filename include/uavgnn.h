@@ -123,6 +123,27 @@ int uavgnn_disc_comm_bwd(const float* d_c, int ld_dc, const float* y0_save, cons
                          const int32_t* t_off, const int32_t* t_dst, const int32_t* t_pos, int N, float inv_tau,
                          float* d_logits, int ld_dl, uavgnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * f1  Device-side observation -> graph construction for a batch of environments (replaces the Python loops of
+ * env_wrappers.py:65-89 build_obs_graph, :139-154 build_comm_graph and dgl.batch/merge :67,:137).
+ * Padded observations: gt[N, M, 1+Fg], ubs[N, U, 1+Fu] with column 0 the visibility flag (mubs_cov.py:215-242),
+ * N = B*n agent rows; d_u2u[B, n, n] pairwise UBS distances.  Two passes with a prefix sum (caller) in between:
+ *   uavgnn_obs_degrees  -> deg_seen[N], deg_near[N]                         (counts of kept rows)
+ *   uavgnn_obs_compact  -> x_gt[E_seen, Fg], x_ubs[E_near, Fu] given seen_off / near_off = exclusive scans
+ *   uavgnn_talk_degrees -> deg_in[N] (in-degree of every agent), env_edges[B] (edges per environment)
+ *   uavgnn_talk_compact -> talk_src[E], talk_eid[E] (CSC; eid = the edge id the reference's i-major loop assigns)
+ *                          given talk_off = scan(deg_in) and env_base = scan(env_edges).
+ * Kept rows keep the reference's order (ascending m / ascending source i).  Fg == 4, Fu == 2, n <= 64.
+ */
+int uavgnn_obs_degrees(const float* gt, int M, int Fg, const float* ubs, int U, int Fu, int N, int32_t* deg_seen,
+                       int32_t* deg_near, uavgnn_stream_t stream);
+int uavgnn_obs_compact(const float* gt, int M, int Fg, const float* ubs, int U, int Fu, int N, const int32_t* seen_off,
+                       const int32_t* near_off, float* x_gt, float* x_ubs, uavgnn_stream_t stream);
+int uavgnn_talk_degrees(const float* d_u2u, int n, int B, float r_comm, int32_t* deg_in, int32_t* env_edges,
+                        uavgnn_stream_t stream);
+int uavgnn_talk_compact(const float* d_u2u, int n, int B, float r_comm, const int32_t* talk_off,
+                        const int32_t* env_base, int32_t* talk_src, int32_t* talk_eid, uavgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -192,3 +192,34 @@ def test_learner_update_reproduces_reference_update():
     assert th.equal(acts, logits.argmax(1)) and h2.shape == b["h0"].shape
     acts_r, _ = L.act(b["obs"][0], b["h0"], 1.0)
     assert int(acts_r.min()) >= 0 and int(acts_r.max()) < cfg["n_actions"]
+
+
+def test_device_side_graph_construction_is_bit_identical_to_host_builder():
+    """f1: HIP count/compact passes == per-environment ``from_obs_dicts`` + ``batch`` (the reference's construction)."""
+    import numpy as np
+    from uav_bs_ctrl_amd import batch, from_obs_dicts, from_padded_obs
+    rng = np.random.default_rng(3)
+    for (B, n, M, r) in [(5, 8, 80, 1.0), (3, 4, 200, 0.4), (2, 16, 70, np.inf), (4, 1, 20, 1.0)]:
+        gt = rng.uniform(-1, 1, (B, n, M, 5)).astype(np.float32)
+        gt[..., 0] = rng.uniform(size=(B, n, M)) < 0.3
+        gt[0, 0, :, 0] = 0                                   # an agent that sees nothing
+        gt[-1, -1, :, 0] = 1                                 # and one that sees everything
+        ub = rng.uniform(-1, 1, (B, n, max(n - 1, 0), 3)).astype(np.float32)
+        ub[..., 0] = rng.uniform(size=ub.shape[:-1]) < 0.5
+        ag = rng.uniform(0, 1, (B, n, 2)).astype(np.float32)
+        d = rng.uniform(0, 2, (B, n, n)).astype(np.float32)
+        d = (d + d.transpose(0, 2, 1)) / 2
+        for b in range(B):
+            np.fill_diagonal(d[b], 0)
+        host = batch([from_obs_dicts([dict(agent=ag[b, i], ubs=ub[b, i], gt=gt[b, i]) for i in range(n)], d[b], r)
+                      for b in range(B)])
+        dev = from_padded_obs(*(th.as_tensor(a).cuda() for a in (gt, ub, ag, d)), r_comm=r)
+        for et in ("seen", "near"):
+            xs, off = dev.relation_segments(et)
+            xh, offh = host.relation_segments(et)
+            assert th.equal(off.cpu(), offh) and th.equal(xs.cpu(), xh), et
+        for a, b_ in zip(dev.talk_csc(), host.talk_csc()):
+            assert th.equal(a.cpu(), b_)
+        assert th.equal(dev.talk_eid().cpu(), host.talk_eid())
+        assert th.equal(dev.agent_feat().cpu(), host.agent_feat())
+        assert th.equal(dev.graph_off.cpu(), host.graph_off)

@@ -40,6 +40,11 @@ SIGNATURES = {
                                       _c_ip, _c_st]),
     "uavgnn_disc_comm_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_ip, _c_int, _c_ip, _c_ip, _c_ip, _c_int, _c_f32, _c_fp,
                                       _c_int, _c_st]),
+    "uavgnn_obs_degrees": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip, _c_st]),
+    "uavgnn_obs_compact": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip, _c_fp, _c_fp,
+                                    _c_st]),
+    "uavgnn_talk_degrees": (_c_int, [_c_fp, _c_int, _c_int, _c_f32, _c_ip, _c_ip, _c_st]),
+    "uavgnn_talk_compact": (_c_int, [_c_fp, _c_int, _c_int, _c_f32, _c_ip, _c_ip, _c_ip, _c_ip, _c_st]),
     "uavgnn_gru_gates_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_st]),
     "uavgnn_gru_gates_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_st]),
 }
