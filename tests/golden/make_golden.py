@@ -224,6 +224,27 @@ def main():
     run_and_save("agent_debugmap_tarmac", net, g, h, arrays, cfg)
 
     make_learner_golden()
+    make_mixer_golden()
+
+
+def make_mixer_golden():
+    """F. QMixer (algos/madrqn/agents/mixers.py:6-49): forward/backward on closed-form weights."""
+    from algos.madrqn.agents.mixers import QMixer
+    T, B, n, S = 3, 4, 5, 11
+    mix = QMixer(S, n, types.SimpleNamespace(embed_dim=8))
+    fill_closed_form(mix)
+    qs = (closed_form_tensor((T * B, n), 0.3) * 10).view(T, B, n).clone().requires_grad_(True)
+    st = (closed_form_tensor((T * B, S), 0.7) * 10).view(T, B, S)
+    y = mix(qs, st)
+    w = closed_form_tensor((T * B, 1), 1.9).view(T, B, 1)
+    grads = th.autograd.grad((y * w).sum(), list(mix.parameters()) + [qs])
+    out = dict(qs=qs.detach().numpy(), states=st.numpy(), y=y.detach().numpy(), w=w.numpy(),
+               param_names=np.array([k for k, _ in mix.named_parameters()]),
+               param_shapes=np.array([repr(tuple(p.shape)) for p in mix.parameters()]))
+    for (k, _), g in zip(list(mix.named_parameters()) + [("__qs__", None)], grads):
+        out["grad:" + k] = g.numpy()
+    np.savez_compressed(os.path.join(HERE, "qmixer.npz"), **out)
+    print("qmixer: y", tuple(y.shape))
 
 
 def make_learner_golden():

@@ -1,0 +1,73 @@
+"""CPU tests of the tensor-native replay (buffer.py semantics) and of the QMixer against the reference fixture."""
+import math
+import types
+
+import numpy as np
+import torch as th
+
+from oracle.closed_form import closed_form_tensor
+from tests.util import GOLDEN, assert_close
+from uav_bs_ctrl_amd.agents.mixers import QMixer
+from uav_bs_ctrl_amd.replay import SequenceReplay
+
+
+def _transition(rng, E, n, M, H, t):
+    f = lambda *s: th.as_tensor(rng.uniform(-1, 1, s).astype(np.float32))  # noqa: E731
+    gt, ub = f(E, n, M, 5), f(E, n, n - 1, 3)
+    gt[..., 0] = (gt[..., 0] > 0).float()
+    ub[..., 0] = (ub[..., 0] > 0).float()
+    return dict(gt=gt, ubs=ub, agent=f(E, n, 2).abs(), d_u2u=f(E, n, n).abs(), h=f(E, n, H), state=f(E, 3),
+                act=th.full((E, n), t), rew=f(E, n), done=th.zeros(E, 1))
+
+
+def test_sequence_semantics_match_reference_buffer():
+    """T pushes make one sequence per env holding T transitions + the next obs/h of the last one (buffer.py:26-35)."""
+    rng = np.random.default_rng(0)
+    E, n, M, H, T = 2, 3, 5, 4, 3
+    rb = SequenceReplay(capacity=4, max_seq_len=T, n_agents=n, n_gts=M, hidden_size=H, n_envs=E, state_dim=3,
+                        r_comm=0.5, device="cpu")
+    trs = [_transition(rng, E, n, M, H, t) for t in range(2 * T + 1)]
+    for t in range(2 * T):
+        tr = dict(trs[t])
+        for k in ("gt", "ubs", "agent", "d_u2u", "h", "state"):
+            tr["next_" + k] = trs[t + 1][k]
+        rb.push(tr)
+        assert len(rb) == (E if t + 1 >= T else 0) + (E if t + 1 >= 2 * T else 0)
+    assert len(rb) == 4 and rb.ptr == 0
+    b = rb.gather(th.tensor([0, 1, 2, 3]))
+    assert len(b["obs"]) == T + 1 and b["obs"][0].num_nodes("agent") == 4 * n
+    assert b["acts"].shape == (T, 4 * n, 1) and b["rews"].shape == (T, 4, n) and b["dones"].shape == (T, 4, 1)
+    assert th.equal(b["acts"][:, 0, 0], th.arange(T)) and th.equal(b["acts"][:, 2 * n, 0], th.arange(T, 2 * T))
+    # sequence 0 (env 0, first T steps): h0/h1 are the stored hidden states of its first two steps
+    assert th.equal(b["h0"][:n], trs[0]["h"][0]) and th.equal(b["h1"][:n], trs[1]["h"][0])
+    # the (T+1)-th observation of the first sequence is the next observation of its last transition
+    assert th.equal(b["obs"][T].agent_feat()[:n], trs[T]["agent"][0])
+    # graphs are rebuilt exactly as the per-step builder would: visible rows only, reference order
+    xs, off = b["obs"][1].relation_segments("seen")
+    keep = trs[1]["gt"][0, 0, :, 0] == 1
+    assert int(off[1]) == int(keep.sum()) and th.equal(xs[:int(off[1])], trs[1]["gt"][0, 0][keep][:, 1:])
+    # ring wrap-around overwrites the oldest sequences
+    for t in range(T):
+        rb.push(dict(trs[t], **{"next_" + k: trs[t + 1][k] for k in ("gt", "ubs", "agent", "d_u2u", "h", "state")}))
+    assert len(rb) == 4 and rb.head == 2
+    idx = rb.sample_indices(3, th.Generator().manual_seed(0))
+    assert idx.unique().numel() == 3
+
+
+def test_qmixer_matches_reference_fixture():
+    z = np.load(f"{GOLDEN}/qmixer.npz")
+    T, B, n = z["qs"].shape
+    S = z["states"].shape[-1]
+    mix = QMixer(S, n, types.SimpleNamespace(embed_dim=8)).double()
+    names = [k for k, _ in mix.named_parameters()]
+    assert names == [str(k) for k in z["param_names"]]
+    with th.no_grad():
+        for i, (k, p) in enumerate(mix.named_parameters()):
+            assert repr(tuple(p.shape)) == str(z["param_shapes"][i])
+            p.copy_(closed_form_tensor(p.shape, 1.0 + i * math.pi / 7, 0.1 if p.dim() == 1 else 0.25, th.float64))
+    qs = th.as_tensor(z["qs"]).requires_grad_(True)
+    y = mix(qs, th.as_tensor(z["states"]))
+    assert_close(y, th.as_tensor(z["y"]), 1e-12, "q_tot")
+    grads = th.autograd.grad((y * th.as_tensor(z["w"])).sum(), list(mix.parameters()) + [qs])
+    for k, g in zip(names + ["__qs__"], grads):
+        assert_close(g, th.as_tensor(z["grad:" + k]), 1e-10, f"grad {k}", floor=1e-14)

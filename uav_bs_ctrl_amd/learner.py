@@ -85,8 +85,17 @@ class MultiAgentQLearner:
         for p in self.target_net.parameters():
             p.requires_grad_(False)
         self.params = list(self.policy_net.parameters())
-        if getattr(args, "mixer", False):
-            raise NotImplementedError("QMixer is outside the hot path (SURVEY 2 row 5); every launcher sets mixer=False")
+        self.mixer = None
+        if getattr(args, "mixer", False):   # QMIX (learner.py:35-40); every launcher of the reference sets mixer=False
+            from copy import deepcopy
+
+            from .agents.mixers import QMixer
+            self.mixer = QMixer(env_info["state_shape"], self.n_agents, args).to(self.device)
+            broadcast_parameters(self.mixer, 0, process_group)
+            self.target_mixer = deepcopy(self.mixer)
+            for p in self.target_mixer.parameters():
+                p.requires_grad_(False)
+            self.params += list(self.mixer.parameters())
 
         ep_limit = env_info.get("episode_limit")
         self.max_seq_len = args.max_seq_len if getattr(args, "max_seq_len", None) is not None else ep_limit
@@ -95,6 +104,7 @@ class MultiAgentQLearner:
         self.double_q = args.double_q
         self.optimizer = th.optim.AdamW(self.params, lr=args.lr)
         self.grads = FlatGradBuffer(self.params)
+        self.n_policy = sum(p.numel() for p in self.policy_net.parameters())
         self._gen = th.Generator(device=self.device)
         self._gen.manual_seed(int(getattr(args, "seed", 0)) + 7919 * (dist.get_rank() if dist.is_initialized() else 0))
 
@@ -146,6 +156,9 @@ class MultiAgentQLearner:
         B = batch["rews"].shape[1]
         qvals = qvals.view(T, B, self.n_agents)
         next_vals = next_vals.view(T, B, self.n_agents)
+        if self.mixer is not None:                       # learner.py:145-148 (batch["states"]: [T+1, B, state_dim])
+            qvals = self.mixer(qvals, batch["states"][:-1])
+            next_vals = self.target_mixer(next_vals, batch["states"][1:])
         rews, dones = batch["rews"].expand_as(next_vals), batch["dones"].expand_as(next_vals)
         target = rews + self.gamma * (1 - dones) * next_vals
         return F.mse_loss(qvals, target), agent_out, target_out
@@ -155,12 +168,17 @@ class MultiAgentQLearner:
         loss, agent_out, _ = self.loss(batch)
         loss.backward()
         self.grads.all_reduce_mean_(self.group)           # the only collective of the data path
-        self.grads.flat.clamp_(-1.0, 1.0)                 # == nn.utils.clip_grad_value_(.., 1) (learner.py:159)
+        # == nn.utils.clip_grad_value_(policy_net.parameters(), 1): the mixer is NOT clipped (learner.py:159)
+        self.grads.flat[:self.n_policy].clamp_(-1.0, 1.0)
         self.optimizer.step()
         with th.no_grad():                                # polyak (learner.py:163-166)
             pt = list(self.target_net.parameters())
             th._foreach_mul_(pt, self.polyak)
-            th._foreach_add_(pt, self.params, alpha=1 - self.polyak)
+            th._foreach_add_(pt, list(self.policy_net.parameters()), alpha=1 - self.polyak)
+            if self.mixer is not None:
+                mt = list(self.target_mixer.parameters())
+                th._foreach_mul_(mt, self.polyak)
+                th._foreach_add_(mt, list(self.mixer.parameters()), alpha=1 - self.polyak)
         return dict(LossQ=loss.detach(), QVals=agent_out.detach())
 
     # ---- checkpoints (same keys as learner.py:175-201) -------------------------------------------------------------
@@ -168,6 +186,8 @@ class MultiAgentQLearner:
         ck = dict(stamp)
         ck["model_state_dict"] = self.policy_net.state_dict()
         ck["optimizer_state_dict"] = self.optimizer.state_dict()
+        if self.mixer is not None:
+            ck["mixer_state_dict"] = self.mixer.state_dict()
         th.save(ck, path)
 
     def load_checkpoint(self, path: str) -> dict:
@@ -176,6 +196,9 @@ class MultiAgentQLearner:
         self.target_net.load_state_dict(self.policy_net.state_dict())
         if "optimizer_state_dict" in ck:
             self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        if self.mixer is not None and "mixer_state_dict" in ck:
+            self.mixer.load_state_dict(ck["mixer_state_dict"])
+            self.target_mixer.load_state_dict(self.mixer.state_dict())
         return dict(epoch=ck.get("epoch"), t=ck.get("t"))
 
 
