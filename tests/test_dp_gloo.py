@@ -94,8 +94,9 @@ def _worker(rank, world, port, q):
         dist.all_gather(gathered, flat1)
         same_after = all(th.equal(gathered[0], g) for g in gathered)
         if rank == 0:
-            q.put(dict(same_init=same_init, same_after=same_after, grad=grad, init=flat0, after=flat1, target=tflat,
-                       loss=float(out["LossQ"])))
+            # numpy (pickled by value): torch tensors travel by fd-sharing, which races with this process exiting
+            q.put(dict(same_init=same_init, same_after=same_after, grad=grad.numpy(), init=flat0.numpy(),
+                       after=flat1.numpy(), target=tflat.numpy(), loss=float(out["LossQ"])))
     finally:
         dist.destroy_process_group()
 
@@ -117,6 +118,7 @@ def test_dp2_gradient_equals_single_process_on_concatenated_batch():
     for p in procs:
         p.start()
     res = q.get(timeout=240)
+    res = {k: (th.as_tensor(v) if hasattr(v, "shape") else v) for k, v in res.items()}
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
