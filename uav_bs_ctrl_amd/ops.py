@@ -249,8 +249,8 @@ class _LinearSplitK(th.autograd.Function):
             dx = th.mm(dy, W)
         if ctx.needs_input_grad[1]:
             n = x.shape[0]
-            S = 1
-            while S < 64 and n % (2 * S) == 0 and n // (2 * S) >= 512:
+            S = 1   # row chunks of >= 2048: S = 16 at N_a = 32768 (measured best or within 10 % on every layer shape)
+            while S < 64 and n % (2 * S) == 0 and n // (2 * S) >= 2048:
                 S *= 2
             if S > 1:
                 xc = x if x.is_contiguous() else x.contiguous()
