@@ -223,3 +223,80 @@ def test_device_side_graph_construction_is_bit_identical_to_host_builder():
         assert th.equal(dev.talk_eid().cpu(), host.talk_eid())
         assert th.equal(dev.agent_feat().cpu(), host.agent_feat())
         assert th.equal(dev.graph_off.cpu(), host.graph_off)
+
+
+@pytest.mark.parametrize("H,nh", [(64, 4), (128, 4), (128, 2), (256, 8), (64, 1), (32, 4)])
+def test_other_head_configurations_vs_oracle(H, nh):
+    """DEFAULT_CONFIG's H=64 (MFMA path, D=16), D=32, and head counts without an MFMA instantiation (VALU kernel)."""
+    cfg = dict(EXP3, hidden_size=H, n_heads=nh, msg_size=16, key_size=8, c="tarmac")
+    p64 = default_init_params(cfg, seed=3)
+    g = synth_graph(6, 5, 70, "ragged", seed=11, talk="sparse")
+    gen = th.Generator().manual_seed(5)
+    N = 30
+    h = 0.5 * th.randn(N, H, generator=gen)
+    wq, wh = th.randn(N, 9, generator=gen), th.randn(N, H, generator=gen) / 8
+    pp = {k: v.detach().clone().requires_grad_(True) for k, v in p64.items()}
+    gg = {k: (v.double() if v.is_floating_point() else v) for k, v in g.items()}
+    hh = h.double().requires_grad_(True)
+    q64, h64 = R.gnn_agent_forward(gg, hh, pp, cfg)
+    g64 = th.autograd.grad(_loss(q64, h64, wq.double(), wh.double()), list(pp.values()) + [hh])
+    net = agent_from_params(p64, cfg)
+    hd = h.cuda().requires_grad_(True)
+    q, h2 = net(to_batch(g), hd)
+    assert_close(q, q64, 1e-5, "q")
+    assert_close(h2, h64, 1e-5, "h'")
+    _loss(q, h2, wq.cuda(), wh.cuda()).backward()
+    for (k, _), a, b in zip(list(pp.items()) + [("__h__", None)], [p_.grad for p_ in net.parameters()] + [hd.grad], g64):
+        assert_close(a, b, 1e-4, f"grad {k}", floor=2e-6)
+
+
+def test_edge_cases_empty_relations_single_agent_and_isolated_nodes():
+    """All agents blind and alone (E_seen = E_near = 0), a talk relation without any edge (the reference's zero-edge
+    branch, gnn_agents.py:139-141, unreachable there because of self loops), and a single-agent graph."""
+    from uav_bs_ctrl_amd import HeteroBatch
+    cfg = dict(EXP3, hidden_size=64, msg_size=16, key_size=8)
+    p64 = default_init_params(cfg, seed=6)
+    net = agent_from_params(p64, cfg)
+    for N in (1, 7):
+        g = dict(x_a=th.rand(N, 2), x_gt=th.zeros(0, 4), seen_off=th.zeros(N + 1, dtype=th.int32), x_ubs=th.zeros(0, 2),
+                 near_off=th.zeros(N + 1, dtype=th.int32), talk_off=th.zeros(N + 1, dtype=th.int32),
+                 talk_src=th.zeros(0, dtype=th.int32))
+        h = th.randn(N, 64)
+        gg = {k: (v.double() if v.is_floating_point() else v) for k, v in g.items()}
+        q64, h64 = R.gnn_agent_forward(gg, h.double(), p64, cfg)
+        hd = h.cuda().requires_grad_(True)
+        q, h2 = net(HeteroBatch.from_arrays(**g).to("cuda"), hd)
+        assert_close(q, q64, 1e-5, f"N={N} q")
+        assert_close(h2, h64, 1e-5, f"N={N} h'")
+        (q.sum() + h2.sum()).backward()
+        assert all(th.isfinite(p_.grad).all() for p_ in net.parameters())
+
+
+def test_mfma_and_valu_kernels_agree_and_order_is_only_a_schedule():
+    """K1 forward: fp32-MFMA kernel vs the VALU kernel of the same library; the degree-sorted hand-out order must not
+    change a single bit of the result."""
+    from uav_bs_ctrl_amd import _lib as L
+    from uav_bs_ctrl_amd.agents.gnn_agents import GATv2Conv
+    hb = to_batch(synth_graph(40, 8, 80, "ragged", seed=21))
+    x_src, off = hb.relation_segments("seen")
+    x_a, N = hb.agent_feat(), hb.num_nodes("agent")
+    th.manual_seed(0)
+    conv = GATv2Conv((4, 2), 64, 4).cuda()
+    p = [t.detach().contiguous() for t in (conv.fc_src.weight, conv.fc_src.bias + 0.1, conv.fc_dst.weight,
+                                           conv.fc_dst.bias - 0.05, conv.attn, conv.res_fc.weight, conv.res_fc.bias)]
+    outs = []
+    for fn, order in ((L.lib().uavgnn_gatv2_fwd, None), (L.lib().uavgnn_gatv2_fwd, hb.relation_order("seen")),
+                      (L.lib().uavgnn_gatv2_fwd_valu, None)):
+        out = th.empty(N, 256, device="cuda")
+        a_save = th.empty(x_src.shape[0], 4, device="cuda")
+        rc = fn(x_src.data_ptr(), 4, x_a.data_ptr(), 2, off.data_ptr(), L.ptr(order), N, *[t.data_ptr() for t in p], 4,
+                64, 0.2, out.data_ptr(), 256, a_save.data_ptr(), L.stream())
+        assert rc == 0
+        outs.append((out, a_save))
+    assert th.equal(outs[0][0], outs[1][0]) and th.equal(outs[0][1], outs[1][1]), "dst_order changed the result"
+    assert_close(outs[0][0], outs[2][0], 2e-6, "mfma vs valu: out")
+    assert_close(outs[0][1], outs[2][1], 2e-6, "mfma vs valu: attention weights")
+    seg = th.repeat_interleave(th.arange(N, device="cuda"), (off[1:] - off[:-1]).long())
+    sums = th.zeros(N, 4, device="cuda").index_add_(0, seg, outs[0][1])
+    deg = (off[1:] - off[:-1]).cuda()
+    assert_close(sums[deg > 0], th.ones_like(sums[deg > 0]), 1e-6, "attention weights sum to one per destination")
