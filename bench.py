@@ -83,7 +83,14 @@ def make_sequence(B, n, M, T, dist_name, device, seed, distinct):
         g.relation_order("seen"), g.relation_order("near")
     obs = [graphs[t % distinct] for t in range(T + 1)]
     N = B * n
-    batch = dict(obs=obs,
+    # the sampled batch in time-major order, as the tensor-native replay hands it over (uav_bs_ctrl_amd/replay.py):
+    # all T+1 observation graphs as ONE graph for the time-batched encoder (steps 1..T again for the target net)
+    from uav_bs_ctrl_amd import batch as hb_batch
+    obs_all, obs_all_next = hb_batch(obs), hb_batch(obs[1:])
+    for g in (obs_all, obs_all_next):
+        g.relation_order("seen"), g.relation_order("near")
+        g.relation_segments("seen"), g.relation_segments("near")
+    batch = dict(obs=obs, obs_all=obs_all, obs_all_next=obs_all_next,
                  h0=th.zeros(N, 256, device=device), h1=0.1 * th.randn(N, 256, device=device, generator=gen),
                  acts=th.randint(9, (T, N, 1), device=device, generator=gen),
                  rews=th.rand(T, B, n, device=device, generator=gen),
@@ -92,17 +99,14 @@ def make_sequence(B, n, M, T, dist_name, device, seed, distinct):
     return batch
 
 
-def alg_bytes_k1_seen(hb, training):
-    """ALGORITHMIC bytes of one K1-forward launch on the `seen` relation:
+def alg_bytes_k1_seen(E, N, training):
+    """ALGORITHMIC bytes / flops of one K1-forward launch on the `seen` relation:
     16 B per edge (x_gt) + per agent 8 (x_a) + 4 (offset) + 4*H (output row) [+ 16 B per edge of saved attention
-    weights when the launch is part of a training forward]."""
-    x, off = hb.relation_segments("seen")
-    E, N = x.shape[0], off.numel() - 1
+    weights when the launch is part of a training forward]; 3360 flop per edge + 3584 per agent."""
     b = 16 * E + N * (8 + 4 + 4 * 256)
     if training:
         b += 16 * E
-    flops = E * 3360 + N * (7168 // 2)
-    return b, flops
+    return b, E * 3360 + N * 3584
 
 
 def measured_traffic(dist_name, n_inf, n_tr, B, n, M):
@@ -266,24 +270,39 @@ def main():
         ktimes = ops.KERNEL_TIMER.summary()
         k = ktimes.get("gatv2_fwd[F=4]")
         if k:
-            b_train, fl = alg_bytes_k1_seen(batch["obs"][0], True)
-            b_inf, _ = alg_bytes_k1_seen(batch["obs"][0], False)
-            # launches in a step: T act + T target (no attn save) and T+1 policy (saves attn weights)
-            n_inf, n_tr = 2 * a.T, a.T + 1
-            avg_bytes = (n_inf * b_inf + n_tr * b_train) / (n_inf + n_tr)
-            ach = avg_bytes / (k["avg_ms"] * 1e-3) / 1e9
+            # every K1-seen launch of the timed region (rollout launches over N_a destinations, the two time-batched
+            # encoder launches of the update over (T+1) N_a / T N_a): achieved = sum(bytes) / sum(time)
+            tot_b = tot_f = 0
+            for (E, N, tr) in k["work"]:
+                b_, f_ = alg_bytes_k1_seen(E, N, tr)
+                tot_b, tot_f = tot_b + b_, tot_f + f_
+            sec = k["total_ms"] * 1e-3
+            ach = tot_b / sec / 1e9
+            # the same figure per launch class: rollout launches (one env-step batch) vs time-batched update launches
+            by_class = {}
+            for cls, sel in (("rollout", lambda N: N <= a.B * a.n), ("update_time_batched", lambda N: N > a.B * a.n)):
+                ms_c = [m for m, (E, N, tr) in zip(k["ms"], k["work"]) if sel(N)]
+                by_c = [alg_bytes_k1_seen(E, N, tr)[0] for (E, N, tr) in k["work"] if sel(N)]
+                if ms_c:
+                    g = sum(by_c) / (sum(ms_c) * 1e-3) / 1e9
+                    by_class[cls] = {"launches": len(ms_c), "avg_launch_ms": sum(ms_c) / len(ms_c), "achieved": g,
+                                     "frac": g / HBM_PEAK_GBS}
+            n_units = sum(N for _, N, _ in k["work"]) / (a.B * a.n)        # launches in units of one env-step batch
+            n_tr = sum(N for _, N, tr in k["work"] if tr) / (a.B * a.n)
+            traffic = measured_traffic(a.dist, n_units - n_tr, n_tr, a.B, a.n, a.M)
             res["roofline"] = {"bound": "hbm", "kernel": "gatv2_fwd_mfma_kernel<4,64> (K1 forward, seen relation)",
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": measured_traffic(a.dist, n_inf, n_tr, a.B, a.n, a.M),
+                               "traffic": None if traffic is None else traffic * n_units / k["count"],
                                "avg_launch_ms": k["avg_ms"], "launches": k["count"],
-                               "alg_bytes_per_launch": avg_bytes,
-                               "fp32_tflops": fl / (k["avg_ms"] * 1e-3) / 1e12,
-                               "fp32_frac": fl / (k["avg_ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                               "alg_bytes_per_launch": tot_b / k["count"],
+                               "ms_per_env_step_batch": k["total_ms"] / n_units,
+                               "by_launch_class": by_class,
+                               "fp32_tflops": tot_f / sec / 1e12, "fp32_frac": tot_f / sec / 1e12 / FP32_PEAK_TFLOPS,
                                "note": ("D-dense is fp32-compute bound (AI ~ 86 FLOP/B, SURVEY 8d): the attainable HBM "
                                         "fraction is <= 23 % even at the fp32 peak; fp32_frac is the binding roof"
                                         if a.dist == "dense" else
                                         "D-env (94 % of agents see no GT) is write-bound: the HBM roof applies")}
-        res["kernel_ms"] = {n: round(v["avg_ms"], 4) for n, v in ktimes.items()}
+        res["kernel_ms_per_launch"] = {n: round(v["avg_ms"], 4) for n, v in ktimes.items()}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.n, a.M)
         print(json.dumps(res), flush=True)

@@ -192,6 +192,16 @@ def test_learner_update_reproduces_reference_update():
     assert th.equal(acts, logits.argmax(1)) and h2.shape == b["h0"].shape
     acts_r, _ = L.act(b["obs"][0], b["h0"], 1.0)
     assert int(acts_r.min()) >= 0 and int(acts_r.max()) < cfg["n_actions"]
+    # time-batched encoder (all T+1 steps encoded by one call per network): same loss, same update
+    from uav_bs_ctrl_amd import batch as hb_batch
+    L2 = MultiAgentQLearner(env_info, args)
+    L2.policy_net.load_state_dict(p)
+    L2.target_net.load_state_dict(p)
+    b2 = dict(b, obs_all=hb_batch(b["obs"]))
+    out2 = L2.update(b2)
+    assert_close(out2["LossQ"], th.as_tensor(z["loss"]).double(), 1e-5, "LossQ (time-batched)")
+    for (k, p1), (_, p2) in zip(L.policy_net.named_parameters(), L2.policy_net.named_parameters()):
+        assert_close(p2.grad, p1.grad, 2e-5, f"time-batched clipped grad {k}", floor=2e-6)
 
 
 def test_device_side_graph_construction_is_bit_identical_to_host_builder():

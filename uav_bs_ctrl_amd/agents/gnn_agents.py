@@ -269,9 +269,15 @@ class GnnAgent(nn.Module):
     def init_hidden(self):
         return th.zeros(1, self._hidden_size)   # on CPU, as the reference does (gnn_agents.py:48-49)
 
-    def forward(self, g: HeteroBatch, h):
-        n = g.num_nodes("agent")
-        x = self.enc(g, None).view(n, -1)
+    def encode(self, g: HeteroBatch):
+        """Observation encoder only: x [N_a, H].  It does not depend on the hidden state, so a BPTT caller may encode
+        all T+1 time steps of a sampled batch in ONE call on the time-batched graph (uav_bs_ctrl_amd.learner) - one K1
+        launch per relation over (T+1) N_a destinations instead of T+1 small ones."""
+        return self.enc(g, None).view(g.num_nodes("agent"), -1)
+
+    def step(self, g: HeteroBatch, x, h):
+        """Communication block (or plain GRU) + Q head on pre-encoded observations x."""
+        n = x.shape[0]
         if h.shape[0] != n:
             h = h.expand(n, -1)
         h = h.contiguous()
@@ -282,6 +288,9 @@ class GnnAgent(nn.Module):
         if isinstance(self.f_out, DuelingLayer):
             return self.f_out(h), h
         return ops.linear(h, self.f_out.weight, self.f_out.bias), h
+
+    def forward(self, g: HeteroBatch, h):
+        return self.step(g, self.encode(g), h)
 
 
 class DrqnGnnAgent(nn.Module):

@@ -259,6 +259,24 @@ class HeteroBatch:
                                     order.to(th.int32).contiguous())
         return self._cache["talkT"]
 
+    def slice_agents(self, lo: int, hi: int) -> "HeteroBatch":
+        """Observation part (agent features + `seen`/`near`) of agents [lo, hi) as a new HeteroBatch whose feature
+        arrays are VIEWS of this one (segments are contiguous) and whose offsets are rebased.  Used to address a span
+        of time steps inside a time-batched graph; the talk relation is per time step and is not carried over."""
+        feat = {"agent": {"feat": self._feat["agent"]["feat"][lo:hi]}}
+        rels, num_nodes = {}, {"agent": hi - lo}
+        for c, r in self._rels.items():
+            if c == TALK:
+                continue
+            if r.src is not None:
+                raise NotImplementedError("slice_agents needs the segment layout (src id == edge id)")
+            off = r.off[lo:hi + 1]
+            e0, e1 = int(off[0]), int(off[-1])
+            rels[c] = _Relation((off - off[0]).contiguous())
+            feat[c[0]] = {"feat": self._feat[c[0]]["feat"][e0:e1]}
+            num_nodes[c[0]] = e1 - e0
+        return HeteroBatch(num_nodes, rels, feat)
+
     def __repr__(self):
         e = {c[1]: r.num_edges for c, r in self._rels.items()}
         return f"HeteroBatch(num_nodes={self._num_nodes}, num_edges={e}, device={self.device})"

@@ -132,19 +132,40 @@ class MultiAgentQLearner:
     def loss(self, batch: Dict) -> tuple:
         """Forward part of ``update`` (learner.py:110-154).  batch: obs (list of T+1 HeteroBatch of B envs each),
         h0 / h1 [B*n, H] (stored hidden states of the first two steps), acts [T, B*n, 1] int64,
-        rews [T, B, n or 1], dones [T, B, 1]."""
+        rews [T, B, n or 1], dones [T, B, 1]; optional obs_all = the T+1 observation graphs batched in time-major
+        order (``graph.batch(obs)``), which switches on the time-batched encoder."""
         obs = batch["obs"]
         T = len(obs) - 1
         h, h_targ = batch["h0"], batch["h1"]
         agent_out, target_out = [], []
-        for t in range(T):
-            logits, h = self.policy_net(obs[t], h)
-            agent_out.append(logits)
+        obs_all = batch.get("obs_all")
+        if obs_all is not None and hasattr(self.policy_net, "encode"):
+            # Time-batched encoder: the observation encoder does not depend on h, so all T+1 steps are encoded by ONE
+            # call per network (one K1 launch per relation over (T+1) N_a destinations, one f_aggr GEMM); only the
+            # recurrent part (comm block, GRU, head) walks the sequence.  Same arithmetic as 2T+1 separate forwards.
+            N = h.shape[0]
+            x_pol = self.policy_net.encode(obs_all)
             with th.no_grad():
-                nxt, h_targ = self.target_net(obs[t + 1], h_targ)
-                target_out.append(nxt)
-        logits, h = self.policy_net(obs[T], h)
-        agent_out.append(logits)
+                x_tgt = self.target_net.encode(batch.get("obs_all_next") or obs_all.slice_agents(N, (T + 1) * N))
+            xs = x_pol.view(T + 1, N, -1).unbind(0)     # unbind: its backward is ONE stack, not T+1 padded adds
+            xt = x_tgt.view(T, N, -1)
+            for t in range(T):
+                logits, h = self.policy_net.step(obs[t], xs[t], h)
+                agent_out.append(logits)
+                with th.no_grad():
+                    nxt, h_targ = self.target_net.step(obs[t + 1], xt[t], h_targ)
+                    target_out.append(nxt)
+            logits, h = self.policy_net.step(obs[T], xs[T], h)
+            agent_out.append(logits)
+        else:
+            for t in range(T):
+                logits, h = self.policy_net(obs[t], h)
+                agent_out.append(logits)
+                with th.no_grad():
+                    nxt, h_targ = self.target_net(obs[t + 1], h_targ)
+                    target_out.append(nxt)
+            logits, h = self.policy_net(obs[T], h)
+            agent_out.append(logits)
         agent_out, target_out = th.stack(agent_out), th.stack(target_out)
 
         qvals = agent_out[:-1].gather(2, batch["acts"])

@@ -25,8 +25,8 @@ class _KernelTimer:
         self.enabled = enabled
 
     class _Span:
-        def __init__(self, timer, name):
-            self.t, self.name = timer, name
+        def __init__(self, timer, name, work=None):
+            self.t, self.name, self.work = timer, name, work
 
         def __enter__(self):
             if self.t.enabled:
@@ -38,18 +38,20 @@ class _KernelTimer:
         def __exit__(self, *exc):
             if self.t.enabled:
                 self.e1.record()
-                self.t._spans.setdefault(self.name, []).append((self.e0, self.e1))
+                self.t._spans.setdefault(self.name, []).append((self.e0, self.e1, self.work))
             return False
 
-    def span(self, name):
-        return _KernelTimer._Span(self, name)
+    def span(self, name, work=None):
+        """work: optional tuple describing the launch (edges, destinations, saves-attention flag) for byte accounting."""
+        return _KernelTimer._Span(self, name, work)
 
     def summary(self):
         th.cuda.synchronize()
         out = {}
         for name, pairs in self._spans.items():
-            ms = [a.elapsed_time(b) for a, b in pairs]
-            out[name] = dict(count=len(ms), avg_ms=sum(ms) / len(ms), total_ms=sum(ms))
+            ms = [a.elapsed_time(b) for a, b, _ in pairs]
+            out[name] = dict(count=len(ms), avg_ms=sum(ms) / len(ms), total_ms=sum(ms), ms=ms,
+                             work=[w for _, _, w in pairs if w is not None])
         return out
 
 
@@ -83,7 +85,7 @@ class _HeteroGATv2(th.autograd.Function):
             b_r_c = None if b_r is None else L.f32c(b_r.detach())
             need = any(ctx.needs_input_grad[2 + i * 10 + 3: 2 + i * 10 + 10])
             a_save = th.empty((max(x_src.shape[0], 1), nh), dtype=th.float32, device=x_dst.device) if need else None
-            with KERNEL_TIMER.span(f"gatv2_fwd[F={FS}]"):
+            with KERNEL_TIMER.span(f"gatv2_fwd[F={FS}]", (x_src.shape[0], N, int(need))):
                 rc = L.lib().uavgnn_gatv2_fwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off),
                                               L.ptr(order), N, *[L.ptr(t) for t in p], L.ptr(b_r_c), nh, D, NEG_SLOPE,
                                               out.data_ptr() + 4 * i * H, R * H, L.ptr(a_save), L.stream())
