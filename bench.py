@@ -56,7 +56,7 @@ def synth_batch_gpu(B, n, M, dist_name, device, gen):
         d_seen = th.full((N,), M, dtype=th.int64, device=device)
     else:  # D-env: 94 % of agents see nothing, the rest U{1..0.65 M}
         hi = max(1, int(0.65 * M))
-        z = th.rand(N, device=device, generator=gen) < 0.94
+        z = th.rand(N, device=device, generator=gen) < {"zero": 2.0, "nz": -1.0}.get(dist_name, 0.94)
         d_seen = th.where(z, th.zeros_like(z, dtype=th.int64), th.randint(1, hi + 1, (N,), device=device, generator=gen))
     seen_off = th.zeros(N + 1, dtype=th.int32, device=device)
     seen_off[1:] = th.cumsum(d_seen, 0).to(th.int32)
