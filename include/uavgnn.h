@@ -46,21 +46,21 @@ const char* uavgnn_strerror(int code);
  * as constructed at gnn_agents.py:93-96 and called at :103-104 (and drqn/agents/gnn_agents.py:17-18,:27).
  *   el = W_s x_u + b_s ; er = W_d x_v + b_d ; e = attn . lrelu_slope(el+er) per head ; a = softmax over in-edges ;
  *   out[v] = ReLU( sum_u a el[u] + W_r x_v + b_r )            
- * x_src[E,F_src], x_dst[N,F_dst], seg_off[N+1]; W_s[H,F_src] b_s[H] W_d[H,F_dst] b_d[H] attn[H] W_r[H,F_dst]
+ * x_src[E,F_src] (E = seg_off[N], also used to pick the schedule for sparse batches), x_dst[N,F_dst], seg_off[N+1]; W_s[H,F_src] b_s[H] W_d[H,F_dst] b_d[H] attn[H] W_r[H,F_dst]
  * b_r[H] (b_r may be NULL = zeros), H = nh*D.  out is written at out[v*ld_out + 0..H) (so two relations can share one
  * [N,2H] buffer = the th.cat of gnn_agents.py:106).  attn_save[E,nh] (may be NULL) receives the softmax weights for
  * the backward.  dst_order[N] (may be NULL = identity) is the order in which destinations are handed to the persistent
  * wavefronts; passing the destinations sorted by decreasing degree balances ragged batches (longest-first).  It only
  * affects scheduling, never results.  Supported: F_src in {2,4}, F_dst == 2, H <= 256, D in {8,16,32,64}.
  */
-int uavgnn_gatv2_fwd(const float* x_src, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
+int uavgnn_gatv2_fwd(const float* x_src, int E, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
                      const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
                      const float* W_r, const float* b_r, int nh, int D, float slope, float* out, int ld_out,
                      float* attn_save, uavgnn_stream_t stream);
 
 /* Same contract, always the plain-VALU kernel (every (nh, D) instantiation; uavgnn_gatv2_fwd prefers the fp32-MFMA
  * kernel when nh == 4 and D in {16,32,64}).  Kept exported as the in-library A/B reference of the MFMA kernel. */
-int uavgnn_gatv2_fwd_valu(const float* x_src, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
+int uavgnn_gatv2_fwd_valu(const float* x_src, int E, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
                           const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
                           const float* W_r, const float* b_r, int nh, int D, float slope, float* out, int ld_out,
                           float* attn_save, uavgnn_stream_t stream);
@@ -70,7 +70,7 @@ int uavgnn_gatv2_fwd_valu(const float* x_src, int F_src, const float* x_dst, int
  * workgroup partials in `workspace` are combined in a fixed order by a second launch (no float atomics).
  * workspace >= uavgnn_gatv2_bwd_workspace_bytes(F_src, nh*D). */
 size_t uavgnn_gatv2_bwd_workspace_bytes(int F_src, int H);
-int uavgnn_gatv2_bwd(const float* x_src, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
+int uavgnn_gatv2_bwd(const float* x_src, int E, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
                      const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
                      int nh, int D, float slope, const float* out, const float* d_out, int ld_out,
                      const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d, float* dattn,

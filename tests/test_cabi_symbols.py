@@ -29,6 +29,6 @@ def test_library_builds_loads_and_exports_every_declared_symbol(repo_root):
 def test_argument_errors_are_codes_not_crashes():
     L = _lib.lib()
     assert L.uavgnn_gru_gates_fwd(None, None, None, 4, 8, None, None) == -1000
-    assert L.uavgnn_gatv2_fwd(None, 4, None, 2, None, None, 3, None, None, None, None, None, None, None, 4, 64, 0.2, None,
+    assert L.uavgnn_gatv2_fwd(None, 0, 4, None, 2, None, None, 3, None, None, None, None, None, None, None, 4, 64, 0.2, None,
                               256, None, None) == -1000
     assert L.uavgnn_gatv2_bwd_workspace_bytes(4, 256) == 1024 * 256 * 12 * 4

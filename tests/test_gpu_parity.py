@@ -299,7 +299,7 @@ def test_mfma_and_valu_kernels_agree_and_order_is_only_a_schedule():
                       (L.lib().uavgnn_gatv2_fwd_valu, None)):
         out = th.empty(N, 256, device="cuda")
         a_save = th.empty(x_src.shape[0], 4, device="cuda")
-        rc = fn(x_src.data_ptr(), 4, x_a.data_ptr(), 2, off.data_ptr(), L.ptr(order), N, *[t.data_ptr() for t in p], 4,
+        rc = fn(x_src.data_ptr(), x_src.shape[0], 4, x_a.data_ptr(), 2, off.data_ptr(), L.ptr(order), N, *[t.data_ptr() for t in p], 4,
                 64, 0.2, out.data_ptr(), 256, a_save.data_ptr(), L.stream())
         assert rc == 0
         outs.append((out, a_save))

@@ -44,11 +44,11 @@ g = [th.empty_like(t) for t in p]
 wsb = lib.uavgnn_gatv2_bwd_workspace_bytes(FS, 256)
 ws = th.empty(wsb // 4, device=dev)
 for _ in range(a.reps):
-    rc = lib.uavgnn_gatv2_fwd(x_src.data_ptr(), FS, x_a.data_ptr(), 2, off.data_ptr(), ORDER, N, *[t.data_ptr() for t in p], 4, 64,
+    rc = lib.uavgnn_gatv2_fwd(x_src.data_ptr(), x_src.shape[0], FS, x_a.data_ptr(), 2, off.data_ptr(), ORDER, N, *[t.data_ptr() for t in p], 4, 64,
                               0.2, out.data_ptr(), 256, a_save.data_ptr() if (a.save or a.bwd) else None, st)
     assert rc == 0
     if a.bwd:
-        rc = lib.uavgnn_gatv2_bwd(x_src.data_ptr(), FS, x_a.data_ptr(), 2, off.data_ptr(), ORDER, N,
+        rc = lib.uavgnn_gatv2_bwd(x_src.data_ptr(), x_src.shape[0], FS, x_a.data_ptr(), 2, off.data_ptr(), ORDER, N,
                                   *[t.data_ptr() for t in p[:5]], 4, 64, 0.2, out.data_ptr(), d_out.data_ptr(), 256,
                                   a_save.data_ptr(), *[t.data_ptr() for t in g], ws.data_ptr(), wsb, st)
         assert rc == 0

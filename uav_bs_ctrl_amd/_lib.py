@@ -23,12 +23,12 @@ _c_st = ctypes.c_void_p   # hipStream_t
 SIGNATURES = {
     "uavgnn_version": (_c_int, []),
     "uavgnn_strerror": (ctypes.c_char_p, [_c_int]),
-    "uavgnn_gatv2_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
+    "uavgnn_gatv2_fwd": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                   _c_fp, _c_fp, _c_int, _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_st]),
-    "uavgnn_gatv2_fwd_valu": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
+    "uavgnn_gatv2_fwd_valu": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                        _c_fp, _c_fp, _c_int, _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_st]),
     "uavgnn_gatv2_bwd_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
-    "uavgnn_gatv2_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
+    "uavgnn_gatv2_bwd": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                   _c_int, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                   _c_fp, _c_fp, _c_fp, ctypes.c_void_p, ctypes.c_size_t, _c_st]),
     "uavgnn_talk_attn_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip,

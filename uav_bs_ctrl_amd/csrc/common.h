@@ -49,7 +49,7 @@ inline int capped_grid(long long work_items, int per_block, int cap = 2048) {
 }
 
 // gatv2_mfma.hip: fp32-MFMA K1 forward; returns UAVGNN_EUNSUPPORTED when (F_src, nh, D) has no MFMA instantiation.
-int gatv2_fwd_mfma(int F_src, int nh, int D, const float* x_src, const float* x_dst, const int32_t* seg_off,
+int gatv2_fwd_mfma(int F_src, int nh, int D, const float* x_src, int E, const float* x_dst, const int32_t* seg_off,
                    const int32_t* dst_order, int N,
                    const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
                    const float* W_r, const float* b_r, float slope, float* out, int ld_out, float* a_save,

@@ -502,17 +502,18 @@ using namespace uavgnn;
   UAVGNN_DISPATCH(4, 1, 64, CALL)    \
   UAVGNN_DISPATCH(2, 1, 64, CALL)
 
-static int gatv2_fwd_checked(bool allow_mfma, const float* x_src, int F_src, const float* x_dst, int F_dst,
+static int gatv2_fwd_checked(bool allow_mfma, const float* x_src, int E, int F_src, const float* x_dst, int F_dst,
                              const int32_t* seg_off, const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d,
                              const float* b_d, const float* attn, const float* W_r, const float* b_r, int nh, int D,
                              float slope, float* out, int ld_out, float* attn_save, uavgnn_stream_t stream) {
-  if (N < 0 || !seg_off || !x_dst || !W_s || !b_s || !W_d || !b_d || !attn || !W_r || !out || ld_out < nh * D)
+  if (N < 0 || E < 0 || (E > 0 && !x_src) || !seg_off || !x_dst || !W_s || !b_s || !W_d || !b_d || !attn || !W_r ||
+      !out || ld_out < nh * D)
     return UAVGNN_EINVAL;
   if (F_dst != 2) return UAVGNN_EUNSUPPORTED;
   if (N == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (allow_mfma) {
-    const int rc = gatv2_fwd_mfma(F_src, nh, D, x_src, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope,
+    const int rc = gatv2_fwd_mfma(F_src, nh, D, x_src, E, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope,
                                   out, ld_out, attn_save, st);
     if (rc != UAVGNN_EUNSUPPORTED) return rc;
   }
@@ -521,20 +522,20 @@ static int gatv2_fwd_checked(bool allow_mfma, const float* x_src, int F_src, con
   return UAVGNN_EUNSUPPORTED;
 }
 
-extern "C" int uavgnn_gatv2_fwd(const float* x_src, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
+extern "C" int uavgnn_gatv2_fwd(const float* x_src, int E, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
                                 const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d,
                                 const float* attn, const float* W_r, const float* b_r, int nh, int D, float slope,
                                 float* out, int ld_out, float* attn_save, uavgnn_stream_t stream) {
-  return gatv2_fwd_checked(true, x_src, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
+  return gatv2_fwd_checked(true, x_src, E, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
                            slope, out, ld_out, attn_save, stream);
 }
 
-extern "C" int uavgnn_gatv2_fwd_valu(const float* x_src, int F_src, const float* x_dst, int F_dst,
+extern "C" int uavgnn_gatv2_fwd_valu(const float* x_src, int E, int F_src, const float* x_dst, int F_dst,
                                      const int32_t* seg_off, const int32_t* dst_order, int N, const float* W_s, const float* b_s,
                                      const float* W_d, const float* b_d, const float* attn, const float* W_r,
                                      const float* b_r, int nh, int D, float slope, float* out, int ld_out,
                                      float* attn_save, uavgnn_stream_t stream) {
-  return gatv2_fwd_checked(false, x_src, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
+  return gatv2_fwd_checked(false, x_src, E, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
                            slope, out, ld_out, attn_save, stream);
 }
 
@@ -542,7 +543,7 @@ extern "C" size_t uavgnn_gatv2_bwd_workspace_bytes(int F_src, int H) {
   return static_cast<size_t>(kMaxBwdBlocks) * static_cast<size_t>(H) * (F_src + 8) * sizeof(float);
 }
 
-extern "C" int uavgnn_gatv2_bwd(const float* x_src, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
+extern "C" int uavgnn_gatv2_bwd(const float* x_src, int E, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
                                 const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d,
                                 const float* attn, int nh, int D, float slope, const float* out, const float* d_out,
                                 int ld_out, const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d,

@@ -75,7 +75,12 @@ __device__ __forceinline__ void load_xrow(const float* __restrict__ p, bool vali
 
 constexpr float kLog2e = 1.4426950408889634f;
 
-template <int FS, int D>
+// CHUNK selects how destinations are handed to the per-destination code:
+//   false - scalar loads of (id, offsets, x_v) one iteration ahead: best when every destination carries real work;
+//   true  - 64 destinations' meta data by VECTOR loads (lane <-> destination) + v_readlane: no scalar-load latency
+//           chain, which bounds batches where most agents see nothing (94 % under a random policy): 62 % vs 44 % of
+//           the HBM peak on an all-zero-degree batch of 262 144 agents.
+template <int FS, int D, bool CHUNK>
 __global__ __launch_bounds__(kThreads, 2) void gatv2_fwd_mfma_kernel(
     const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off,
     const int32_t* __restrict__ dst_order, int N, const float* __restrict__ W_s, const float* __restrict__ b_s,
@@ -144,30 +149,13 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_fwd_mfma_kernel(
   float* __restrict__ sw = sS[wave];
 
   const int stride = gridDim.x * kWavesPerBlock;
-  int it = blockIdx.x * kWavesPerBlock + wave;       // position in the hand-out order
-  if (it >= N) return;
-  // destination scalars are fetched one iteration ahead (raw values: nothing derived from them until next iteration)
-  int nv = dst_order ? dst_order[it] : it;
-  float2 nxv = *reinterpret_cast<const float2*>(x_dst + 2 * nv);
-  int ne0 = seg_off[nv], ne1 = seg_off[nv + 1];
-  int nnv = dst_order ? dst_order[min(it + stride, N - 1)] : min(it + stride, N - 1);
+  const int it0 = blockIdx.x * kWavesPerBlock + wave;   // this wave owns positions it0 + k*stride of the hand-out order
 
-  for (; it < N; it += stride) {
-    const int v = nv;
-    const float cxv0 = nxv.x, cxv1 = nxv.y;
-    const int ce0 = ne0, cdeg = ne1 - ne0;
+  auto process = [&](const int v, const int ce0, const int cdeg, const float cxv0, const float cxv1) {
     // first row tile of this destination: issue the loads before anything else
     float xr[FS];
     load_xrow<FS>(x_src + static_cast<size_t>(ce0 + j) * FS, j < cdeg, xr);
     float xBn = (j < cdeg && g < FS) ? x_src[static_cast<size_t>(ce0 + j) * FS + g] : 0.f;
-    {  // clamped look-ahead: always legal addresses, unused after the last iteration
-      nv = nnv;
-      nxv = *reinterpret_cast<const float2*>(x_dst + 2 * nv);
-      ne0 = seg_off[nv];
-      ne1 = seg_off[nv + 1];
-      const int it2 = min(it + 2 * stride, N - 1);
-      nnv = dst_order ? dst_order[it2] : it2;
-    }
     float res[J];
 #pragma unroll
     for (int jj = 0; jj < J; ++jj) res[jj] = fmaf(wr1[jj], cxv1, fmaf(wr0[jj], cxv0, br[jj]));
@@ -178,7 +166,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_fwd_mfma_kernel(
         const int n = lane + kWave * jj;
         if (n < H) orow[n] = fmaxf(res[jj], 0.f);
       }
-      continue;
+      return;
     }
 #pragma unroll
     for (int jj = 0; jj < J; ++jj) {
@@ -264,6 +252,44 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_fwd_mfma_kernel(
       }
     }
     wave_sync_lds();
+  };
+
+  if constexpr (CHUNK) {
+    for (int kb = 0; it0 + kb * stride < N; kb += kWave) {
+      const int my_it = it0 + (kb + lane) * stride;
+      const bool mine = my_it < N;
+      const int m_v = mine ? (dst_order ? dst_order[my_it] : my_it) : 0;
+      const int m_e0 = mine ? seg_off[m_v] : 0;
+      const int m_e1 = mine ? seg_off[m_v + 1] : 0;
+      const float2 m_xv = mine ? *reinterpret_cast<const float2*>(x_dst + 2 * m_v) : make_float2(0.f, 0.f);
+      const int cnt = min(kWave, (N - it0 - kb * stride + stride - 1) / stride);
+      for (int ii = 0; ii < cnt; ++ii) {
+        const int e0 = __builtin_amdgcn_readlane(m_e0, ii);
+        process(__builtin_amdgcn_readlane(m_v, ii), e0, __builtin_amdgcn_readlane(m_e1, ii) - e0,
+                __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(m_xv.x), ii)),
+                __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(m_xv.y), ii)));
+      }
+    }
+  } else {
+    if (it0 >= N) return;
+    // destination scalars are fetched one iteration ahead (raw values: nothing derived from them until next iteration)
+    int nv = dst_order ? dst_order[it0] : it0;
+    float2 nxv = *reinterpret_cast<const float2*>(x_dst + 2 * nv);
+    int ne0 = seg_off[nv], ne1 = seg_off[nv + 1];
+    int nnv = dst_order ? dst_order[min(it0 + stride, N - 1)] : min(it0 + stride, N - 1);
+    for (int it = it0; it < N; it += stride) {
+      const int v = nv, ce0 = ne0, cdeg = ne1 - ne0;
+      const float cxv0 = nxv.x, cxv1 = nxv.y;
+      {  // clamped look-ahead: always legal addresses, unused after the last iteration
+        nv = nnv;
+        nxv = *reinterpret_cast<const float2*>(x_dst + 2 * nv);
+        ne0 = seg_off[nv];
+        ne1 = seg_off[nv + 1];
+        const int it2 = min(it + 2 * stride, N - 1);
+        nnv = dst_order ? dst_order[it2] : it2;
+      }
+      process(v, ce0, cdeg, cxv0, cxv1);
+    }
   }
 }
 
@@ -271,24 +297,30 @@ template <int FS, int D>
 int launch(const float* x_src, const float* x_dst, const int32_t* seg_off, const int32_t* dst_order, int N,
            const float* W_s, const float* b_s,
            const float* W_d, const float* b_d, const float* attn, const float* W_r, const float* b_r, float slope,
-           float* out, int ld_out, float* a_save, hipStream_t st) {
+           float* out, int ld_out, float* a_save, bool sparse_hint, hipStream_t st) {
   const int grid = capped_grid(N, kWavesPerBlock, 512);  // persistent: 2 workgroups per CU, constants loaded once
-  hipLaunchKernelGGL((gatv2_fwd_mfma_kernel<FS, D>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, dst_order,
-                     N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope, out, ld_out, a_save);
+  if (sparse_hint)
+    hipLaunchKernelGGL((gatv2_fwd_mfma_kernel<FS, D, true>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off,
+                       dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope, out, ld_out, a_save);
+  else
+    hipLaunchKernelGGL((gatv2_fwd_mfma_kernel<FS, D, false>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off,
+                       dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope, out, ld_out, a_save);
   return launch_status();
 }
 
 }  // namespace
 
-int gatv2_fwd_mfma(int F_src, int nh, int D, const float* x_src, const float* x_dst, const int32_t* seg_off,
+int gatv2_fwd_mfma(int F_src, int nh, int D, const float* x_src, int E, const float* x_dst, const int32_t* seg_off,
                    const int32_t* dst_order, int N,
                    const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
                    const float* W_r, const float* b_r, float slope, float* out, int ld_out, float* a_save,
                    hipStream_t st) {
   if (nh != NH) return UAVGNN_EUNSUPPORTED;
+  const bool sparse_hint = static_cast<long long>(E) < 16LL * N;   // mean in-degree below one row tile
 #define UAVGNN_MFMA_CASE(FSV, DV)                                                                                  \
   if (F_src == FSV && D == DV)                                                                                     \
-    return launch<FSV, DV>(x_src, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope, out, ld_out, a_save, st);
+    return launch<FSV, DV>(x_src, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope, out, ld_out, a_save,  \
+                           sparse_hint, st);
   UAVGNN_MFMA_CASE(4, 64)
   UAVGNN_MFMA_CASE(2, 64)
   UAVGNN_MFMA_CASE(4, 32)

@@ -86,7 +86,7 @@ class _HeteroGATv2(th.autograd.Function):
             need = any(ctx.needs_input_grad[2 + i * 10 + 3: 2 + i * 10 + 10])
             a_save = th.empty((max(x_src.shape[0], 1), nh), dtype=th.float32, device=x_dst.device) if need else None
             with KERNEL_TIMER.span(f"gatv2_fwd[F={FS}]", (x_src.shape[0], N, int(need))):
-                rc = L.lib().uavgnn_gatv2_fwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off),
+                rc = L.lib().uavgnn_gatv2_fwd(L.ptr(x_src), x_src.shape[0], FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off),
                                               L.ptr(order), N, *[L.ptr(t) for t in p], L.ptr(b_r_c), nh, D, NEG_SLOPE,
                                               out.data_ptr() + 4 * i * H, R * H, L.ptr(a_save), L.stream())
             L.check(rc, "uavgnn_gatv2_fwd")
@@ -117,7 +117,7 @@ class _HeteroGATv2(th.autograd.Function):
             ws_bytes = L.lib().uavgnn_gatv2_bwd_workspace_bytes(FS, H)
             ws = th.empty(ws_bytes // 4, dtype=th.float32, device=dev)
             with KERNEL_TIMER.span(f"gatv2_bwd[F={FS}]"):
-                rc = L.lib().uavgnn_gatv2_bwd(L.ptr(x_src), FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off),
+                rc = L.lib().uavgnn_gatv2_bwd(L.ptr(x_src), x_src.shape[0], FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off),
                                               L.ptr(order) if has_ord else None, N, L.ptr(W_s), L.ptr(b_s), L.ptr(W_d), L.ptr(b_d), L.ptr(attn), nh, H // nh,
                                               NEG_SLOPE, out.data_ptr() + 4 * i * H, d_out.data_ptr() + 4 * i * H,
                                               R * H, L.ptr(a_save), *[L.ptr(t) for t in g], ws.data_ptr(), ws_bytes,
