@@ -7,7 +7,7 @@ import torch as th
 
 from oracle.closed_form import closed_form_tensor
 from tests.util import GOLDEN, assert_close
-from uav_bs_ctrl_amd.agents.mixers import QMixer
+from uav_bs_ctrl_amd.agents.qmix import QMixer
 from uav_bs_ctrl_amd.replay import SequenceReplay
 
 

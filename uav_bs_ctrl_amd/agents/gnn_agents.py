@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..graph import HeteroBatch, RelationView
-from .dueling import DuelingLayer
+from .heads import DuelingLayer
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -89,7 +89,7 @@ class MultiAgentQLearner:
         if getattr(args, "mixer", False):   # QMIX (learner.py:35-40); every launcher of the reference sets mixer=False
             from copy import deepcopy
 
-            from .agents.mixers import QMixer
+            from .agents.qmix import QMixer
             self.mixer = QMixer(env_info["state_shape"], self.n_agents, args).to(self.device)
             broadcast_parameters(self.mixer, 0, process_group)
             self.target_mixer = deepcopy(self.mixer)
