@@ -310,3 +310,66 @@ def test_mfma_and_valu_kernels_agree_and_order_is_only_a_schedule():
     sums = th.zeros(N, 4, device="cuda").index_add_(0, seg, outs[0][1])
     deg = (off[1:] - off[:-1]).cuda()
     assert_close(sums[deg > 0], th.ones_like(sums[deg > 0]), 1e-6, "attention weights sum to one per destination")
+
+
+def _random_talk(N, max_deg, seed):
+    """Random CSC with in-degrees in [0, max_deg] (some zero), arbitrary sources; returns a HeteroBatch with talk only."""
+    from uav_bs_ctrl_amd import HeteroBatch
+    gen = th.Generator().manual_seed(seed)
+    deg = th.randint(0, max_deg + 1, (N,), generator=gen)
+    deg[0] = max_deg
+    deg[1] = 0
+    off = th.zeros(N + 1, dtype=th.int32)
+    off[1:] = th.cumsum(deg, 0).to(th.int32)
+    src = th.randint(0, N, (int(off[-1]),), generator=gen).to(th.int32)
+    return HeteroBatch.from_arrays(x_a=th.zeros(N, 2), talk_off=off, talk_src=src), off, src
+
+
+@pytest.mark.parametrize("N,max_deg,K,M", [(40, 150, 16, 64), (300, 9, 5, 200), (64, 70, 64, 256), (17, 3, 1, 1)])
+def test_talk_attention_kernel_vs_oracle(N, max_deg, K, M):
+    """K3b alone, incl. in-degree > 64 (multi-pass), K / M at their limits, zero-in-degree nodes, duplicate edges."""
+    from uav_bs_ctrl_amd import ops
+    g, off, src = _random_talk(N, max_deg, seed=N)
+    g = g.to("cuda")
+    gen = th.Generator().manual_seed(1)
+    s, q, v = (th.randn(N, d, generator=gen) for d in (K, K, M))
+    w = th.randn(N, M, generator=gen)
+    dst = R.seg_ids(off)
+
+    def ref(s_, q_, v_, uniform):
+        if uniform:
+            return R.segment_mean(v_[src.long()], dst, N)
+        e = (s_[src.long()] * q_[dst]).sum(-1, keepdim=True) / K
+        return R.segment_sum(v_[src.long()] * R.segment_softmax(e, dst, N), dst, N)
+
+    for uniform in (False, True):
+        s64, q64, v64 = (t.double().requires_grad_(True) for t in (s, q, v))
+        c64 = ref(s64, q64, v64, uniform)
+        g64 = th.autograd.grad((c64 * w.double()).sum(), [v64] if uniform else [s64, q64, v64])
+        sd, qd, vd = (t.cuda().requires_grad_(True) for t in (s, q, v))
+        c = ops.talk_attention(None if uniform else sd, None if uniform else qd, vd, g, 1.0 / K)
+        assert_close(c, c64, 1e-5, f"c uniform={uniform}")
+        got = th.autograd.grad((c * w.cuda()).sum(), [vd] if uniform else [sd, qd, vd])
+        for a, b, nm in zip(got, g64, ["d_v"] if uniform else ["d_s", "d_q", "d_v"]):
+            assert_close(a, b, 1e-4, f"{nm} uniform={uniform}", floor=1e-6)
+
+
+@pytest.mark.parametrize("N,H", [(1000, 256), (33, 30), (5, 7)])
+def test_gru_gates_kernel_vs_oracle(N, H):
+    from uav_bs_ctrl_amd import ops
+    gen = th.Generator().manual_seed(H)
+    gi, gh, h, w = (th.randn(N, d, generator=gen) for d in (3 * H, 3 * H, H, H))
+
+    def ref(gi_, gh_, h_):
+        r = th.sigmoid(gi_[:, :H] + gh_[:, :H])
+        z = th.sigmoid(gi_[:, H:2 * H] + gh_[:, H:2 * H])
+        n = th.tanh(gi_[:, 2 * H:] + r * gh_[:, 2 * H:])
+        return (1 - z) * n + z * h_
+    a64 = [t.double().requires_grad_(True) for t in (gi, gh, h)]
+    o64 = ref(*a64)
+    g64 = th.autograd.grad((o64 * w.double()).sum(), a64)
+    ad = [t.cuda().requires_grad_(True) for t in (gi, gh, h)]
+    o = ops.gru_gates(*ad)
+    assert_close(o, o64, 1e-5, "h'")
+    for a, b, nm in zip(th.autograd.grad((o * w.cuda()).sum(), ad), g64, ("d_gi", "d_gh", "d_h")):
+        assert_close(a, b, 1e-5, nm, floor=1e-7)
