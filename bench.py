@@ -24,6 +24,7 @@ cores on a bounded sample of the same cycle.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -235,12 +236,22 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
+    # Python's cyclic GC is kept out of the timed region (a gen-2 pass over the autograd objects of a 101-forward
+    # BPTT graph stalls the launch thread for 70-100 ms roughly every 8th step); memory is released by reference
+    # counting as usual.
+    gc.collect()
+    gc.disable()
     ops.KERNEL_TIMER.reset(enabled=True)
     t0 = time.perf_counter()
+    marks = []
     for _ in range(a.steps):
         out = step()
+        ev = th.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append(ev)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     ops.KERNEL_TIMER.enabled = False
     el = th.tensor([elapsed], device=device, dtype=th.float64)
     if use_dist:
@@ -265,6 +276,7 @@ def main():
                                    f"act forwards + 1 update ({2 * a.T + 1} forwards + BPTT backward + AdamW)",
                        "global_batch": world * a.B, "seq_len": a.T, "parallelism": f"dp{world}"},
             "loss": loss,
+            "step_ms_device": [round(marks[i - 1].elapsed_time(marks[i]), 1) for i in range(1, len(marks))],
         }
         # ---- roofline of the dominant message-passing kernel (K1 forward, seen relation) -------------------------
         ktimes = ops.KERNEL_TIMER.summary()
