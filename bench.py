@@ -233,6 +233,7 @@ def main():
             dist.barrier()
         th.cuda.synchronize()
 
+    ops.KERNEL_TIMER.reset(enabled=True)   # warm-up runs instrumented too, so the event pool exists before timing
     for _ in range(a.warmup):
         step()
     barrier()
