@@ -143,3 +143,21 @@ def test_general_unsorted_relation_is_gathered_into_segments():
     xs, off = g.relation_segments("seen")
     assert off.tolist() == [0, 2, 4]
     assert th.equal(xs, feat[[0, 3, 2, 1]])
+
+
+def test_slice_agents_views_and_relation_order():
+    rng = np.random.default_rng(4)
+    gs = [from_obs_dicts(_obs(rng, 4, 9), np.zeros((4, 4)), r_comm=1.0) for _ in range(3)]
+    big = batch(gs)
+    mid = big.slice_agents(4, 8)                       # the agents of the second environment
+    for et in ("seen", "near"):
+        xs, off = mid.relation_segments(et)
+        xr, offr = gs[1].relation_segments(et)
+        assert th.equal(off, offr) and th.equal(xs, xr)
+        assert xs.data_ptr() >= big.relation_segments(et)[0].data_ptr()      # a view, not a copy
+    assert th.equal(mid.agent_feat(), gs[1].agent_feat()) and not mid.has_relation("talk")
+    order = big.relation_order("seen")
+    _, off = big.relation_segments("seen")
+    deg = (off[1:] - off[:-1])[order.long()]
+    assert sorted(order.tolist()) == list(range(12)) and bool((deg[1:] <= deg[:-1]).all())
+    assert big.graph_off.tolist() == [0, 4, 8, 12]

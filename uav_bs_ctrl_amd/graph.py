@@ -30,8 +30,6 @@ SEEN = ("gt", "seen", "agent")
 NEAR = ("ubs", "near", "agent")
 TALK = ("agent", "talk", "agent")
 SEEN_BY = ("gt", "seen-by", "agent")  # DRQN twin (algos/drqn/utils/env_wrappers.py:66)
-_REL_OF_NAME = {"seen": SEEN, "near": NEAR, "talk": TALK, "seen-by": SEEN_BY}
-_SRC_KEY = {"seen": "gt", "near": "ubs", "seen-by": "gt"}
 
 
 def _i32(x, device=None) -> th.Tensor:
@@ -343,15 +341,16 @@ def batch(graphs: Sequence[HeteroBatch]) -> HeteroBatch:
             s_base += g._num_nodes.get(c[0], 0)
         rels[c] = _Relation(th.cat(offs).to(th.int32), th.cat(srcs).to(th.int32) if need_src else None,
                             th.cat(eids).to(th.int32) if has_eid and eids else None)
-    counts = []
-    for g in graphs:
+    parts, base = [th.zeros(1, dtype=th.int32, device=g0.device)], 0
+    for g in graphs:                       # env boundaries of the union, without leaving the device
+        n_ag = g._num_nodes.get("agent", 0)
         if g.graph_off is not None:
-            counts += (g.graph_off[1:] - g.graph_off[:-1]).tolist()
+            parts.append(g.graph_off[1:].to(g0.device) + base)
         else:
-            counts.append(g._num_nodes.get("agent", 0))
-    go = th.zeros(len(counts) + 1, dtype=th.int32)
-    go[1:] = th.cumsum(th.as_tensor(counts, dtype=th.int64), 0).to(th.int32)
-    return HeteroBatch(num_nodes, rels, feat, go.to(g0.device) if g0._feat.get("agent") else go)
+            parts.append(th.full((1,), base + n_ag, dtype=th.int32, device=g0.device))
+        base += n_ag
+    go = th.cat(parts).to(th.int32)
+    return HeteroBatch(num_nodes, rels, feat, go.to(g0.device))
 
 
 def merge(graphs: Sequence[HeteroBatch]) -> HeteroBatch:
