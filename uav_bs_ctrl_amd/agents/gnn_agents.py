@@ -13,7 +13,6 @@ from __future__ import annotations
 
 import torch as th
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..graph import HeteroBatch, RelationView
@@ -82,7 +81,7 @@ class GraphObservationEncoder(nn.Module):
             rels.append((x_src, off, g.relation_order(et), self.f_conv[et]))
         x_cat = ops.hetero_gatv2(x_a, self._n_heads, rels)                  # [N_a, 2H]
         lin = self.f_aggr[0]
-        return F.relu(ops.linear(x_cat, lin.weight, lin.bias))
+        return ops.linear_relu(x_cat, lin.weight, lin.bias)
 
 
 class DenseObservationEncoder(nn.Module):

@@ -245,6 +245,10 @@ class _LinearSplitK(th.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
+        return _LinearSplitK._grads(ctx, x, W, dy, ctx.has_bias)
+
+    @staticmethod
+    def _grads(ctx, x, W, dy, has_bias):
         dy = dy.contiguous()
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
@@ -260,13 +264,35 @@ class _LinearSplitK(th.autograd.Function):
                 dW = part.sum(0)
             else:
                 dW = th.mm(dy.t(), x)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dW, db
 
 
 def linear(x, W, b=None):
     return _LinearSplitK.apply(x, W, b)
+
+
+class _LinearReLU(th.autograd.Function):
+    """relu(x W^T + b) with the bias + ReLU applied in the GEMM epilogue (hipBLASLt, via ``torch._addmm_activation``):
+    the separate elementwise pass over [N_a, H] (and over [(T+1) N_a, H] in the time-batched encoder) disappears from
+    the forward.  Backward masks dy with (y > 0) and reuses the split-K weight-gradient path."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        y = th._addmm_activation(b, x, W.t())
+        ctx.save_for_backward(x, W, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        dy = th.where(y > 0, dy, th.zeros((), dtype=dy.dtype, device=dy.device))
+        return _LinearSplitK._grads(ctx, x, W, dy, True)
+
+
+def linear_relu(x, W, b):
+    return _LinearReLU.apply(x, W, b)
 
 
 class _DiscComm(th.autograd.Function):
