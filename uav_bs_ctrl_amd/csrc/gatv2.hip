@@ -193,24 +193,35 @@ __global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
     const float* __restrict__ W_s, const float* __restrict__ b_s, const float* __restrict__ W_d,
     const float* __restrict__ b_d, const float* __restrict__ attn, float slope, const float* __restrict__ out,
     const float* __restrict__ d_out, int ld_out, const float* __restrict__ a_save, float* __restrict__ partial) {
+  // Per destination v (one wavefront), head k, channel n = (k,d), in-edges u with attention a_uk:
+  //   g = d_out * [out > 0];  G[k] = sum_d g[n] W_s[n,:];  de_uk = a_uk (G[k].x_u - T[k]),  T[k] = sum_u a_uk G[k].x_u
+  // With lrelu'(z) = c_lin + c_abs sgn(z), c_lin = (1+s)/2, c_abs = (1-s)/2 (SURVEY A.3 i) everything that is linear in
+  // the edge collapses to per-(destination, head) sums in INPUT space, and only the sign part is per (edge, channel):
+  //   s_un = +de_uk if z_un > 0 else -de_uk;   S1[n] = sum_u s_un;   S2[n,:] = sum_u s_un x_u
+  //   P[k,:] = sum_u de_uk x_u;   Sb[k,:] = sum_u a_uk x_u          (sum_u de_uk = 0)
+  //   d attn[n]  += c_abs (W_s[n,:].S2[n,:] + c[n] S1[n]) + c_lin W_s[n,:].P[k,:]
+  //   d W_s[n,:] += attn[n] (c_abs S2[n,:] + c_lin P[k,:]) + g[n] Sb[k,:]
+  //   d er[v,n]   = attn[n] c_abs S1[n]  ->  d b_s += g + der, d b_d += der, d W_d += der (x) x_v
+  // i.e. F_src FMAs (z) + 2 (sign select) + 1 + F_src FMAs per (edge, channel) instead of ~2 F_src + 8.
   constexpr int H = NH * D;
   constexpr int J = (H + kWave - 1) / kWave;
   constexpr int KF = NH * FS;
   static_assert(KF <= kWave && (kWave % KF) == 0, "nh*F_src must divide 64");
   constexpr int PARTS = kWave / KF;
   constexpr int P = partial_len<FS>(H);
-  constexpr int ES = FS + NH;  // staged floats per edge: x[FS], de[NH]
+  constexpr int ES = FS + 2 * NH;  // staged floats per edge: x[FS], de[NH], a[NH]
 
   __shared__ float sW[H * FS];
   __shared__ float sG[kWavesPerBlock][H];
   __shared__ float sGk[kWavesPerBlock][KF];
-  __shared__ float sSb[kWavesPerBlock][KF];
+  __shared__ float sPS[kWavesPerBlock][2 * KF];   // P[k][f] | Sb[k][f]
   __shared__ float sE[kWavesPerBlock][kWave * ES];
   __shared__ float sRed[P];
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float c_lin = 0.5f * (1.f + slope), c_abs = 0.5f * (1.f - slope);
 
   for (int i = tid; i < H * FS; i += kThreads) sW[i] = W_s[i];
 
@@ -233,11 +244,13 @@ __global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
     bc[j] = ok ? b_d[n] + b_s[n] : 0.f;
     abs_[j] = aWd0[j] = aWd1[j] = abd[j] = aatt[j] = aWr0[j] = aWr1[j] = abr[j] = 0.f;
   }
+  // lanes 0..KF-1 additionally own one (head, feature) pair of the input-space sums P and Sb
+  const int pk = (lane < KF) ? lane / FS : 0, pf = (lane < KF) ? lane % FS : 0;
   __syncthreads();
 
   float* __restrict__ gw = sG[wave];
   float* __restrict__ gk = sGk[wave];
-  float* __restrict__ sb = sSb[wave];
+  float* __restrict__ ps = sPS[wave];
   float* __restrict__ ew = sE[wave];
 
   for (int it = blockIdx.x * kWavesPerBlock + wave; it < N; it += gridDim.x * kWavesPerBlock) {
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
     const float* __restrict__ orow = out + static_cast<size_t>(v) * ld_out;
     const float* __restrict__ grow = d_out + static_cast<size_t>(v) * ld_out;
 
-    float g[J], c[J], der[J];
+    float g[J], c[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const int n = lane + kWave * j;
@@ -257,11 +270,10 @@ __global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
       aWr1[j] = fmaf(g[j], xv1, aWr1[j]);
       abr[j] += g[j];
       c[j] = fmaf(wd1[j], xv1, fmaf(wd0[j], xv0, bc[j]));
-      der[j] = 0.f;
     }
     if (deg == 0) continue;
 
-    // G[k][f] = sum_d g[k,d] W_s[k,d,f]   (d a_uv = G[k].x_u up to a per-destination constant that cancels)
+    // G[k][f] = sum_d g[k,d] W_s[k,d,f]
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const int n = lane + kWave * j;
@@ -280,13 +292,13 @@ __global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
       for (int o = PARTS / 2; o > 0; o >>= 1) gp += __shfl_xor(gp, o);
       if (part == 0) gk[kf] = gp;
     }
-    // sbar[k][f] = sum_u a_uv x_u[f]
+    wave_sync();
+    // T[k] = sum_u a_uk (G[k].x_u): one wave reduction per head
+    float T[NH];
     {
-      float acc[NH][FS];
+      float t[NH];
 #pragma unroll
-      for (int k = 0; k < NH; ++k)
-#pragma unroll
-        for (int f = 0; f < FS; ++f) acc[k][f] = 0.f;
+      for (int k = 0; k < NH; ++k) t[k] = 0.f;
       for (int base = 0; base < deg; base += kWave) {
         if (base + lane < deg) {
           const int u = e0 + base + lane;
@@ -294,51 +306,58 @@ __global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
           load_row<FS>(x_src + static_cast<size_t>(u) * FS, x);
 #pragma unroll
           for (int k = 0; k < NH; ++k) {
-            const float a = a_save[static_cast<size_t>(u) * NH + k];
+            float dot = 0.f;
 #pragma unroll
-            for (int f = 0; f < FS; ++f) acc[k][f] = fmaf(a, x[f], acc[k][f]);
+            for (int f = 0; f < FS; ++f) dot = fmaf(gk[k * FS + f], x[f], dot);
+            t[k] = fmaf(a_save[static_cast<size_t>(u) * NH + k], dot, t[k]);
           }
         }
       }
 #pragma unroll
-      for (int k = 0; k < NH; ++k)
-#pragma unroll
-        for (int f = 0; f < FS; ++f) {
-          const float t = wave_sum(acc[k][f]);
-          if (lane == 0) sb[k * FS + f] = t;
-        }
+      for (int k = 0; k < NH; ++k) T[k] = wave_sum(t[k]);
     }
-    wave_sync();
+
+    float S1[J], S2[J][FS];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      S1[j] = 0.f;
+#pragma unroll
+      for (int f = 0; f < FS; ++f) S2[j][f] = 0.f;
+    }
+    float accP = 0.f, accSb = 0.f;   // lanes < KF: P[pk][pf], Sb[pk][pf]
 
     for (int base = 0; base < deg; base += kWave) {
-      // stage x_u and de[u,k] = a_uv (G[k].(x_u - sbar[k])) of up to 64 edges in LDS (lane <-> edge)
-      {
+      {  // stage x_u, de_uk, a_uk of up to 64 edges in LDS (lane <-> edge)
         const bool valid = base + lane < deg;
         const int u = e0 + base + lane;
-        float x[FS];
-        float de[NH];
+        float x[FS], de[NH], a[NH];
         if (valid) {
           load_row<FS>(x_src + static_cast<size_t>(u) * FS, x);
 #pragma unroll
           for (int k = 0; k < NH; ++k) {
             float dot = 0.f;
 #pragma unroll
-            for (int f = 0; f < FS; ++f) dot = fmaf(gk[k * FS + f], x[f] - sb[k * FS + f], dot);
-            de[k] = a_save[static_cast<size_t>(u) * NH + k] * dot;
+            for (int f = 0; f < FS; ++f) dot = fmaf(gk[k * FS + f], x[f], dot);
+            a[k] = a_save[static_cast<size_t>(u) * NH + k];
+            de[k] = a[k] * (dot - T[k]);
           }
         } else {
 #pragma unroll
           for (int f = 0; f < FS; ++f) x[f] = 0.f;
 #pragma unroll
-          for (int k = 0; k < NH; ++k) de[k] = 0.f;
+          for (int k = 0; k < NH; ++k) de[k] = a[k] = 0.f;
         }
 #pragma unroll
         for (int f = 0; f < FS; ++f) ew[lane * ES + f] = x[f];
 #pragma unroll
-        for (int k = 0; k < NH; ++k) ew[lane * ES + FS + k] = de[k];
+        for (int k = 0; k < NH; ++k) {
+          ew[lane * ES + FS + k] = de[k];
+          ew[lane * ES + FS + NH + k] = a[k];
+        }
       }
       wave_sync();
       const int cnt = min(kWave, deg - base);
+#pragma unroll 4
       for (int i = 0; i < cnt; ++i) {  // lane <-> channel, edge data is a broadcast LDS read
         float xe[FS];
 #pragma unroll
@@ -349,26 +368,39 @@ __global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
           float z = c[j];
 #pragma unroll
           for (int f = 0; f < FS; ++f) z = fmaf(Ws[j][f], xe[f], z);
-          const bool pos = z > 0.f;
-          const float lz = pos ? z : slope * z;
-          aatt[j] = fmaf(dek, lz, aatt[j]);
-          const float dz = dek * att[j] * (pos ? 1.f : slope);
-          der[j] += dz;
+          const float sde = z > 0.f ? dek : -dek;
+          S1[j] += sde;
 #pragma unroll
-          for (int f = 0; f < FS; ++f) aWs[j][f] = fmaf(dz, xe[f], aWs[j][f]);
+          for (int f = 0; f < FS; ++f) S2[j][f] = fmaf(sde, xe[f], S2[j][f]);
         }
+        const float xpf = ew[i * ES + pf];
+        accP = fmaf(ew[i * ES + FS + pk], xpf, accP);
+        accSb = fmaf(ew[i * ES + FS + NH + pk], xpf, accSb);
       }
       wave_sync();
     }
+    if (lane < KF) {
+      ps[lane] = accP;
+      ps[KF + lane] = accSb;
+    }
+    wave_sync();
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      // aggregate path: d el[u] += a_uv g  ->  dW_s += g (x) sbar[k], db_s += g (sum_u a_uv = 1)
+      const int k = kj[j];
+      float wS2 = 0.f, wP = 0.f;
 #pragma unroll
-      for (int f = 0; f < FS; ++f) aWs[j][f] = fmaf(g[j], sb[kj[j] * FS + f], aWs[j][f]);
-      abs_[j] += g[j] + der[j];
-      abd[j] += der[j];
-      aWd0[j] = fmaf(der[j], xv0, aWd0[j]);
-      aWd1[j] = fmaf(der[j], xv1, aWd1[j]);
+      for (int f = 0; f < FS; ++f) {
+        const float pkf = ps[k * FS + f], sbf = ps[KF + k * FS + f];
+        wS2 = fmaf(Ws[j][f], S2[j][f], wS2);
+        wP = fmaf(Ws[j][f], pkf, wP);
+        aWs[j][f] += att[j] * fmaf(c_abs, S2[j][f], c_lin * pkf) + g[j] * sbf;
+      }
+      aatt[j] += fmaf(c_abs, fmaf(c[j], S1[j], wS2), c_lin * wP);
+      const float der = att[j] * c_abs * S1[j];
+      abs_[j] += g[j] + der;
+      abd[j] += der;
+      aWd0[j] = fmaf(der, xv0, aWd0[j]);
+      aWd1[j] = fmaf(der, xv1, aWd1[j]);
     }
     wave_sync();
   }
