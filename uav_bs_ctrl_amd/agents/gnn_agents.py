@@ -127,6 +127,19 @@ class TarMAC(nn.Module):
         self.f_que = nn.Linear(2 * H, self._key_size)
         self.f_udt = nn.GRUCell(H + self._msg_size, H)
 
+    def fused_projection(self):
+        """[f_val; f_sign; f_que] stacked into one [M+2K, 2H] weight (+ bias), rebuilt only when a parameter changed
+        (one optimiser step per update, 151 uses per cycle).  The stacked tensors carry no autograd history: the fused
+        step (ops.tarmac_step) returns / sinks the gradient of the stack and splits it back itself."""
+        ps = (self.f_val.weight, self.f_sign.weight, self.f_que.weight, self.f_val.bias, self.f_sign.bias,
+              self.f_que.bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_fused_key", None) != key:
+            with th.no_grad():
+                self._fused = (th.cat(ps[:3], 0), th.cat(ps[3:], 0))
+            self._fused_key = key
+        return self._fused
+
     def forward(self, g, x, h):
         g = _parent(g)
         H, M, K = self._hidden_size, self._msg_size, self._key_size
@@ -280,6 +293,8 @@ class GnnAgent(nn.Module):
         if h.shape[0] != n:
             h = h.expand(n, -1)
         h = h.contiguous()
+        if self._comm_protocol == "tarmac" and self.f_comm._n_rounds == 1 and isinstance(self.f_out, nn.Linear):
+            return self._tarmac_step(g, x, h)          # headline configuration: one fused autograd node per step
         if self._comm_protocol is not None:
             h = self.f_comm(g["talk"], x, h)
         else:
@@ -287,6 +302,16 @@ class GnnAgent(nn.Module):
         if isinstance(self.f_out, DuelingLayer):
             return self.f_out(h), h
         return ops.linear(h, self.f_out.weight, self.f_out.bias), h
+
+    def _tarmac_step(self, g, x, h):
+        comm = self.f_comm
+        needs = th.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs and ops.GRAD_SINK is None:
+            # no sink: the stacked projection weight must be part of the autograd graph
+            Wp = th.cat((comm.f_val.weight, comm.f_sign.weight, comm.f_que.weight), 0)
+            bp = th.cat((comm.f_val.bias, comm.f_sign.bias, comm.f_que.bias), 0)
+            return ops.tarmac_step(x, h, g, comm, self.f_out, stacked=(Wp, bp))
+        return ops.tarmac_step(x, h, g, comm, self.f_out)
 
     def forward(self, g: HeteroBatch, h):
         return self.step(g, self.encode(g), h)

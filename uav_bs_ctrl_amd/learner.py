@@ -23,6 +23,7 @@ import torch as th
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import ops
 from .agents import REGISTRY as agent_REGISTRY
 
 
@@ -186,8 +187,16 @@ class MultiAgentQLearner:
 
     def update(self, batch: Dict) -> Dict:
         self.grads.zero_()
-        loss, agent_out, _ = self.loss(batch)
-        loss.backward()
+        # weight gradients of the fused recurrent step are accumulated in place across the T+1 steps and folded into
+        # the flat gradient buffer once (ops.WeightGradSink); everything else reaches it through autograd
+        ops.GRAD_SINK = sink = ops.WeightGradSink() if self.device.type == "cuda" else None
+        try:
+            loss, agent_out, _ = self.loss(batch)
+            loss.backward()
+            if sink is not None:
+                sink.flush()
+        finally:
+            ops.GRAD_SINK = None
         self.grads.all_reduce_mean_(self.group)           # the only collective of the data path
         # == nn.utils.clip_grad_value_(policy_net.parameters(), 1): the mixer is NOT clipped (learner.py:159)
         self.grads.flat[:self.n_policy].clamp_(-1.0, 1.0)

@@ -295,6 +295,189 @@ def linear_relu(x, W, b):
     return _LinearReLU.apply(x, W, b)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Fused recurrent step of the TarMAC agent: ONE autograd node per time step.
+
+class WeightGradSink:
+    """In-place accumulator for the weight / bias gradients of the recurrent step across the T+1 steps of a BPTT
+    backward.  Every step adds its contribution INSIDE the weight-gradient GEMM (beta = 1, row chunks batched as in
+    ``_LinearSplitK``), so the per-step ``sum`` over chunks, the per-step bias reduction result and autograd's
+    per-parameter ``AccumulateGrad`` adds (12 parameters x 51 steps small kernels) disappear; ``flush()`` folds the
+    accumulators into ``param.grad`` once, in a fixed order (deterministic)."""
+
+    def __init__(self):
+        self.slots = {}      # key -> (buffer, flush_fn)
+
+    @staticmethod
+    def _chunks(n):
+        S = 1
+        while S < 64 and n % (2 * S) == 0 and n // (2 * S) >= 2048:
+            S *= 2
+        return S
+
+    def weight(self, key, dy, x, flush_fn):
+        """buffer[S, out, in] += chunked dy^T x"""
+        n, S = x.shape[0], self._chunks(x.shape[0])
+        slot = self.slots.get(key)
+        if slot is None or slot[0].shape[0] != S:
+            buf = th.zeros((S, dy.shape[1], x.shape[1]), dtype=th.float32, device=x.device)
+            self.slots[key] = slot = (buf, flush_fn)
+        if S == 1:
+            slot[0][0].addmm_(dy.t(), x)
+        else:
+            slot[0].baddbmm_(dy.view(S, n // S, -1).transpose(1, 2), x.view(S, n // S, -1))
+
+    def bias(self, key, dy, flush_fn):
+        slot = self.slots.get(key)
+        if slot is None:
+            self.slots[key] = slot = (th.zeros(dy.shape[1], dtype=th.float32, device=dy.device), flush_fn)
+        slot[0].add_(dy.sum(0))     # (a transposed GEMV with beta = 1 was measured 20x slower than sum + add)
+
+    def flush(self):
+        for key, (buf, fn) in self.slots.items():
+            if fn is not None:
+                fn(buf.sum(0) if buf.dim() == 3 else buf)
+        self.slots = {}
+
+
+def _wgrad(dy, x):
+    """dy^T x with the reduction over rows split into chunks (see _LinearSplitK)."""
+    n, S = x.shape[0], WeightGradSink._chunks(x.shape[0])
+    if S == 1:
+        return th.mm(dy.t(), x)
+    return th.bmm(dy.view(S, n // S, -1).transpose(1, 2), x.view(S, n // S, -1)).sum(0)
+
+
+GRAD_SINK = None   # set by the learner around loss.backward(); None -> gradients are returned to autograd as usual
+
+
+def _add_grad(p, g):
+    if p.grad is None:
+        p.grad = g.clone()
+    else:
+        p.grad.add_(g)
+
+
+class _TarmacStep(th.autograd.Function):
+    """q, h' = head(GRU([x || c], h)), c = targeted attention over `talk` of the projections of [x || stopgrad(h)]
+    (gnn_agents.py:248-271 with n_rounds = 1, then :56).  Forward: 5 vendor GEMMs + K3b + K4, the projection of the two
+    halves accumulated in place, c written by K3b straight into the GRU input buffer (no cat, no add kernels).
+    Backward: hand-written; weight gradients go to ``GRAD_SINK`` when one is active."""
+
+    @staticmethod
+    def forward(ctx, x, h, Wp, bp, W_ih, b_ih, W_hh, b_hh, W_out, b_out, M, K, talk_off, talk_src, t_off, t_dst, t_pos,
+                split):
+        L.require_gpu(x, h, Wp, W_ih, talk_off)
+        N, H = x.shape
+        x, h = L.f32c(x), L.f32c(h)
+        proj = th.addmm(bp, x, Wp[:, :H].t())
+        proj.addmm_(h, Wp[:, H:].t())                                     # [N, M + 2K]: value | signature | query
+        inp = th.empty((N, H + M), dtype=th.float32, device=x.device)
+        inp[:, :H].copy_(x)
+        E = talk_src.shape[0]
+        a_save = th.empty(max(E, 1), dtype=th.float32, device=x.device)
+        ld = M + 2 * K
+        with KERNEL_TIMER.span("talk_attn_fwd"):
+            rc = L.lib().uavgnn_talk_attn_fwd(proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld,
+                                              proj.data_ptr(), ld, K, M, L.ptr(talk_off), L.ptr(talk_src), N,
+                                              1.0 / K, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(), L.stream())
+        L.check(rc, "uavgnn_talk_attn_fwd")
+        gi = th.addmm(b_ih, inp, W_ih.t())
+        gh = th.addmm(b_hh, h, W_hh.t())
+        h2 = th.empty_like(h)
+        with KERNEL_TIMER.span("gru_gates_fwd"):
+            rc = L.lib().uavgnn_gru_gates_fwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), N, H, h2.data_ptr(), L.stream())
+        L.check(rc, "uavgnn_gru_gates_fwd")
+        q = th.addmm(b_out, h2, W_out.t())
+        ctx.dims = (M, K)
+        ctx.split = split
+        ctx.save_for_backward(x, h, proj, inp, gi, gh, h2, a_save, Wp, W_ih, W_hh, W_out, talk_off, talk_src, t_off,
+                              t_dst, t_pos)
+        return q, h2
+
+    @staticmethod
+    def backward(ctx, dq, dh2):
+        (x, h, proj, inp, gi, gh, h2, a_save, Wp, W_ih, W_hh, W_out, talk_off, talk_src, t_off, t_dst,
+         t_pos) = ctx.saved_tensors
+        M, K = ctx.dims
+        N, H = x.shape
+        sink = GRAD_SINK
+        dq = L.f32c(dq) if dq is not None else th.zeros((N, W_out.shape[0]), dtype=th.float32, device=x.device)
+        dh2_tot = th.mm(dq, W_out) if dh2 is None else th.addmm(dh2, dq, W_out)
+        d_gi, d_gh, dh = th.empty_like(gi), th.empty_like(gh), th.empty_like(h)
+        with KERNEL_TIMER.span("gru_gates_bwd"):
+            rc = L.lib().uavgnn_gru_gates_bwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), dh2_tot.data_ptr(), N, H,
+                                              d_gi.data_ptr(), d_gh.data_ptr(), dh.data_ptr(), L.stream())
+        L.check(rc, "uavgnn_gru_gates_bwd")
+        d_inp = th.mm(d_gi, W_ih)                                          # [N, H + M]: d x | d c
+        dh.addmm_(d_gh, W_hh)
+        ld = M + 2 * K
+        d_proj = th.empty((N, ld), dtype=th.float32, device=x.device)
+        de = th.empty_like(a_save)
+        with KERNEL_TIMER.span("talk_attn_bwd"):
+            rc = L.lib().uavgnn_talk_attn_bwd(proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld,
+                                              proj.data_ptr(), ld, K, M, L.ptr(talk_off), L.ptr(talk_src), L.ptr(t_off),
+                                              L.ptr(t_dst), L.ptr(t_pos), N, 1.0 / K, a_save.data_ptr(),
+                                              d_inp.data_ptr() + 4 * H, H + M, d_proj.data_ptr() + 4 * M, ld,
+                                              d_proj.data_ptr() + 4 * (M + K), ld, d_proj.data_ptr(), ld, de.data_ptr(),
+                                              L.stream())
+        L.check(rc, "uavgnn_talk_attn_bwd")
+        dx = th.addmm(d_inp[:, :H], d_proj, Wp[:, :H])                    # h enters the projections stop-gradded
+        if sink is not None:
+            split = ctx.split
+            sink.weight(("Wp_x", id(Wp)), d_proj, x, lambda g: split("Wp", g, 0))
+            sink.weight(("Wp_h", id(Wp)), d_proj, h, lambda g: split("Wp", g, H))
+            sink.bias(("bp", id(Wp)), d_proj, lambda g: split("bp", g, 0))
+            sink.weight(("W_ih", id(W_ih)), d_gi, inp, lambda g: split("W_ih", g, 0))
+            sink.bias(("b_ih", id(W_ih)), d_gi, lambda g: split("b_ih", g, 0))
+            sink.weight(("W_hh", id(W_hh)), d_gh, h, lambda g: split("W_hh", g, 0))
+            sink.bias(("b_hh", id(W_hh)), d_gh, lambda g: split("b_hh", g, 0))
+            sink.weight(("W_out", id(W_out)), dq, h2, lambda g: split("W_out", g, 0))
+            sink.bias(("b_out", id(W_out)), dq, lambda g: split("b_out", g, 0))
+            gWp = gbp = gWih = gbih = gWhh = gbhh = gWo = gbo = None
+        else:
+            gWp = th.cat((_wgrad(d_proj, x), _wgrad(d_proj, h)), 1)
+            gbp = d_proj.sum(0)
+            gWih, gbih = _wgrad(d_gi, inp), d_gi.sum(0)
+            gWhh, gbhh = _wgrad(d_gh, h), d_gh.sum(0)
+            gWo, gbo = _wgrad(dq, h2), dq.sum(0)
+        return (dx, dh, gWp, gbp, gWih, gbih, gWhh, gbhh, gWo, gbo) + (None,) * 8
+
+
+def tarmac_step(x, h, g, comm, f_out, stacked=None):
+    """comm: the TarMAC module (f_val / f_sign / f_que / f_udt), f_out: nn.Linear head.  Returns (q, h').
+    ``stacked`` = (Wp, bp) built WITH autograd history when no GRAD_SINK will collect the weight gradients."""
+    M, K = comm._msg_size, comm._key_size
+    Wp, bp = stacked if stacked is not None else comm.fused_projection()
+    off, src = g.talk_csc()
+    t_off, t_dst, t_pos = g.talk_transpose()
+    cell = comm.f_udt
+    params = {"W_ih": cell.weight_ih, "b_ih": cell.bias_ih, "W_hh": cell.weight_hh, "b_hh": cell.bias_hh,
+              "W_out": f_out.weight, "b_out": f_out.bias}
+
+    def split(name, grad, col0):
+        """flush target of the sink: distribute an accumulated gradient to the module's parameters."""
+        if name == "Wp":        # rows: f_val | f_sign | f_que ; columns col0 .. col0 + grad.shape[1]
+            r = 0
+            for lin in (comm.f_val, comm.f_sign, comm.f_que):
+                rows = lin.weight.shape[0]
+                if lin.weight.grad is None:
+                    lin.weight.grad = th.zeros_like(lin.weight)
+                lin.weight.grad[:, col0:col0 + grad.shape[1]].add_(grad[r:r + rows])
+                r += rows
+        elif name == "bp":
+            r = 0
+            for lin in (comm.f_val, comm.f_sign, comm.f_que):
+                rows = lin.bias.shape[0]
+                _add_grad(lin.bias, grad[r:r + rows])
+                r += rows
+        else:
+            _add_grad(params[name], grad)
+
+    return _TarmacStep.apply(x, h, Wp, bp, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, f_out.weight,
+                             f_out.bias, M, K, off, src, t_off, t_dst, t_pos, split)
+
+
 class _DiscComm(th.autograd.Function):
     """K5.  Hard Gumbel-softmax messages (straight-through) + OR (max) aggregation of DiscreteComm."""
 
