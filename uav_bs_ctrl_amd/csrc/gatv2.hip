@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void gatv2_fwd_kernel(
 template <int FS>
 __host__ __device__ constexpr int partial_len(int H) { return H * (FS + 8); }
 
-template <int FS, int NH, int D>
+template <int FS, int NH, int D, bool CHUNK>
 __global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
     const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off,
     const int32_t* __restrict__ dst_order, int N,
@@ -253,25 +253,30 @@ __global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
   float* __restrict__ ps = sPS[wave];
   float* __restrict__ ew = sE[wave];
 
-  for (int it = blockIdx.x * kWavesPerBlock + wave; it < N; it += gridDim.x * kWavesPerBlock) {
-    const int v = dst_order ? dst_order[it] : it;
-    const float xv0 = x_dst[2 * v], xv1 = x_dst[2 * v + 1];
-    const int e0 = seg_off[v];
-    const int deg = seg_off[v + 1] - e0;
+  // rows of the forward output and of its gradient for destination v (lane <-> channel)
+  auto load_rows = [&](const int v, float (&o)[J], float (&gr)[J]) {
     const float* __restrict__ orow = out + static_cast<size_t>(v) * ld_out;
     const float* __restrict__ grow = d_out + static_cast<size_t>(v) * ld_out;
-
-    float g[J], c[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const int n = lane + kWave * j;
-      g[j] = (n < H && orow[n] > 0.f) ? grow[n] : 0.f;  // ReLU mask
+      o[j] = n < H ? orow[n] : 0.f;
+      gr[j] = n < H ? grow[n] : 0.f;
+    }
+  };
+
+  auto process = [&](const float (&o_)[J], const float (&gr_)[J], const int e0, const int deg, const float xv0,
+                     const float xv1) {
+    float g[J], c[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      g[j] = o_[j] > 0.f ? gr_[j] : 0.f;  // ReLU mask
       aWr0[j] = fmaf(g[j], xv0, aWr0[j]);
       aWr1[j] = fmaf(g[j], xv1, aWr1[j]);
       abr[j] += g[j];
       c[j] = fmaf(wd1[j], xv1, fmaf(wd0[j], xv0, bc[j]));
     }
-    if (deg == 0) continue;
+    if (deg == 0) return;
 
     // G[k][f] = sum_d g[k,d] W_s[k,d,f]
 #pragma unroll
@@ -403,6 +408,56 @@ __global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
       aWd1[j] = fmaf(der, xv1, aWd1[j]);
     }
     wave_sync();
+  };
+
+  const int stride = gridDim.x * kWavesPerBlock;
+  const int it0 = blockIdx.x * kWavesPerBlock + wave;
+  if constexpr (CHUNK) {   // sparse batches: 64 destinations' meta data by vector loads + v_readlane (see the forward)
+    for (int kb = 0; it0 + kb * stride < N; kb += kWave) {
+      const int my_it = it0 + (kb + lane) * stride;
+      const bool mine = my_it < N;
+      const int m_v = mine ? (dst_order ? dst_order[my_it] : my_it) : 0;
+      const int m_e0 = mine ? seg_off[m_v] : 0;
+      const int m_e1 = mine ? seg_off[m_v + 1] : 0;
+      const float2 m_xv = mine ? *reinterpret_cast<const float2*>(x_dst + 2 * m_v) : make_float2(0.f, 0.f);
+      const int cnt = min(kWave, (N - it0 - kb * stride + stride - 1) / stride);
+      float on[J], gn[J];                       // rows of the NEXT destination are in flight while this one computes
+      load_rows(__builtin_amdgcn_readlane(m_v, 0), on, gn);
+      for (int ii = 0; ii < cnt; ++ii) {
+        float oc[J], gc[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          oc[j] = on[j];
+          gc[j] = gn[j];
+        }
+        if (ii + 1 < cnt) load_rows(__builtin_amdgcn_readlane(m_v, ii + 1), on, gn);
+        const int e0 = __builtin_amdgcn_readlane(m_e0, ii);
+        process(oc, gc, e0, __builtin_amdgcn_readlane(m_e1, ii) - e0,
+                __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(m_xv.x), ii)),
+                __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(m_xv.y), ii)));
+      }
+    }
+  } else {
+    if (it0 < N) {
+      float on[J], gn[J];
+      int vn = dst_order ? dst_order[it0] : it0;
+      load_rows(vn, on, gn);
+      for (int it = it0; it < N; it += stride) {
+        const int v = vn;
+        float oc[J], gc[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          oc[j] = on[j];
+          gc[j] = gn[j];
+        }
+        if (it + stride < N) {   // rows of the next destination are in flight while this one computes
+          vn = dst_order ? dst_order[it + stride] : it + stride;
+          load_rows(vn, on, gn);
+        }
+        const int e0 = seg_off[v];
+        process(oc, gc, e0, seg_off[v + 1] - e0, x_dst[2 * v], x_dst[2 * v + 1]);
+      }
+    }
   }
 
   // fold the 4 waves in fixed order through LDS, then one partial row per workgroup
@@ -494,12 +549,17 @@ template <int FS, int NH, int D>
 int launch_bwd(const float* x_src, const float* x_dst, const int32_t* seg_off, const int32_t* dst_order, int N,
                const float* W_s,
                const float* b_s, const float* W_d, const float* b_d, const float* attn, float slope, const float* out,
-               const float* d_out, int ld_out, const float* a_save, const GradPtrs& gp, float* ws, hipStream_t st) {
+               const float* d_out, int ld_out, const float* a_save, const GradPtrs& gp, float* ws, bool sparse_hint,
+               hipStream_t st) {
   constexpr int H = NH * D;
   constexpr int P = partial_len<FS>(H);
   const int grid = bwd_blocks(N);
-  hipLaunchKernelGGL((gatv2_bwd_kernel<FS, NH, D>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, dst_order,
-                     N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws);
+  if (sparse_hint)
+    hipLaunchKernelGGL((gatv2_bwd_kernel<FS, NH, D, true>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off,
+                       dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws);
+  else
+    hipLaunchKernelGGL((gatv2_bwd_kernel<FS, NH, D, false>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off,
+                       dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws);
   int rc = launch_status();
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + kWave - 1) / kWave), dim3(1024), 0, st, ws, grid, P, gp);
@@ -599,7 +659,8 @@ extern "C" int uavgnn_gatv2_bwd(const float* x_src, int E, int F_src, const floa
   gp.off[7] = gp.off[6] + H;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
+  const bool sparse_hint = static_cast<long long>(E) < 16LL * N;
   UAVGNN_DISPATCH_ALL((launch_bwd<FS_, NH_, D_>(x_src, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out,
-                                                 ld_out, attn_save, gp, ws, st)))
+                                                 ld_out, attn_save, gp, ws, sparse_hint, st)))
   return UAVGNN_EUNSUPPORTED;
 }
