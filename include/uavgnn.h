@@ -85,10 +85,13 @@ int uavgnn_gatv2_bwd(const float* x_src, int E, int F_src, const float* x_dst, i
  * a_save[E] receives the attention weights in CSC order.  K <= 64, M <= 256.
  * With s == q == NULL the attention is uniform: c = mean of in-neighbour rows (the UDF reduce `mailbox.mean(1)` of
  * BaseComm/CommNet, gnn_agents.py:130-133,:214-216).
+ * x_copy (may be NULL): when given, row d of x_copy[N, n_copy] (ld_x) is also copied to the n_copy floats IN FRONT of
+ * c[d, :] (i.e. c - n_copy + d*ld_c), so that one pass leaves the GRU input [x || c] of gnn_agents.py:270 in place
+ * of a separate th.cat.
  */
 int uavgnn_talk_attn_fwd(const float* s, int ld_s, const float* q, int ld_q, const float* v, int ld_v, int K, int M,
                          const int32_t* talk_off, const int32_t* talk_src, int N, float scale, float* c, int ld_c,
-                         float* a_save, uavgnn_stream_t stream);
+                         float* a_save, const float* x_copy, int ld_x, int n_copy, uavgnn_stream_t stream);
 
 /* K3b backward.  d_c[N,M] -> d_s, d_q [N,K], d_v [N,M] (overwritten; any of d_s/d_q may be NULL in uniform mode).
  * t_off[N+1], t_dst[E], t_pos[E]: transpose of the CSC (out-edges of each source, destination of each, and the CSC

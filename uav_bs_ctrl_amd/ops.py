@@ -156,7 +156,7 @@ class _TalkAttention(th.autograd.Function):
             rc = L.lib().uavgnn_talk_attn_fwd(L.ptr(s), 0 if s is None else s.stride(0), L.ptr(q),
                                               0 if q is None else q.stride(0), L.ptr(v), v.stride(0), K, M,
                                               L.ptr(talk_off), L.ptr(talk_src), N, float(scale), c.data_ptr(),
-                                              c.stride(0), a_save.data_ptr(), L.stream())
+                                              c.stride(0), a_save.data_ptr(), None, 0, 0, L.stream())
         L.check(rc, "uavgnn_talk_attn_fwd")
         ctx.scale, ctx.uniform = float(scale), s is None
         ctx.save_for_backward(*(t for t in (s, q) if t is not None), v, talk_off, talk_src, t_off, t_dst, t_pos, a_save)
@@ -372,15 +372,15 @@ class _TarmacStep(th.autograd.Function):
         x, h = L.f32c(x), L.f32c(h)
         proj = th.addmm(bp, x, Wp[:, :H].t())
         proj.addmm_(h, Wp[:, H:].t())                                     # [N, M + 2K]: value | signature | query
-        inp = th.empty((N, H + M), dtype=th.float32, device=x.device)
-        inp[:, :H].copy_(x)
+        inp = th.empty((N, H + M), dtype=th.float32, device=x.device)     # [x || c], both halves filled by K3b
         E = talk_src.shape[0]
         a_save = th.empty(max(E, 1), dtype=th.float32, device=x.device)
         ld = M + 2 * K
         with KERNEL_TIMER.span("talk_attn_fwd"):
             rc = L.lib().uavgnn_talk_attn_fwd(proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld,
                                               proj.data_ptr(), ld, K, M, L.ptr(talk_off), L.ptr(talk_src), N,
-                                              1.0 / K, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(), L.stream())
+                                              1.0 / K, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(),
+                                              x.data_ptr(), x.stride(0), H, L.stream())
         L.check(rc, "uavgnn_talk_attn_fwd")
         gi = th.addmm(b_ih, inp, W_ih.t())
         gh = th.addmm(b_hh, h, W_hh.t())
