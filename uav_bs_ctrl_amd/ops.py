@@ -229,6 +229,27 @@ def gru_gates(gi, gh, h):
     return _GruGates.apply(gi, gh, h)
 
 
+def _row_blocks(n, cap=256, min_rows=32):
+    """Largest power-of-two block count <= cap that divides n with >= min_rows rows per block."""
+    S = 1
+    while S < cap and n % (2 * S) == 0 and n // (2 * S) >= min_rows:
+        S *= 2
+    return S
+
+
+def _colsum_partial(dy):
+    """[S, C] partial column sums of a (possibly column-sliced) [n, C] matrix.  torch's one-pass column reduction
+    over 10^4..10^5 rows runs at 0.01-3 TB/s depending on C (48 us for [32768, 9], 34 us for [32768, 768]); blocking
+    the rows S = 256 ways first reaches ~5 TB/s for every width (tools/colsum_probe.py), fixed order."""
+    n = dy.shape[0]
+    S = _row_blocks(n)
+    return dy.unflatten(0, (S, n // S)).sum(1)
+
+
+def _colsum(dy):
+    return _colsum_partial(dy).sum(0)
+
+
 class _LinearSplitK(th.autograd.Function):
     """y = x W^T (+ b) on the vendor GEMM (hipBLASLt/rocBLAS fp32), with a weight-gradient path shaped for this
     workload: N_a is 10^4..10^5 rows while W is at most 768 x 512, so dW = dY^T X has a tiny output and a huge
@@ -265,7 +286,7 @@ class _LinearSplitK(th.autograd.Function):
             else:
                 dW = th.mm(dy.t(), x)
         if has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(0)
+            db = _colsum(dy)
         return dx, dW, db
 
 
@@ -328,15 +349,18 @@ class WeightGradSink:
             slot[0].baddbmm_(dy.view(S, n // S, -1).transpose(1, 2), x.view(S, n // S, -1))
 
     def bias(self, key, dy, flush_fn):
+        """buffer[S, out] += row-blocked column sums of dy (a transposed GEMV with beta = 1 was measured 20x slower)"""
+        part = _colsum_partial(dy)
         slot = self.slots.get(key)
-        if slot is None:
-            self.slots[key] = slot = (th.zeros(dy.shape[1], dtype=th.float32, device=dy.device), flush_fn)
-        slot[0].add_(dy.sum(0))     # (a transposed GEMV with beta = 1 was measured 20x slower than sum + add)
+        if slot is None or slot[0].shape != part.shape:
+            self.slots[key] = (part, flush_fn)
+        else:
+            slot[0].add_(part)
 
     def flush(self):
         for key, (buf, fn) in self.slots.items():
             if fn is not None:
-                fn(buf.sum(0) if buf.dim() == 3 else buf)
+                fn(buf.sum(0))
         self.slots = {}
 
 
@@ -356,6 +380,12 @@ def _add_grad(p, g):
         p.grad = g.clone()
     else:
         p.grad.add_(g)
+
+
+def _add_grad_cols(p, g, start):
+    if p.grad is None:
+        p.grad = th.zeros_like(p)
+    p.grad[start:start + g.shape[0]].add_(g)
 
 
 class _TarmacStep(th.autograd.Function):
@@ -431,16 +461,17 @@ class _TarmacStep(th.autograd.Function):
             sink.weight(("W_ih", id(W_ih)), d_gi, inp, lambda g: split("W_ih", g, 0))
             sink.bias(("b_ih", id(W_ih)), d_gi, lambda g: split("b_ih", g, 0))
             sink.weight(("W_hh", id(W_hh)), d_gh, h, lambda g: split("W_hh", g, 0))
-            sink.bias(("b_hh", id(W_hh)), d_gh, lambda g: split("b_hh", g, 0))
+            # d_gh == d_gi on the r and z columns: only the n block of b_hh needs its own pass over d_gh
+            sink.bias(("b_hh_n", id(W_hh)), d_gh[:, 2 * H:], lambda g: split("b_hh", g, 2 * H))
             sink.weight(("W_out", id(W_out)), dq, h2, lambda g: split("W_out", g, 0))
             sink.bias(("b_out", id(W_out)), dq, lambda g: split("b_out", g, 0))
             gWp = gbp = gWih = gbih = gWhh = gbhh = gWo = gbo = None
         else:
             gWp = th.cat((_wgrad(d_proj, x), _wgrad(d_proj, h)), 1)
-            gbp = d_proj.sum(0)
-            gWih, gbih = _wgrad(d_gi, inp), d_gi.sum(0)
-            gWhh, gbhh = _wgrad(d_gh, h), d_gh.sum(0)
-            gWo, gbo = _wgrad(dq, h2), dq.sum(0)
+            gbp = _colsum(d_proj)
+            gWih, gbih = _wgrad(d_gi, inp), _colsum(d_gi)
+            gWhh, gbhh = _wgrad(d_gh, h), th.cat((gbih[:2 * H], _colsum(d_gh[:, 2 * H:])))
+            gWo, gbo = _wgrad(dq, h2), _colsum(dq)
         return (dx, dh, gWp, gbp, gWih, gbih, gWhh, gbhh, gWo, gbo) + (None,) * 8
 
 
@@ -452,6 +483,7 @@ def tarmac_step(x, h, g, comm, f_out, stacked=None):
     off, src = g.talk_csc()
     t_off, t_dst, t_pos = g.talk_transpose()
     cell = comm.f_udt
+    H = cell.weight_hh.shape[1]
     params = {"W_ih": cell.weight_ih, "b_ih": cell.bias_ih, "W_hh": cell.weight_hh, "b_hh": cell.bias_hh,
               "W_out": f_out.weight, "b_out": f_out.bias}
 
@@ -471,6 +503,11 @@ def tarmac_step(x, h, g, comm, f_out, stacked=None):
                 rows = lin.bias.shape[0]
                 _add_grad(lin.bias, grad[r:r + rows])
                 r += rows
+        elif name == "b_ih":    # its r and z columns are b_hh's too (see _TarmacStep.backward)
+            _add_grad(params["b_ih"], grad)
+            _add_grad_cols(params["b_hh"], grad[:2 * H], 0)
+        elif name == "b_hh":    # the n block
+            _add_grad_cols(params["b_hh"], grad, col0)
         else:
             _add_grad(params[name], grad)
 
