@@ -79,18 +79,12 @@ def make_sequence(B, n, M, T, dist_name, device, seed, distinct):
     gen = th.Generator(device=device)
     gen.manual_seed(seed)
     graphs = [synth_batch_gpu(B, n, M, dist_name, device, gen) for _ in range(distinct)]
-    for g in graphs:
-        g.talk_transpose()   # built once per graph, part of graph construction, not of the hot path
-        g.relation_order("seen"), g.relation_order("near")
     obs = [graphs[t % distinct] for t in range(T + 1)]
     N = B * n
     # the sampled batch in time-major order, as the tensor-native replay hands it over (uav_bs_ctrl_amd/replay.py):
     # all T+1 observation graphs as ONE graph for the time-batched encoder (steps 1..T again for the target net)
     from uav_bs_ctrl_amd import batch as hb_batch
     obs_all, obs_all_next = hb_batch(obs), hb_batch(obs[1:])
-    for g in (obs_all, obs_all_next):
-        g.relation_order("seen"), g.relation_order("near")
-        g.relation_segments("seen"), g.relation_segments("near")
     batch = dict(obs=obs, obs_all=obs_all, obs_all_next=obs_all_next,
                  h0=th.zeros(N, 256, device=device), h1=0.1 * th.randn(N, 256, device=device, generator=gen),
                  acts=th.randint(9, (T, N, 1), device=device, generator=gen),
@@ -223,10 +217,15 @@ def main():
     batch = make_sequence(a.B, a.n, a.M, a.T, a.dist, device, seed=1234 + rank, distinct=a.distinct)
 
     def step():
+        # Every cycle sees NEWLY BUILT graphs: .fresh() shares the arrays but drops every derived index (K1 hand-out
+        # order, talk-CSC transpose), so building them is inside the timed region - as with fresh observations from a
+        # simulator or a new replay sample (the reference pays DGL's lazy CSR/CSC materialisation the same way).
+        obs = [g.fresh() for g in batch["obs"]]
+        fb = dict(batch, obs=obs, obs_all=batch["obs_all"].fresh(), obs_all_next=batch["obs_all_next"].fresh())
         h = learner.init_hidden(a.B)
         for t in range(a.T):
-            _, h = learner.act(batch["obs"][t], h, 0.05)
-        return learner.update(batch)
+            _, h = learner.act(obs[t].fresh(), h, 0.05)
+        return learner.update(fb)
 
     def barrier():
         if use_dist:

@@ -147,6 +147,27 @@ int uavgnn_talk_degrees(const float* d_u2u, int n, int B, float r_comm, int32_t*
 int uavgnn_talk_compact(const float* d_u2u, int n, int B, float r_comm, const int32_t* talk_off,
                         const int32_t* env_base, int32_t* talk_src, int32_t* talk_eid, uavgnn_stream_t stream);
 
+/* ---- derived indexes of a batch --------------------------------------------------------------------------------
+ * What the reference gets from DGL's lazy format materialisation (CSR/CSC created inside the first message-passing
+ * call on every new graph - reached from gnn_agents.py:103-104, :264-267) is explicit here and deterministic.
+ *
+ * uavgnn_degree_order: order[N] = destinations of a segment relation sorted by decreasing in-degree
+ *   (stable; degrees >= 255 share one bucket).  A scheduling hint for uavgnn_gatv2_fwd / _bwd (dst_order), never
+ *   needed for correctness.  workspace: uavgnn_degree_order_workspace_bytes(N).
+ * uavgnn_csc_transpose: out-edge lists of the talk CSC: t_off[N+1]; for slot k of source u, t_dst[k] = destination
+ *   and t_pos[k] = position of that edge in the CSC, ascending within each source.  Consumed by
+ *   uavgnn_talk_attn_bwd / uavgnn_disc_comm_bwd.  talk_src values must lie in [0, N).  Out-lists are sorted by one
+ *   lane each (insertion sort): meant for the short lists of this domain (<= n_agents - 1 per source).
+ *   workspace: uavgnn_csc_transpose_workspace_bytes(N).
+ */
+size_t uavgnn_degree_order_workspace_bytes(int N);
+int uavgnn_degree_order(const int32_t* seg_off, int N, int32_t* order, void* workspace, size_t workspace_bytes,
+                        uavgnn_stream_t stream);
+size_t uavgnn_csc_transpose_workspace_bytes(int N);
+int uavgnn_csc_transpose(const int32_t* talk_off, const int32_t* talk_src, int N, int E, int32_t* t_off,
+                         int32_t* t_dst, int32_t* t_pos, void* workspace, size_t workspace_bytes,
+                         uavgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -520,3 +520,65 @@ def test_replay_to_update_end_to_end_on_device():
     assert abs(loss_dev - loss_host) <= 1e-6 * max(1.0, abs(loss_host)), (loss_dev, loss_host)
     out = L.update(b)
     assert np.isfinite(float(out["LossQ"]))
+
+
+@pytest.mark.parametrize("n,maxdeg,seed", [(1, 3, 0), (300, 6, 1), (4097, 90, 2), (70001, 12, 3), (50, 0, 4), (2000, 400, 5)])
+def test_degree_order_is_the_stable_descending_sort(n, maxdeg, seed):
+    """uavgnn_degree_order == torch.sort(deg, descending, stable) while degrees stay below the bucket cap (255); above
+    the cap it stays a permutation with non-increasing buckets."""
+    from uav_bs_ctrl_amd.graph import HeteroBatch
+    gen = th.Generator().manual_seed(seed)
+    deg = th.randint(0, maxdeg + 1, (n,), generator=gen)
+    if seed == 3:
+        deg[th.rand(n, generator=gen) < 0.9] = 0
+    off = th.zeros(n + 1, dtype=th.int32)
+    off[1:] = th.cumsum(deg, 0)
+    E = int(off[-1])
+    g = HeteroBatch.from_arrays(x_a=th.zeros(n, 2), x_gt=th.zeros(E, 4), seen_off=off, device="cuda")
+    order = g.relation_order("seen").cpu().long()
+    assert sorted(order.tolist()) == list(range(n))
+    ref = th.sort(deg.clamp(max=255), descending=True, stable=True)[1]
+    assert th.equal(order, ref)
+
+
+@pytest.mark.parametrize("B,n,p,seed", [(1, 8, 0.5, 0), (257, 8, 0.3, 1), (64, 32, 0.9, 2), (5000, 8, 0.05, 3), (3, 64, 1.0, 4)])
+def test_csc_transpose_matches_host_construction(B, n, p, seed):
+    """uavgnn_csc_transpose == the sort-based host construction (t_off, t_dst, t_pos identical)."""
+    from uav_bs_ctrl_amd.graph import HeteroBatch
+    gen = th.Generator().manual_seed(seed)
+    adj = th.rand(B, n, n, generator=gen) < p            # adj[b, i, j]: edge i -> j
+    src, dst = [], []
+    b, i, j = adj.nonzero(as_tuple=True)
+    # CSC order: by destination, then by source
+    key = (b * n + j) * (B * n) + (b * n + i)
+    o = th.argsort(key)
+    src, dst = (b * n + i)[o], (b * n + j)[o]
+    N = B * n
+    off = th.zeros(N + 1, dtype=th.int32)
+    off[1:] = th.cumsum(th.bincount(dst, minlength=N), 0)
+    kw = dict(x_a=th.zeros(N, 2), talk_off=off, talk_src=src.to(th.int32))
+    g_host = HeteroBatch.from_arrays(**kw)
+    g_dev = HeteroBatch.from_arrays(**kw, device="cuda")
+    for a, bb in zip(g_host.talk_transpose(), g_dev.talk_transpose()):
+        assert th.equal(a, bb.cpu())
+
+
+@pytest.mark.parametrize("N", [200_003, 4_300_001])
+def test_csc_transpose_large_scan_and_empty(N):
+    """N above one scan tile (4096) takes the tile-totals + carry launches, above 1024 tiles the recursive level;
+    E = 0 gives all-zero offsets."""
+    from uav_bs_ctrl_amd.graph import HeteroBatch
+    gen = th.Generator().manual_seed(0)
+    deg = th.randint(0, 3, (N,), generator=gen)
+    off = th.zeros(N + 1, dtype=th.int32)
+    off[1:] = th.cumsum(deg, 0)
+    E = int(off[-1])
+    src = th.randint(0, N, (E,), generator=gen).to(th.int32)
+    kw = dict(x_a=th.zeros(N, 2), talk_off=off, talk_src=src)
+    for a, b in zip(HeteroBatch.from_arrays(**kw).talk_transpose(),
+                    HeteroBatch.from_arrays(**kw, device="cuda").talk_transpose()):
+        assert th.equal(a, b.cpu())
+    g0 = HeteroBatch.from_arrays(x_a=th.zeros(7, 2), talk_off=th.zeros(8, dtype=th.int32),
+                                 talk_src=th.zeros(0, dtype=th.int32), device="cuda")
+    t_off, t_dst, t_pos = g0.talk_transpose()
+    assert t_off.cpu().tolist() == [0] * 8 and t_dst.numel() == 0 and t_pos.numel() == 0

@@ -24,10 +24,12 @@ batch = make_sequence(4096, 8, 80, 50, a.dist, dev, seed=1, distinct=4)
 
 
 def cycle():
+    obs = [g.fresh() for g in batch["obs"]]      # as bench.py: derived indexes are rebuilt every cycle
+    fb = dict(batch, obs=obs, obs_all=batch["obs_all"].fresh(), obs_all_next=batch["obs_all_next"].fresh())
     h = L.init_hidden(4096)
     for t in range(50):
-        _, h = L.act(batch["obs"][t], h, 0.05)
-    L.update(batch)
+        _, h = L.act(obs[t].fresh(), h, 0.05)
+    L.update(fb)
 
 
 def timed(fn):

@@ -20,5 +20,22 @@ th.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     L.update(batch)
     th.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="device_time_total", row_limit=45,
-                                                         max_name_column_width=40, max_shapes_column_width=70))
+def show(prof, title):
+    rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.self_device_time_total > 0]
+    rows.sort(key=lambda e: -e.self_device_time_total)
+    tot = sum(e.self_device_time_total for e in rows if not e.key.startswith(("aten::", "_", "autograd")))
+    print(f"== {title}: kernel time {tot / 1e3:.2f} ms")
+    for e in rows[:90]:
+        print(f"{e.self_device_time_total / 1e3:9.3f} ms {e.count:5d}x {e.self_device_time_total / e.count:9.1f} us  "
+              f"{e.key[:70]:70s} {str(e.input_shapes)[:90]}")
+
+
+show(prof, "update")
+h = L.init_hidden(4096)
+_, h = L.act(batch["obs"][0], h, 0.05)
+th.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof2:
+    for t in range(10):
+        _, h = L.act(batch["obs"][t], h, 0.05)
+    th.cuda.synchronize()
+show(prof2, "10 x act")

@@ -120,6 +120,223 @@ __global__ __launch_bounds__(kThreads) void talk_compact_kernel(const float* __r
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Derived indexes of a batch: the K1 hand-out order and the transpose of the `talk` CSC.  The reference pays the
+// equivalent (DGL materialises CSR/CSC formats lazily inside the first message-passing call of every new graph); here
+// they are integer passes of a few microseconds, deterministic (no float atomics, integer atomics only where the
+// result does not depend on their order).
+
+constexpr int kOrderBins = 256;      // degree buckets: bin = 255 - min(deg, 255)  (ascending bin = descending degree)
+constexpr int kOrderThreads = 256;
+constexpr int kOrderMaxBlocks = 256;
+constexpr int kScanThreads = 1024;
+constexpr int kScanPer = 4;
+constexpr int kScanTile = kScanThreads * kScanPer;   // elements per block of the scan
+
+__device__ __forceinline__ int order_bin(const int32_t* __restrict__ seg_off, int v) {
+  const int deg = seg_off[v + 1] - seg_off[v];
+  return kOrderBins - 1 - (deg < kOrderBins - 1 ? deg : kOrderBins - 1);
+}
+
+// hist[bin * G + b] = destinations of block b's contiguous chunk that fall into `bin`
+__global__ __launch_bounds__(kOrderThreads) void order_hist_kernel(const int32_t* __restrict__ seg_off, int N, int chunk,
+                                                                   int32_t* __restrict__ hist) {
+  __shared__ int h[kOrderBins];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int lo = blockIdx.x * chunk, hi = min(N, lo + chunk);
+  for (int v = lo + threadIdx.x; v < hi; v += kOrderThreads) atomicAdd(&h[order_bin(seg_off, v)], 1);
+  __syncthreads();
+  hist[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+// Stable scatter: block b walks its chunk in index order; the slot of destination v is
+// (prefix of its (bin, block) cell) + (destinations of the same bin earlier in the chunk).
+__global__ __launch_bounds__(kOrderThreads) void order_scatter_kernel(const int32_t* __restrict__ seg_off, int N,
+                                                                      int chunk, const int32_t* __restrict__ cell_incl,
+                                                                      int32_t* __restrict__ order) {
+  __shared__ int base[kOrderBins];
+  __shared__ int bins[kOrderThreads];
+  const int t = threadIdx.x;
+  const int cell = t * gridDim.x + blockIdx.x;   // cell_incl = inclusive scan over (bin-major, block-minor) cells
+  base[t] = cell > 0 ? cell_incl[cell - 1] : 0;
+  const int lo = blockIdx.x * chunk, hi = min(N, lo + chunk);
+  for (int tile = lo; tile < hi; tile += kOrderThreads) {
+    const int v = tile + t;
+    const int bin = v < hi ? order_bin(seg_off, v) : -1;
+    bins[t] = bin;
+    __syncthreads();
+    int rank = 0;
+    if (bin >= 0)
+      for (int j = 0; j < t; ++j) rank += bins[j] == bin;
+    const int pos = bin >= 0 ? base[bin] + rank : 0;
+    __syncthreads();
+    if (bin >= 0) {
+      order[pos] = v;
+      atomicAdd(&base[bin], 1);
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ int wave_scan_inclusive(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int u = __shfl_up(v, o);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+
+// Inclusive scan of one tile of kScanTile elements, in place: coalesced load into LDS, every thread scans its
+// kScanPer consecutive elements, wave + block prefix, coalesced store.  sums (optional) receives the tile total.
+__global__ __launch_bounds__(kScanThreads) void scan_tile_kernel(int32_t* __restrict__ data, int n,
+                                                                 int32_t* __restrict__ sums) {
+  __shared__ int buf[kScanTile];
+  __shared__ int wave_tot[kScanThreads / kWave];
+  const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+  const int lo = blockIdx.x * kScanTile;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    const int i = lo + k * kScanThreads + t;
+    buf[k * kScanThreads + t] = i < n ? data[i] : 0;
+  }
+  __syncthreads();
+  int v[kScanPer];
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    s += buf[t * kScanPer + k];
+    v[k] = s;
+  }
+  const int inc = wave_scan_inclusive(s, lane);
+  if (lane == kWave - 1) wave_tot[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    const int w = lane < kScanThreads / kWave ? wave_tot[lane] : 0;
+    const int ws = wave_scan_inclusive(w, lane);
+    if (lane < kScanThreads / kWave) wave_tot[lane] = ws - w;   // exclusive prefix of the waves
+    if (sums != nullptr && lane == kScanThreads / kWave - 1) sums[blockIdx.x] = ws;
+  }
+  __syncthreads();
+  const int base = wave_tot[wave] + inc - s;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) buf[t * kScanPer + k] = base + v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    const int i = lo + k * kScanThreads + t;
+    if (i < n) data[i] = buf[k * kScanThreads + t];
+  }
+}
+
+// Adds the carry of the preceding tiles to tile blockIdx.x + 1.  scanned = false: sums holds raw tile totals and the
+// block reduces sums[0 .. b) itself (b <= kScanThreads; saves the launch that would scan them); scanned = true: sums
+// holds their inclusive scan.
+__global__ __launch_bounds__(kScanThreads) void scan_carry_kernel(int32_t* __restrict__ data, int n,
+                                                                  const int32_t* __restrict__ sums, bool scanned) {
+  __shared__ int carry_s;
+  const int t = threadIdx.x, lane = t & (kWave - 1);
+  const int b = blockIdx.x + 1;   // tile 0 needs no carry
+  if (t == 0) carry_s = scanned ? sums[b - 1] : 0;
+  __syncthreads();
+  if (!scanned) {
+    int c = t < b ? sums[t] : 0;
+    c = wave_scan_inclusive(c, lane);
+    if (lane == kWave - 1 && c != 0) atomicAdd(&carry_s, c);   // integer: order-independent
+    __syncthreads();
+  }
+  const int carry = carry_s;
+  const int lo = b * kScanTile;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    const int i = lo + k * kScanThreads + t;
+    if (i < n) data[i] += carry;
+  }
+}
+
+// ints of scratch scan_inclusive_i32 needs for n elements (tile totals of every level)
+inline size_t scan_scratch_elems(long long n) {
+  size_t tot = 0;
+  while (n > kScanTile) {
+    n = (n + kScanTile - 1) / kScanTile;
+    tot += static_cast<size_t>(n);
+  }
+  return tot + 1;
+}
+
+// data[0..n) <- inclusive scan, in place.
+int scan_inclusive_i32(int32_t* data, int n, int32_t* scratch, hipStream_t st) {
+  if (n <= 0) return 0;
+  const int tiles = (n + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(scan_tile_kernel, dim3(tiles), dim3(kScanThreads), 0, st, data, n,
+                     tiles > 1 ? scratch : static_cast<int32_t*>(nullptr));
+  if (tiles > 1) {
+    const bool scanned = tiles > kScanThreads;
+    if (scanned) {
+      const int rc = scan_inclusive_i32(scratch, tiles, scratch + tiles, st);
+      if (rc != 0) return rc;
+    }
+    hipLaunchKernelGGL(scan_carry_kernel, dim3(tiles - 1), dim3(kScanThreads), 0, st, data, n, scratch, scanned);
+  }
+  return launch_status();
+}
+
+// t_off[1 + u] += 1 for every edge leaving u (integer atomics: the counts do not depend on their order)
+__global__ void csc_out_degrees_kernel(const int32_t* __restrict__ talk_src, int E, int32_t* __restrict__ t_off) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x)
+    atomicAdd(&t_off[1 + talk_src[e]], 1);
+}
+
+// Every in-edge (position e in the CSC, destination d) takes a free slot of its source's out-list (8 edges in flight
+// per lane so that the returning atomics overlap) ...
+__global__ void csc_transpose_fill_kernel(const int32_t* __restrict__ talk_off, const int32_t* __restrict__ talk_src,
+                                          int N, const int32_t* __restrict__ t_off, int32_t* __restrict__ cursor,
+                                          int32_t* __restrict__ t_dst, int32_t* __restrict__ t_pos) {
+  for (int d = blockIdx.x * blockDim.x + threadIdx.x; d < N; d += gridDim.x * blockDim.x) {
+    const int e1 = talk_off[d + 1];
+    for (int e0 = talk_off[d]; e0 < e1; e0 += 8) {
+      int u[8], k[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) u[i] = e0 + i < e1 ? talk_src[e0 + i] : -1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) k[i] = u[i] >= 0 ? t_off[u[i]] + atomicAdd(&cursor[u[i]], 1) : 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (u[i] >= 0) {
+          t_pos[k[i]] = e0 + i;
+          t_dst[k[i]] = d;
+        }
+    }
+  }
+}
+
+// ... and every source then orders its out-list by CSC position (= by destination), which makes the result
+// independent of the slot race above.  Out-lists are short here (<= n_agents - 1); insertion sort by one lane.
+__global__ void csc_transpose_sort_kernel(int N, const int32_t* __restrict__ t_off, int32_t* __restrict__ t_dst,
+                                          int32_t* __restrict__ t_pos) {
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < N; u += gridDim.x * blockDim.x) {
+    const int k0 = t_off[u], k1 = t_off[u + 1];
+    for (int k = k0 + 1; k < k1; ++k) {
+      const int p = t_pos[k], d = t_dst[k];
+      int j = k - 1;
+      while (j >= k0 && t_pos[j] > p) {
+        t_pos[j + 1] = t_pos[j];
+        t_dst[j + 1] = t_dst[j];
+        --j;
+      }
+      t_pos[j + 1] = p;
+      t_dst[j + 1] = d;
+    }
+  }
+}
+
+inline int order_blocks(int N) {
+  const int b = (N + kOrderThreads - 1) / kOrderThreads;
+  return b < 1 ? 1 : (b > kOrderMaxBlocks ? kOrderMaxBlocks : b);
+}
+
 }  // namespace
 }  // namespace uavgnn
 
@@ -163,5 +380,55 @@ extern "C" int uavgnn_talk_compact(const float* d_u2u, int n, int B, float r_com
   if (B == 0) return 0;
   hipLaunchKernelGGL(talk_compact_kernel, dim3(capped_grid(B, kWavesPerBlock, 4096)), dim3(kThreads), 0,
                      static_cast<hipStream_t>(stream), d_u2u, n, B, r_comm, talk_off, env_base, talk_src, talk_eid);
+  return launch_status();
+}
+
+extern "C" size_t uavgnn_degree_order_workspace_bytes(int N) {   // the (bin, block) cells + the scan's tile totals
+  const size_t cells = static_cast<size_t>(kOrderBins) * order_blocks(N);
+  return (cells + scan_scratch_elems(static_cast<long long>(cells))) * sizeof(int32_t);
+}
+
+extern "C" int uavgnn_degree_order(const int32_t* seg_off, int N, int32_t* order, void* workspace,
+                                   size_t workspace_bytes, uavgnn_stream_t stream) {
+  if (N < 0 || !seg_off || (N > 0 && (!order || !workspace))) return UAVGNN_EINVAL;
+  if (N == 0) return 0;
+  if (workspace_bytes < uavgnn_degree_order_workspace_bytes(N)) return UAVGNN_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int G = order_blocks(N);
+  int chunk = (N + G - 1) / G;
+  chunk = (chunk + kOrderThreads - 1) / kOrderThreads * kOrderThreads;
+  int32_t* cells = static_cast<int32_t*>(workspace);
+  hipLaunchKernelGGL(order_hist_kernel, dim3(G), dim3(kOrderThreads), 0, st, seg_off, N, chunk, cells);
+  int rc = scan_inclusive_i32(cells, kOrderBins * G, cells + kOrderBins * G, st);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(order_scatter_kernel, dim3(G), dim3(kOrderThreads), 0, st, seg_off, N, chunk, cells, order);
+  return launch_status();
+}
+
+extern "C" size_t uavgnn_csc_transpose_workspace_bytes(int N) {   // slot cursors + the scan's tile totals
+  const size_t n = static_cast<size_t>(N > 0 ? N : 0);
+  return (n + scan_scratch_elems(static_cast<long long>(n))) * sizeof(int32_t);
+}
+
+extern "C" int uavgnn_csc_transpose(const int32_t* talk_off, const int32_t* talk_src, int N, int E, int32_t* t_off,
+                                    int32_t* t_dst, int32_t* t_pos, void* workspace, size_t workspace_bytes,
+                                    uavgnn_stream_t stream) {
+  if (N < 0 || E < 0 || !talk_off || !t_off || (E > 0 && (!talk_src || !t_dst || !t_pos)) || (N > 0 && !workspace))
+    return UAVGNN_EINVAL;
+  if (workspace_bytes < uavgnn_csc_transpose_workspace_bytes(N)) return UAVGNN_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(t_off, 0, (static_cast<size_t>(N) + 1) * sizeof(int32_t), st);
+  if (e != hipSuccess) return -static_cast<int>(e);
+  if (N == 0 || E == 0) return 0;
+  int32_t* cursor = static_cast<int32_t*>(workspace);
+  int32_t* sums = cursor + N;
+  e = hipMemsetAsync(cursor, 0, static_cast<size_t>(N) * sizeof(int32_t), st);
+  if (e != hipSuccess) return -static_cast<int>(e);
+  hipLaunchKernelGGL(csc_out_degrees_kernel, dim3(capped_grid(E, 256)), dim3(256), 0, st, talk_src, E, t_off);
+  int rc = scan_inclusive_i32(t_off + 1, N, sums, st);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(csc_transpose_fill_kernel, dim3(capped_grid(N, 256)), dim3(256), 0, st, talk_off, talk_src, N,
+                     t_off, cursor, t_dst, t_pos);
+  hipLaunchKernelGGL(csc_transpose_sort_kernel, dim3(capped_grid(N, 256)), dim3(256), 0, st, N, t_off, t_dst, t_pos);
   return launch_status();
 }

@@ -234,8 +234,18 @@ class HeteroBatch:
         key = "ord:" + etype
         if key not in self._cache:
             off = self._rels[self._canon(etype)].off
-            deg = (off[1:] - off[:-1])
-            self._cache[key] = th.sort(deg, descending=True, stable=True)[1].to(th.int32).contiguous()
+            if off.is_cuda:     # HIP counting sort (csrc/build_graph.hip): 3 launches, no host sync
+                from . import _lib as L
+                n = off.numel() - 1
+                order = th.empty(n, dtype=th.int32, device=off.device)
+                nbytes = L.lib().uavgnn_degree_order_workspace_bytes(n)
+                ws = th.empty(nbytes // 4, dtype=th.int32, device=off.device)
+                L.check(L.lib().uavgnn_degree_order(off.data_ptr(), n, L.ptr(order), ws.data_ptr(), nbytes,
+                                                    L.stream()), "uavgnn_degree_order")
+                self._cache[key] = order
+            else:
+                deg = (off[1:] - off[:-1])
+                self._cache[key] = th.sort(deg, descending=True, stable=True)[1].to(th.int32).contiguous()
         return self._cache[key]
 
     def talk_csc(self):
@@ -251,11 +261,29 @@ class HeteroBatch:
         if "talkT" not in self._cache:
             off, src = self.talk_csc()
             n = self._num_nodes["agent"]
-            dst = seg_ids(off)
-            order = th.sort(src.long(), stable=True)[1]
-            self._cache["talkT"] = (_offsets_from_dst(src, n), dst[order].to(th.int32).contiguous(),
-                                    order.to(th.int32).contiguous())
+            if off.is_cuda:     # HIP transpose (csrc/build_graph.hip): no sort, no host sync
+                from . import _lib as L
+                E = src.shape[0]
+                t_off = th.empty(n + 1, dtype=th.int32, device=off.device)
+                t_dst = th.empty(E, dtype=th.int32, device=off.device)
+                t_pos = th.empty(E, dtype=th.int32, device=off.device)
+                nbytes = L.lib().uavgnn_csc_transpose_workspace_bytes(n)
+                ws = th.empty(nbytes // 4, dtype=th.int32, device=off.device)
+                L.check(L.lib().uavgnn_csc_transpose(off.data_ptr(), L.ptr(src), n, E, t_off.data_ptr(), L.ptr(t_dst),
+                                                     L.ptr(t_pos), ws.data_ptr(), nbytes, L.stream()),
+                        "uavgnn_csc_transpose")
+                self._cache["talkT"] = (t_off, t_dst, t_pos)
+            else:
+                dst = seg_ids(off)
+                order = th.sort(src.long(), stable=True)[1]
+                self._cache["talkT"] = (_offsets_from_dst(src, n), dst[order].to(th.int32).contiguous(),
+                                        order.to(th.int32).contiguous())
         return self._cache["talkT"]
+
+    def fresh(self) -> "HeteroBatch":
+        """The same graph (shared storage) without any derived index - how a newly built batch looks to the path."""
+        return HeteroBatch(self._num_nodes, self._rels, {nt: dict(fr) for nt, fr in self._feat.items()},
+                           self.graph_off)
 
     def slice_agents(self, lo: int, hi: int) -> "HeteroBatch":
         """Observation part (agent features + `seen`/`near`) of agents [lo, hi) as a new HeteroBatch whose feature

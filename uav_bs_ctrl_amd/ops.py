@@ -138,6 +138,13 @@ def hetero_gatv2(x_dst, nh, relations):
     return _HeteroGATv2.apply(x_dst, nh, *flat)
 
 
+def _talk_transpose_if_needed(g, *tensors):
+    """The transpose of the talk CSC is a backward-only index: skip building it for no-grad forwards (act, target)."""
+    if th.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        return g.talk_transpose()
+    return None, None, None
+
+
 class _TalkAttention(th.autograd.Function):
     """K3b.  c_v = sum_u softmax_u(<s_u, q_v> * scale) v_u over the talk relation; s = q = None -> mean."""
 
@@ -192,7 +199,7 @@ class _TalkAttention(th.autograd.Function):
 def talk_attention(s, q, v, g, scale=1.0):
     """g: HeteroBatch carrying the talk relation."""
     off, src = g.talk_csc()
-    t_off, t_dst, t_pos = g.talk_transpose()
+    t_off, t_dst, t_pos = _talk_transpose_if_needed(g, s, q, v)
     return _TalkAttention.apply(s, q, v, off, src, t_off, t_dst, t_pos, scale)
 
 
@@ -481,8 +488,8 @@ def tarmac_step(x, h, g, comm, f_out, stacked=None):
     M, K = comm._msg_size, comm._key_size
     Wp, bp = stacked if stacked is not None else comm.fused_projection()
     off, src = g.talk_csc()
-    t_off, t_dst, t_pos = g.talk_transpose()
     cell = comm.f_udt
+    t_off, t_dst, t_pos = _talk_transpose_if_needed(g, x, h, Wp, cell.weight_ih, f_out.weight)
     H = cell.weight_hh.shape[1]
     params = {"W_ih": cell.weight_ih, "b_ih": cell.bias_ih, "W_hh": cell.weight_hh, "b_hh": cell.bias_hh,
               "W_out": f_out.weight, "b_out": f_out.bias}
@@ -557,5 +564,5 @@ def disc_comm_aggregate(logits, gumbel, g, tau=0.5):
     """Hard Gumbel-softmax messages + OR aggregation of DiscreteComm (gnn_agents.py:166-178).  logits [N, 2*msg] per
     source node, gumbel [E, msg, 2] in CSC order."""
     off, src = g.talk_csc()
-    t_off, t_dst, t_pos = g.talk_transpose()
+    t_off, t_dst, t_pos = _talk_transpose_if_needed(g, logits)
     return _DiscComm.apply(logits, gumbel, off, src, t_off, t_dst, t_pos, 1.0 / tau)
