@@ -72,7 +72,8 @@ def synth_batch_gpu(B, n, M, dist_name, device, gen):
     talk_src = (base + th.arange(n, device=device).repeat(N)).to(th.int32)
     return HeteroBatch.from_arrays(x_a=x_a, x_gt=x_gt, seen_off=seen_off, x_ubs=x_ubs, near_off=near_off,
                                    talk_off=talk_off, talk_src=talk_src,
-                                   graph_off=th.arange(0, N + 1, n, dtype=th.int32, device=device), device=device)
+                                   graph_off=th.arange(0, N + 1, n, dtype=th.int32, device=device), device=device,
+                                   hints={"max_graph_agents": n, "max_deg:seen": M, "max_deg:near": n - 1})
 
 
 def make_sequence(B, n, M, T, dist_name, device, seed, distinct):

@@ -159,6 +159,10 @@ int uavgnn_talk_compact(const float* d_u2u, int n, int B, float r_comm, const in
  *   uavgnn_talk_attn_bwd / uavgnn_disc_comm_bwd.  talk_src values must lie in [0, N).  Out-lists are sorted by one
  *   lane each (insertion sort): meant for the short lists of this domain (<= n_agents - 1 per source).
  *   workspace: uavgnn_csc_transpose_workspace_bytes(N).
+ * uavgnn_csc_transpose_env: the same result for a batch of B small graphs (graph_off[B+1] = agent-node boundaries,
+ *   graph_off[0] == 0, graph_off[B] == N) whose talk edges stay inside their graph - what dgl.batch of per-env
+ *   graphs produces (common.py:45, env_wrappers.py:67).  One wavefront per graph, one launch, no workspace; cost per
+ *   graph ~ ceil(agents / 64) x its edge count, so it is meant for graphs of up to a few hundred agents.
  */
 size_t uavgnn_degree_order_workspace_bytes(int N);
 int uavgnn_degree_order(const int32_t* seg_off, int N, int32_t* order, void* workspace, size_t workspace_bytes,
@@ -167,6 +171,8 @@ size_t uavgnn_csc_transpose_workspace_bytes(int N);
 int uavgnn_csc_transpose(const int32_t* talk_off, const int32_t* talk_src, int N, int E, int32_t* t_off,
                          int32_t* t_dst, int32_t* t_pos, void* workspace, size_t workspace_bytes,
                          uavgnn_stream_t stream);
+int uavgnn_csc_transpose_env(const int32_t* talk_off, const int32_t* talk_src, const int32_t* graph_off, int B, int N,
+                             int32_t* t_off, int32_t* t_dst, int32_t* t_pos, uavgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -558,9 +558,43 @@ def test_csc_transpose_matches_host_construction(B, n, p, seed):
     off[1:] = th.cumsum(th.bincount(dst, minlength=N), 0)
     kw = dict(x_a=th.zeros(N, 2), talk_off=off, talk_src=src.to(th.int32))
     g_host = HeteroBatch.from_arrays(**kw)
-    g_dev = HeteroBatch.from_arrays(**kw, device="cuda")
-    for a, bb in zip(g_host.talk_transpose(), g_dev.talk_transpose()):
-        assert th.equal(a, bb.cpu())
+    g_dev = HeteroBatch.from_arrays(**kw, device="cuda")                      # generic kernels (count, scan, fill, sort)
+    g_env = HeteroBatch.from_arrays(**kw, device="cuda", graph_off=list(range(0, N + 1, n)))   # one wavefront per graph
+    assert g_env.hints["max_graph_agents"] == n
+    ref = g_host.talk_transpose()
+    for g in (g_dev, g_env):
+        for a, bb in zip(ref, g.talk_transpose()):
+            assert th.equal(a, bb.cpu())
+
+
+def test_csc_transpose_env_ragged_graphs():
+    """Graphs of different sizes in one batch, one of them wider than a wavefront (chunked sources), some without
+    edges."""
+    from uav_bs_ctrl_amd.graph import HeteroBatch
+    gen = th.Generator().manual_seed(11)
+    sizes = [3, 1, 100, 8, 64, 65, 2, 130]
+    bounds = [0]
+    for k in sizes:
+        bounds.append(bounds[-1] + k)
+    N = bounds[-1]
+    src_l, dst_l = [], []
+    for gi, k in enumerate(sizes):
+        p = 0.0 if gi == 3 else 0.4
+        adj = th.rand(k, k, generator=gen) < p
+        i, j = adj.nonzero(as_tuple=True)
+        src_l.append(i + bounds[gi])
+        dst_l.append(j + bounds[gi])
+    src, dst = th.cat(src_l), th.cat(dst_l)
+    o = th.argsort(dst * N + src)
+    src, dst = src[o], dst[o]
+    off = th.zeros(N + 1, dtype=th.int32)
+    off[1:] = th.cumsum(th.bincount(dst, minlength=N), 0)
+    kw = dict(x_a=th.zeros(N, 2), talk_off=off, talk_src=src.to(th.int32))
+    ref = HeteroBatch.from_arrays(**kw).talk_transpose()
+    g = HeteroBatch.from_arrays(**kw, device="cuda", graph_off=bounds)
+    assert g.hints["max_graph_agents"] == 130
+    for a, b in zip(ref, g.talk_transpose()):
+        assert th.equal(a, b.cpu())
 
 
 @pytest.mark.parametrize("N", [200_003, 4_300_001])

@@ -147,8 +147,10 @@ def test_general_unsorted_relation_is_gathered_into_segments():
 
 def test_slice_agents_views_and_relation_order():
     rng = np.random.default_rng(4)
-    gs = [from_obs_dicts(_obs(rng, 4, 9), np.zeros((4, 4)), r_comm=1.0) for _ in range(3)]
+    gs = [from_obs_dicts(_obs(rng, 4, 29), np.zeros((4, 4)), r_comm=1.0) for _ in range(3)]
     big = batch(gs)
+    assert big.hints == {"max_graph_agents": 4, "max_deg:seen": 29, "max_deg:near": 3}
+    assert big.relation_order("near") is None          # bounded by one 16-edge row tile: nothing to balance
     mid = big.slice_agents(4, 8)                       # the agents of the second environment
     for et in ("seen", "near"):
         xs, off = mid.relation_segments(et)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "uavgnn_csc_transpose_workspace_bytes": (ctypes.c_size_t, [_c_int]),
     "uavgnn_csc_transpose": (_c_int, [_c_ip, _c_ip, _c_int, _c_int, _c_ip, _c_ip, _c_ip, ctypes.c_void_p,
                                       ctypes.c_size_t, _c_st]),
+    "uavgnn_csc_transpose_env": (_c_int, [_c_ip, _c_ip, _c_ip, _c_int, _c_int, _c_ip, _c_ip, _c_ip, _c_st]),
     "uavgnn_gru_gates_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_st]),
     "uavgnn_gru_gates_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_st]),
 }

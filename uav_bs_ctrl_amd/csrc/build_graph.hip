@@ -332,6 +332,45 @@ __global__ void csc_transpose_sort_kernel(int N, const int32_t* __restrict__ t_o
   }
 }
 
+// Transpose for batches of small graphs whose talk edges never leave their graph (every batch built by
+// batch() / from_padded_obs / from_obs_dicts): one wavefront per graph, lane = source.  Pass 1 counts the out-edges
+// of every source (the graph's in-edges are scanned once, wave-uniform loads); the graph's out-slots start at the
+// CSC position of its first in-edge, so no global scan is needed; pass 2 walks the destinations in order and appends,
+// which leaves every out-list sorted by CSC position.  No atomics, no workspace, one launch.
+__global__ __launch_bounds__(kThreads) void csc_transpose_env_kernel(const int32_t* __restrict__ talk_off,
+                                                                     const int32_t* __restrict__ talk_src,
+                                                                     const int32_t* __restrict__ graph_off, int B,
+                                                                     int32_t* __restrict__ t_off,
+                                                                     int32_t* __restrict__ t_dst,
+                                                                     int32_t* __restrict__ t_pos) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int b = blockIdx.x * kWavesPerBlock + wave; b < B; b += gridDim.x * kWavesPerBlock) {
+    const int a0 = graph_off[b], a1 = graph_off[b + 1];
+    const int e_lo = talk_off[a0], e_hi = talk_off[a1];
+    int base = e_lo;
+    for (int u0 = a0; u0 < a1; u0 += kWave) {      // one trip when the graph has <= 64 agents
+      const int u = u0 + lane;
+      int cnt = 0;
+      for (int e = e_lo; e < e_hi; ++e) cnt += talk_src[e] == u;
+      const int inc = wave_scan_inclusive(cnt, lane);
+      int pos = base + inc - cnt;
+      if (u < a1) t_off[u] = pos;
+      for (int d = a0; d < a1; ++d) {
+        const int d1 = talk_off[d + 1];
+        for (int e = talk_off[d]; e < d1; ++e)
+          if (talk_src[e] == u) {
+            t_pos[pos] = e;
+            t_dst[pos] = d;
+            ++pos;
+          }
+      }
+      base += __shfl(inc, kWave - 1);
+    }
+    if (lane == 0) t_off[a1] = e_hi;   // == the next graph's first slot; the last graph closes the array
+  }
+}
+
 inline int order_blocks(int N) {
   const int b = (N + kOrderThreads - 1) / kOrderThreads;
   return b < 1 ? 1 : (b > kOrderMaxBlocks ? kOrderMaxBlocks : b);
@@ -430,5 +469,19 @@ extern "C" int uavgnn_csc_transpose(const int32_t* talk_off, const int32_t* talk
   hipLaunchKernelGGL(csc_transpose_fill_kernel, dim3(capped_grid(N, 256)), dim3(256), 0, st, talk_off, talk_src, N,
                      t_off, cursor, t_dst, t_pos);
   hipLaunchKernelGGL(csc_transpose_sort_kernel, dim3(capped_grid(N, 256)), dim3(256), 0, st, N, t_off, t_dst, t_pos);
+  return launch_status();
+}
+
+extern "C" int uavgnn_csc_transpose_env(const int32_t* talk_off, const int32_t* talk_src, const int32_t* graph_off,
+                                        int B, int N, int32_t* t_off, int32_t* t_dst, int32_t* t_pos,
+                                        uavgnn_stream_t stream) {
+  if (B < 0 || N < 0 || !talk_off || !graph_off || !t_off) return UAVGNN_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (B == 0 || N == 0) {
+    hipError_t e = hipMemsetAsync(t_off, 0, (static_cast<size_t>(N) + 1) * sizeof(int32_t), st);
+    return e == hipSuccess ? 0 : -static_cast<int>(e);
+  }
+  hipLaunchKernelGGL(csc_transpose_env_kernel, dim3(capped_grid(B, kWavesPerBlock, 4096)), dim3(kThreads), 0, st,
+                     talk_off, talk_src, graph_off, B, t_off, t_dst, t_pos);
   return launch_status();
 }

@@ -114,18 +114,25 @@ class RelationView:
 
 class HeteroBatch:
     def __init__(self, num_nodes: Dict[str, int], rels: Dict[tuple, _Relation],
-                 feat: Optional[Dict[str, Dict[str, th.Tensor]]] = None, graph_off: Optional[th.Tensor] = None):
+                 feat: Optional[Dict[str, Dict[str, th.Tensor]]] = None, graph_off: Optional[th.Tensor] = None,
+                 hints: Optional[Dict[str, int]] = None):
         self._num_nodes = dict(num_nodes)
         self._rels = dict(rels)
         self._feat = feat if feat is not None else {}
-        self.graph_off = graph_off          # [B+1] agent-node offsets of the batched env graphs (int32) or None
+        self.graph_off = graph_off          # [B+1] agent-node offsets of the batched env graphs (int32) or None;
+        #                                     talk edges never cross these boundaries
+        # Host-side facts the builders know for free and the device arrays would only yield through a sync:
+        #   "max_graph_agents"       - largest number of agents of one batched graph
+        #   "max_deg:seen" / ":near" - upper bound of the in-degree (the padded width M / U of the observation)
+        self.hints: Dict[str, int] = dict(hints or {})
         self._cache: Dict[str, object] = {}
 
     # ---- constructors -------------------------------------------------------------------------------------------
     @classmethod
     def from_arrays(cls, x_a, x_gt=None, seen_off=None, x_ubs=None, near_off=None, talk_off=None, talk_src=None,
-                    talk_eid=None, graph_off=None, x_flat=None, device=None) -> "HeteroBatch":
-        """Direct construction from segment-layout arrays (tests, benchmarks, device-side producers)."""
+                    talk_eid=None, graph_off=None, x_flat=None, device=None, hints=None) -> "HeteroBatch":
+        """Direct construction from segment-layout arrays (tests, benchmarks, device-side producers).  graph_off asserts
+        that talk edges stay inside the graphs it delimits; hints: see ``HeteroBatch.hints``."""
         f = lambda t: None if t is None else th.as_tensor(t, dtype=th.float32).to(device)  # noqa: E731
         x_a = f(x_a)
         n = x_a.shape[0]
@@ -144,7 +151,12 @@ class HeteroBatch:
             rels[TALK] = _Relation(_i32(talk_off, device), _i32(talk_src, device),
                                    None if talk_eid is None else _i32(talk_eid, device))
         go = None if graph_off is None else _i32(graph_off, device)
-        return cls(num_nodes, rels, feat, go)
+        hints = dict(hints or {})
+        if graph_off is not None and "max_graph_agents" not in hints and not (
+                isinstance(graph_off, th.Tensor) and graph_off.is_cuda):
+            d = np.diff(np.asarray(graph_off, dtype=np.int64))
+            hints["max_graph_agents"] = int(d.max()) if d.size else 0
+        return cls(num_nodes, rels, feat, go, hints)
 
     # ---- DGL-like surface ---------------------------------------------------------------------------------------
     @property
@@ -202,7 +214,7 @@ class HeteroBatch:
                 for nt, fr in self._feat.items()}
         rels = {c: r.to(device) for c, r in self._rels.items()}
         go = None if self.graph_off is None else self.graph_off.to(device)
-        return HeteroBatch(self._num_nodes, rels, feat, go)
+        return HeteroBatch(self._num_nodes, rels, feat, go, self.hints)
 
     def pin_memory(self) -> "HeteroBatch":
         for fr in self._feat.values():
@@ -234,7 +246,10 @@ class HeteroBatch:
         key = "ord:" + etype
         if key not in self._cache:
             off = self._rels[self._canon(etype)].off
-            if off.is_cuda:     # HIP counting sort (csrc/build_graph.hip): 3 launches, no host sync
+            if self.hints.get("max_deg:" + etype, 1 << 30) <= 16:
+                # every destination costs one 16-edge row tile whatever its degree: nothing to balance
+                self._cache[key] = None
+            elif off.is_cuda:     # HIP counting sort (csrc/build_graph.hip): 3 launches, no host sync
                 from . import _lib as L
                 n = off.numel() - 1
                 order = th.empty(n, dtype=th.int32, device=off.device)
@@ -267,11 +282,18 @@ class HeteroBatch:
                 t_off = th.empty(n + 1, dtype=th.int32, device=off.device)
                 t_dst = th.empty(E, dtype=th.int32, device=off.device)
                 t_pos = th.empty(E, dtype=th.int32, device=off.device)
-                nbytes = L.lib().uavgnn_csc_transpose_workspace_bytes(n)
-                ws = th.empty(nbytes // 4, dtype=th.int32, device=off.device)
-                L.check(L.lib().uavgnn_csc_transpose(off.data_ptr(), L.ptr(src), n, E, t_off.data_ptr(), L.ptr(t_dst),
-                                                     L.ptr(t_pos), ws.data_ptr(), nbytes, L.stream()),
-                        "uavgnn_csc_transpose")
+                go = self.graph_off
+                if go is not None and go.is_cuda and self.hints.get("max_graph_agents", 1 << 30) <= 256:
+                    # batch of small graphs: one wavefront per graph, one launch
+                    L.check(L.lib().uavgnn_csc_transpose_env(off.data_ptr(), L.ptr(src), go.data_ptr(),
+                                                             go.numel() - 1, n, t_off.data_ptr(), L.ptr(t_dst),
+                                                             L.ptr(t_pos), L.stream()), "uavgnn_csc_transpose_env")
+                else:
+                    nbytes = L.lib().uavgnn_csc_transpose_workspace_bytes(n)
+                    ws = th.empty(nbytes // 4, dtype=th.int32, device=off.device)
+                    L.check(L.lib().uavgnn_csc_transpose(off.data_ptr(), L.ptr(src), n, E, t_off.data_ptr(),
+                                                         L.ptr(t_dst), L.ptr(t_pos), ws.data_ptr(), nbytes,
+                                                         L.stream()), "uavgnn_csc_transpose")
                 self._cache["talkT"] = (t_off, t_dst, t_pos)
             else:
                 dst = seg_ids(off)
@@ -283,7 +305,7 @@ class HeteroBatch:
     def fresh(self) -> "HeteroBatch":
         """The same graph (shared storage) without any derived index - how a newly built batch looks to the path."""
         return HeteroBatch(self._num_nodes, self._rels, {nt: dict(fr) for nt, fr in self._feat.items()},
-                           self.graph_off)
+                           self.graph_off, self.hints)
 
     def slice_agents(self, lo: int, hi: int) -> "HeteroBatch":
         """Observation part (agent features + `seen`/`near`) of agents [lo, hi) as a new HeteroBatch whose feature
@@ -301,7 +323,7 @@ class HeteroBatch:
             rels[c] = _Relation((off - off[0]).contiguous())
             feat[c[0]] = {"feat": self._feat[c[0]]["feat"][e0:e1]}
             num_nodes[c[0]] = e1 - e0
-        return HeteroBatch(num_nodes, rels, feat)
+        return HeteroBatch(num_nodes, rels, feat, hints={k: v for k, v in self.hints.items() if k.startswith("max_deg:")})
 
     def __repr__(self):
         e = {c[1]: r.num_edges for c, r in self._rels.items()}
@@ -336,6 +358,20 @@ def heterograph(data_dict, num_nodes_dict=None) -> HeteroBatch:
         else:
             rels[c] = _Relation(off, None if ident else su.to(th.int32))
     return HeteroBatch(num_nodes, rels, {})
+
+
+def _union_hints(graphs: Sequence[HeteroBatch]) -> Dict[str, int]:
+    """Hints of a disjoint union: a bound holds for the union when every part states it."""
+    out: Dict[str, int] = {}
+    per_graph = [g.hints.get("max_graph_agents") if g.graph_off is not None else g._num_nodes.get("agent", 0)
+                 for g in graphs]
+    if all(v is not None for v in per_graph):
+        out["max_graph_agents"] = max(per_graph)
+    for key in ("max_deg:seen", "max_deg:near"):
+        vals = [g.hints.get(key) for g in graphs]
+        if all(v is not None for v in vals):
+            out[key] = max(vals)
+    return out
 
 
 def batch(graphs: Sequence[HeteroBatch]) -> HeteroBatch:
@@ -378,7 +414,7 @@ def batch(graphs: Sequence[HeteroBatch]) -> HeteroBatch:
             parts.append(th.full((1,), base + n_ag, dtype=th.int32, device=g0.device))
         base += n_ag
     go = th.cat(parts).to(th.int32)
-    return HeteroBatch(num_nodes, rels, feat, go.to(g0.device))
+    return HeteroBatch(num_nodes, rels, feat, go.to(g0.device), _union_hints(graphs))
 
 
 def merge(graphs: Sequence[HeteroBatch]) -> HeteroBatch:
@@ -405,7 +441,12 @@ def merge(graphs: Sequence[HeteroBatch]) -> HeteroBatch:
             if g._num_nodes.get(nt, 0) == num_nodes[nt]:
                 for k, v in g._feat.get(nt, {}).items():
                     feat[nt].setdefault(k, v)
-    return HeteroBatch(num_nodes, rels, feat)
+    go = next((g.graph_off for g in graphs if g.graph_off is not None), None)
+    hints: Dict[str, int] = {}
+    for g in graphs:
+        for k, v in g.hints.items():
+            hints[k] = max(v, hints.get(k, v))
+    return HeteroBatch(num_nodes, rels, feat, go, hints)
 
 
 def cat(data_list: List):
@@ -432,7 +473,7 @@ def from_obs_dicts(obs: Sequence[dict], d_u2u=None, r_comm: float = np.inf, with
     seen_off = np.concatenate([[0], np.cumsum(mg.sum(1))]).astype(np.int32)
     near_off = np.concatenate([[0], np.cumsum(mu.sum(1))]).astype(np.int32)
     kw = dict(x_a=xa, x_gt=gt[mg][:, 1:], seen_off=seen_off, x_ubs=ub[mu][:, 1:], near_off=near_off,
-              graph_off=[0, n])
+              graph_off=[0, n], hints={"max_deg:seen": gt.shape[1], "max_deg:near": ub.shape[1]})
     if with_comm:
         adj = np.asarray(d_u2u) <= r_comm                                    # adj[i, j]: edge i -> j
         eid_of = np.cumsum(adj.reshape(-1)).reshape(n, n) - 1                 # reference edge id (i-major order)
@@ -481,7 +522,8 @@ def from_padded_obs(gt: th.Tensor, ubs: th.Tensor, agent: th.Tensor, d_u2u: Opti
                                        near_off.data_ptr(), x_gt.data_ptr(), x_ubs.data_ptr(), L.stream()),
             "uavgnn_obs_compact")
     kw = dict(x_a=agent.view(N, -1), x_gt=x_gt, seen_off=seen_off, x_ubs=x_ubs, near_off=near_off,
-              graph_off=th.arange(0, N + 1, n, **i32))
+              graph_off=th.arange(0, N + 1, n, **i32),
+              hints={"max_graph_agents": n, "max_deg:seen": M, "max_deg:near": U})
     if with_comm:
         talk_src, talk_eid = th.empty(Et, **i32), th.empty(Et, **i32)
         L.check(L.lib().uavgnn_talk_compact(d_u2u.data_ptr(), n, B, float(min(r_comm, 3.0e38)), talk_off.data_ptr(),
