@@ -147,6 +147,24 @@ int uavgnn_talk_degrees(const float* d_u2u, int n, int B, float r_comm, int32_t*
 int uavgnn_talk_compact(const float* d_u2u, int n, int B, float r_comm, const int32_t* talk_off,
                         const int32_t* env_base, int32_t* talk_src, int32_t* talk_eid, uavgnn_stream_t stream);
 
+/* ---- K3b, per-graph formulation ---------------------------------------------------------------------------------
+ * Same contract and arithmetic as uavgnn_talk_attn_fwd / _bwd for a batch of B SMALL graphs (what dgl.batch of
+ * per-environment graphs gives: common.py:45, env_wrappers.py:139-154): graph_off[B+1] = agent-node boundaries, every
+ * graph has at most n_max <= 16 agents and at most n_max^2 talk edges, all of them inside the graph.  One wavefront
+ * per graph, projections staged in LDS; the backward needs neither the transposed CSC nor a scratch array.  A graph
+ * that violates the bounds gets NaN outputs.  uavgnn_talk_attn_env_supported(n_max, M, K) -> 1 when the shape fits
+ * (K = 0 for uniform mode); otherwise use the per-destination entry points.
+ */
+int uavgnn_talk_attn_env_supported(int n_max, int M, int K);
+int uavgnn_talk_attn_env_fwd(const float* s, int ld_s, const float* q, int ld_q, const float* v, int ld_v, int K, int M,
+                             const int32_t* talk_off, const int32_t* talk_src, const int32_t* graph_off, int B,
+                             int n_max, float scale, float* c, int ld_c, float* a_save, const float* x_copy, int ld_x,
+                             int n_copy, uavgnn_stream_t stream);
+int uavgnn_talk_attn_env_bwd(const float* s, int ld_s, const float* q, int ld_q, const float* v, int ld_v, int K, int M,
+                             const int32_t* talk_off, const int32_t* talk_src, const int32_t* graph_off, int B,
+                             int n_max, float scale, const float* a_save, const float* d_c, int ld_dc, float* d_s,
+                             int ld_ds, float* d_q, int ld_dq, float* d_v, int ld_dv, uavgnn_stream_t stream);
+
 /* ---- derived indexes of a batch --------------------------------------------------------------------------------
  * What the reference gets from DGL's lazy format materialisation (CSR/CSC created inside the first message-passing
  * call on every new graph - reached from gnn_agents.py:103-104, :264-267) is explicit here and deterministic.

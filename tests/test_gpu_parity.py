@@ -616,3 +616,108 @@ def test_csc_transpose_large_scan_and_empty(N):
                                  talk_src=th.zeros(0, dtype=th.int32), device="cuda")
     t_off, t_dst, t_pos = g0.talk_transpose()
     assert t_off.cpu().tolist() == [0] * 8 and t_dst.numel() == 0 and t_pos.numel() == 0
+
+
+def _ragged_env_talk(sizes, p, seed):
+    """Batch of small graphs with random in-graph talk edges (simple graphs, CSC order).  Returns host arrays."""
+    gen = th.Generator().manual_seed(seed)
+    bounds = [0]
+    for k in sizes:
+        bounds.append(bounds[-1] + k)
+    N = bounds[-1]
+    src_l, dst_l = [], []
+    for gi, k in enumerate(sizes):
+        adj = th.rand(k, k, generator=gen) < (0.0 if gi % 5 == 3 else p)
+        i, j = adj.nonzero(as_tuple=True)
+        src_l.append(i + bounds[gi])
+        dst_l.append(j + bounds[gi])
+    src, dst = th.cat(src_l), th.cat(dst_l)
+    o = th.argsort(dst * N + src)
+    src, dst = src[o], dst[o]
+    off = th.zeros(N + 1, dtype=th.int32)
+    off[1:] = th.cumsum(th.bincount(dst, minlength=N), 0)
+    return N, off, src.to(th.int32), dst, bounds
+
+
+@pytest.mark.parametrize("sizes,p,K,M", [([8] * 37, 1.0, 16, 64), ([1, 16, 3, 8, 2, 16, 5, 7, 9, 1, 1, 12], 0.5, 16, 64),
+                                         ([4] * 9 + [13, 2], 0.7, 5, 200), ([16] * 5, 1.0, 32, 128),
+                                         ([6, 6, 6], 0.3, 1, 1)])
+def test_talk_attention_per_graph_kernels_vs_oracle_and_per_destination_kernels(sizes, p, K, M):
+    """K3b per-graph formulation (one wavefront per graph, LDS-staged, transpose-free backward) against the fp64 oracle
+    and against the per-destination kernels on the same batch: ragged graph sizes 1..16, graphs without edges, complete
+    graphs with self loops, K / M at their limits, uniform (mean) mode."""
+    from uav_bs_ctrl_amd import ops
+    from uav_bs_ctrl_amd.graph import HeteroBatch
+    N, off, src, dst, bounds = _ragged_env_talk(sizes, p, seed=len(sizes))
+    kw = dict(x_a=th.zeros(N, 2), talk_off=off, talk_src=src)
+    g_env = HeteroBatch.from_arrays(**kw, graph_off=bounds, device="cuda")
+    g_dst = HeteroBatch.from_arrays(**kw, device="cuda")
+    assert ops._talk_env(g_env, M, K) is not None and ops._talk_env(g_dst, M, K) is None
+    assert ops._talk_env(g_env, 256, 64) is None or max(sizes) < 16     # LDS budget: falls back to per-destination
+    gen = th.Generator().manual_seed(2)
+    s, q, v = (th.randn(N, d, generator=gen) for d in (K, K, M))
+    w = th.randn(N, M, generator=gen)
+
+    def ref(s_, q_, v_, uniform):
+        if uniform:
+            return R.segment_mean(v_[src.long()], dst, N)
+        e = (s_[src.long()] * q_[dst]).sum(-1, keepdim=True) / K
+        return R.segment_sum(v_[src.long()] * R.segment_softmax(e, dst, N), dst, N)
+
+    for uniform in (False, True):
+        s64, q64, v64 = (t.double().requires_grad_(True) for t in (s, q, v))
+        c64 = ref(s64, q64, v64, uniform)
+        g64 = th.autograd.grad((c64 * w.double()).sum(), [v64] if uniform else [s64, q64, v64])
+        outs = []
+        for g in (g_env, g_dst):
+            sd, qd, vd = (t.cuda().requires_grad_(True) for t in (s, q, v))
+            c = ops.talk_attention(None if uniform else sd, None if uniform else qd, vd, g, 1.0 / K)
+            got = th.autograd.grad((c * w.cuda()).sum(), [vd] if uniform else [sd, qd, vd])
+            outs.append((c, got))
+        (c, got), (c2, got2) = outs
+        assert "talkT" not in g_env._cache                 # the per-graph backward never builds the transpose
+        assert_close(c, c64, 1e-5, f"c uniform={uniform}")
+        assert_close(c, c2, 2e-6, f"c env vs dst uniform={uniform}")
+        for a, b, b2, nm in zip(got, g64, got2, ["d_v"] if uniform else ["d_s", "d_q", "d_v"]):
+            assert_close(a, b, 1e-4, f"{nm} uniform={uniform}", floor=1e-6)
+            assert_close(a, b2, 1e-5, f"{nm} env vs dst uniform={uniform}", floor=1e-6)
+
+
+def test_talk_attention_per_graph_kernel_fails_loudly_on_a_wrong_hint():
+    """A graph larger than the hinted bound must not be silently mis-computed: its rows come back NaN."""
+    from uav_bs_ctrl_amd import ops
+    from uav_bs_ctrl_amd.graph import HeteroBatch
+    N, off, src, dst, bounds = _ragged_env_talk([4, 9, 4], 1.0, seed=0)
+    g = HeteroBatch.from_arrays(x_a=th.zeros(N, 2), talk_off=off, talk_src=src, graph_off=bounds, device="cuda",
+                                hints={"max_graph_agents": 4})
+    v = th.randn(N, 8, device="cuda")
+    c = ops.talk_attention(None, None, v, g, 1.0)
+    assert th.isnan(c[4:13]).all() and th.isfinite(c[:4]).all() and th.isfinite(c[13:]).all()
+
+
+def test_agent_paths_per_graph_and_per_destination_agree():
+    """The whole TarMAC agent (fused step) through both K3b formulations: hints present -> per-graph kernels, hints
+    stripped -> per-destination kernels + device-built transpose.  Same loss and gradients."""
+    from gpu_util import synth_graph, to_batch, default_init_params, agent_from_params
+    cfg = dict(enc="gnn", c="tarmac", n_heads=4, key_size=16, msg_size=64, n_rounds=1, dueling=False, hidden_size=64,
+               n_actions=7)
+    B, n, M = 48, 8, 20
+    g1 = to_batch(synth_graph(B, n, M, dist="env", seed=3, talk="sparse"))
+    g2 = g1.fresh()
+    g2.hints = {}
+    p = default_init_params(cfg, seed=1)
+    res = []
+    for g in (g1, g2):
+        net = agent_from_params(p, cfg)
+        h = 0.1 * th.randn(B * n, 64, device="cuda", generator=th.Generator(device="cuda").manual_seed(0))
+        h.requires_grad_(True)
+        q, h2 = net(g, h)
+        loss = (q ** 2).mean() + (h2 ** 2).mean()
+        loss.backward()
+        res.append((loss.detach(), {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None},
+                    h.grad.clone()))
+    assert ("talkT" in g2._cache) and ("talkT" not in g1._cache)
+    assert_close(res[0][0], res[1][0], 1e-6, "loss")
+    assert_close(res[0][2], res[1][2], 1e-5, "d_h", floor=1e-7)
+    for k in res[0][1]:
+        assert_close(res[0][1][k], res[1][1][k], 1e-5, k, floor=1e-7)

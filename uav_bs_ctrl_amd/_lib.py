@@ -51,6 +51,13 @@ SIGNATURES = {
     "uavgnn_csc_transpose": (_c_int, [_c_ip, _c_ip, _c_int, _c_int, _c_ip, _c_ip, _c_ip, ctypes.c_void_p,
                                       ctypes.c_size_t, _c_st]),
     "uavgnn_csc_transpose_env": (_c_int, [_c_ip, _c_ip, _c_ip, _c_int, _c_int, _c_ip, _c_ip, _c_ip, _c_st]),
+    "uavgnn_talk_attn_env_supported": (_c_int, [_c_int, _c_int, _c_int]),
+    "uavgnn_talk_attn_env_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip,
+                                          _c_ip, _c_int, _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_int,
+                                          _c_st]),
+    "uavgnn_talk_attn_env_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip,
+                                          _c_ip, _c_int, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_int, _c_fp,
+                                          _c_int, _c_fp, _c_int, _c_st]),
     "uavgnn_gru_gates_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_st]),
     "uavgnn_gru_gates_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_st]),
 }

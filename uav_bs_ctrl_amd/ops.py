@@ -145,11 +145,53 @@ def _talk_transpose_if_needed(g, *tensors):
     return None, None, None
 
 
+def _talk_env(g, M, K):
+    """(graph_off, B, n_max) when the batch is made of small graphs the per-graph K3b kernels cover, else None."""
+    go, n_max = g.graph_off, g.hints.get("max_graph_agents")
+    if go is None or not go.is_cuda or n_max is None or n_max < 1:
+        return None
+    if not L.lib().uavgnn_talk_attn_env_supported(int(n_max), int(M), int(K)):
+        return None
+    return go, go.numel() - 1, int(n_max)
+
+
+def _launch_talk_fwd(env, s, ld_s, q, ld_q, v, ld_v, K, M, talk_off, talk_src, N, scale, c, ld_c, a_save, x_copy, ld_x,
+                     n_copy):
+    """K3b forward on raw pointers: per-graph kernel when `env` describes the batch, per-destination kernel otherwise."""
+    with KERNEL_TIMER.span("talk_attn_fwd"):
+        if env is not None:
+            go, B, n_max = env
+            rc = L.lib().uavgnn_talk_attn_env_fwd(s, ld_s, q, ld_q, v, ld_v, K, M, L.ptr(talk_off), L.ptr(talk_src),
+                                                  go.data_ptr(), B, n_max, scale, c, ld_c, a_save, x_copy, ld_x, n_copy,
+                                                  L.stream())
+        else:
+            rc = L.lib().uavgnn_talk_attn_fwd(s, ld_s, q, ld_q, v, ld_v, K, M, L.ptr(talk_off), L.ptr(talk_src), N,
+                                              scale, c, ld_c, a_save, x_copy, ld_x, n_copy, L.stream())
+    L.check(rc, "uavgnn_talk_attn_fwd")
+
+
+def _launch_talk_bwd(env, s, ld_s, q, ld_q, v, ld_v, K, M, talk_off, talk_src, transpose, N, scale, a_save, d_c, ld_dc,
+                     d_s, ld_ds, d_q, ld_dq, d_v, ld_dv):
+    with KERNEL_TIMER.span("talk_attn_bwd"):
+        if env is not None:
+            go, B, n_max = env
+            rc = L.lib().uavgnn_talk_attn_env_bwd(s, ld_s, q, ld_q, v, ld_v, K, M, L.ptr(talk_off), L.ptr(talk_src),
+                                                  go.data_ptr(), B, n_max, scale, a_save.data_ptr(), d_c, ld_dc, d_s,
+                                                  ld_ds, d_q, ld_dq, d_v, ld_dv, L.stream())
+        else:
+            t_off, t_dst, t_pos = transpose
+            de = th.empty_like(a_save) if s is not None else None
+            rc = L.lib().uavgnn_talk_attn_bwd(s, ld_s, q, ld_q, v, ld_v, K, M, L.ptr(talk_off), L.ptr(talk_src),
+                                              L.ptr(t_off), L.ptr(t_dst), L.ptr(t_pos), N, scale, a_save.data_ptr(),
+                                              d_c, ld_dc, d_s, ld_ds, d_q, ld_dq, d_v, ld_dv, L.ptr(de), L.stream())
+    L.check(rc, "uavgnn_talk_attn_bwd")
+
+
 class _TalkAttention(th.autograd.Function):
     """K3b.  c_v = sum_u softmax_u(<s_u, q_v> * scale) v_u over the talk relation; s = q = None -> mean."""
 
     @staticmethod
-    def forward(ctx, s, q, v, talk_off, talk_src, t_off, t_dst, t_pos, scale):
+    def forward(ctx, s, q, v, talk_off, talk_src, t_off, t_dst, t_pos, scale, env=None):
         L.require_gpu(v, talk_off, talk_src, s, q)
         N, M = v.shape
         K = 0 if s is None else s.shape[1]
@@ -159,13 +201,10 @@ class _TalkAttention(th.autograd.Function):
         E = talk_src.shape[0]
         c = th.empty((N, M), dtype=th.float32, device=v.device)
         a_save = th.empty(max(E, 1), dtype=th.float32, device=v.device)
-        with KERNEL_TIMER.span("talk_attn_fwd"):
-            rc = L.lib().uavgnn_talk_attn_fwd(L.ptr(s), 0 if s is None else s.stride(0), L.ptr(q),
-                                              0 if q is None else q.stride(0), L.ptr(v), v.stride(0), K, M,
-                                              L.ptr(talk_off), L.ptr(talk_src), N, float(scale), c.data_ptr(),
-                                              c.stride(0), a_save.data_ptr(), None, 0, 0, L.stream())
-        L.check(rc, "uavgnn_talk_attn_fwd")
-        ctx.scale, ctx.uniform = float(scale), s is None
+        _launch_talk_fwd(env, L.ptr(s), 0 if s is None else s.stride(0), L.ptr(q), 0 if q is None else q.stride(0),
+                         L.ptr(v), v.stride(0), K, M, talk_off, talk_src, N, float(scale), c.data_ptr(), c.stride(0),
+                         a_save.data_ptr(), None, 0, 0)
+        ctx.scale, ctx.uniform, ctx.env = float(scale), s is None, env
         ctx.save_for_backward(*(t for t in (s, q) if t is not None), v, talk_off, talk_src, t_off, t_dst, t_pos, a_save)
         return c
 
@@ -180,27 +219,22 @@ class _TalkAttention(th.autograd.Function):
         K = 0 if s is None else s.shape[1]
         d_c = d_c.contiguous()
         d_v = th.empty((N, M), dtype=th.float32, device=v.device)
-        d_s = d_q = de = None
+        d_s = d_q = None
         if not ctx.uniform:
             d_s = th.empty((N, K), dtype=th.float32, device=v.device)
             d_q = th.empty((N, K), dtype=th.float32, device=v.device)
-            de = th.empty_like(a_save)
-        with KERNEL_TIMER.span("talk_attn_bwd"):
-            rc = L.lib().uavgnn_talk_attn_bwd(L.ptr(s), 0 if s is None else s.stride(0), L.ptr(q),
-                                              0 if q is None else q.stride(0), L.ptr(v), v.stride(0), K, M,
-                                              L.ptr(talk_off), L.ptr(talk_src), L.ptr(t_off), L.ptr(t_dst),
-                                              L.ptr(t_pos), N, ctx.scale, a_save.data_ptr(), d_c.data_ptr(),
-                                              d_c.stride(0), L.ptr(d_s), K, L.ptr(d_q), K, d_v.data_ptr(), M,
-                                              L.ptr(de), L.stream())
-        L.check(rc, "uavgnn_talk_attn_bwd")
-        return d_s, d_q, d_v, None, None, None, None, None, None
+        _launch_talk_bwd(ctx.env, L.ptr(s), 0 if s is None else s.stride(0), L.ptr(q), 0 if q is None else q.stride(0),
+                         L.ptr(v), v.stride(0), K, M, talk_off, talk_src, (t_off, t_dst, t_pos), N, ctx.scale, a_save,
+                         d_c.data_ptr(), d_c.stride(0), L.ptr(d_s), K, L.ptr(d_q), K, d_v.data_ptr(), M)
+        return d_s, d_q, d_v, None, None, None, None, None, None, None
 
 
 def talk_attention(s, q, v, g, scale=1.0):
     """g: HeteroBatch carrying the talk relation."""
     off, src = g.talk_csc()
-    t_off, t_dst, t_pos = _talk_transpose_if_needed(g, s, q, v)
-    return _TalkAttention.apply(s, q, v, off, src, t_off, t_dst, t_pos, scale)
+    env = _talk_env(g, v.shape[1], 0 if s is None else s.shape[1])
+    t_off, t_dst, t_pos = (None, None, None) if env is not None else _talk_transpose_if_needed(g, s, q, v)
+    return _TalkAttention.apply(s, q, v, off, src, t_off, t_dst, t_pos, scale, env)
 
 
 class _GruGates(th.autograd.Function):
@@ -403,7 +437,7 @@ class _TarmacStep(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, h, Wp, bp, W_ih, b_ih, W_hh, b_hh, W_out, b_out, M, K, talk_off, talk_src, t_off, t_dst, t_pos,
-                split):
+                split, env=None):
         L.require_gpu(x, h, Wp, W_ih, talk_off)
         N, H = x.shape
         x, h = L.f32c(x), L.f32c(h)
@@ -413,12 +447,9 @@ class _TarmacStep(th.autograd.Function):
         E = talk_src.shape[0]
         a_save = th.empty(max(E, 1), dtype=th.float32, device=x.device)
         ld = M + 2 * K
-        with KERNEL_TIMER.span("talk_attn_fwd"):
-            rc = L.lib().uavgnn_talk_attn_fwd(proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld,
-                                              proj.data_ptr(), ld, K, M, L.ptr(talk_off), L.ptr(talk_src), N,
-                                              1.0 / K, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(),
-                                              x.data_ptr(), x.stride(0), H, L.stream())
-        L.check(rc, "uavgnn_talk_attn_fwd")
+        _launch_talk_fwd(env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld, K, M,
+                         talk_off, talk_src, N, 1.0 / K, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(), x.data_ptr(),
+                         x.stride(0), H)
         gi = th.addmm(b_ih, inp, W_ih.t())
         gh = th.addmm(b_hh, h, W_hh.t())
         h2 = th.empty_like(h)
@@ -427,7 +458,7 @@ class _TarmacStep(th.autograd.Function):
         L.check(rc, "uavgnn_gru_gates_fwd")
         q = th.addmm(b_out, h2, W_out.t())
         ctx.dims = (M, K)
-        ctx.split = split
+        ctx.split, ctx.env = split, env
         ctx.save_for_backward(x, h, proj, inp, gi, gh, h2, a_save, Wp, W_ih, W_hh, W_out, talk_off, talk_src, t_off,
                               t_dst, t_pos)
         return q, h2
@@ -450,15 +481,10 @@ class _TarmacStep(th.autograd.Function):
         dh.addmm_(d_gh, W_hh)
         ld = M + 2 * K
         d_proj = th.empty((N, ld), dtype=th.float32, device=x.device)
-        de = th.empty_like(a_save)
-        with KERNEL_TIMER.span("talk_attn_bwd"):
-            rc = L.lib().uavgnn_talk_attn_bwd(proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld,
-                                              proj.data_ptr(), ld, K, M, L.ptr(talk_off), L.ptr(talk_src), L.ptr(t_off),
-                                              L.ptr(t_dst), L.ptr(t_pos), N, 1.0 / K, a_save.data_ptr(),
-                                              d_inp.data_ptr() + 4 * H, H + M, d_proj.data_ptr() + 4 * M, ld,
-                                              d_proj.data_ptr() + 4 * (M + K), ld, d_proj.data_ptr(), ld, de.data_ptr(),
-                                              L.stream())
-        L.check(rc, "uavgnn_talk_attn_bwd")
+        _launch_talk_bwd(ctx.env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld,
+                         K, M, talk_off, talk_src, (t_off, t_dst, t_pos), N, 1.0 / K, a_save, d_inp.data_ptr() + 4 * H,
+                         H + M, d_proj.data_ptr() + 4 * M, ld, d_proj.data_ptr() + 4 * (M + K), ld, d_proj.data_ptr(),
+                         ld)
         dx = th.addmm(d_inp[:, :H], d_proj, Wp[:, :H])                    # h enters the projections stop-gradded
         if sink is not None:
             split = ctx.split
@@ -479,7 +505,7 @@ class _TarmacStep(th.autograd.Function):
             gWih, gbih = _wgrad(d_gi, inp), _colsum(d_gi)
             gWhh, gbhh = _wgrad(d_gh, h), th.cat((gbih[:2 * H], _colsum(d_gh[:, 2 * H:])))
             gWo, gbo = _wgrad(dq, h2), _colsum(dq)
-        return (dx, dh, gWp, gbp, gWih, gbih, gWhh, gbhh, gWo, gbo) + (None,) * 8
+        return (dx, dh, gWp, gbp, gWih, gbih, gWhh, gbhh, gWo, gbo) + (None,) * 9
 
 
 def tarmac_step(x, h, g, comm, f_out, stacked=None):
@@ -489,7 +515,9 @@ def tarmac_step(x, h, g, comm, f_out, stacked=None):
     Wp, bp = stacked if stacked is not None else comm.fused_projection()
     off, src = g.talk_csc()
     cell = comm.f_udt
-    t_off, t_dst, t_pos = _talk_transpose_if_needed(g, x, h, Wp, cell.weight_ih, f_out.weight)
+    env = _talk_env(g, M, K)
+    t_off, t_dst, t_pos = ((None, None, None) if env is not None else
+                           _talk_transpose_if_needed(g, x, h, Wp, cell.weight_ih, f_out.weight))
     H = cell.weight_hh.shape[1]
     params = {"W_ih": cell.weight_ih, "b_ih": cell.bias_ih, "W_hh": cell.weight_hh, "b_hh": cell.bias_hh,
               "W_out": f_out.weight, "b_out": f_out.bias}
@@ -519,7 +547,7 @@ def tarmac_step(x, h, g, comm, f_out, stacked=None):
             _add_grad(params[name], grad)
 
     return _TarmacStep.apply(x, h, Wp, bp, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, f_out.weight,
-                             f_out.bias, M, K, off, src, t_off, t_dst, t_pos, split)
+                             f_out.bias, M, K, off, src, t_off, t_dst, t_pos, split, env)
 
 
 class _DiscComm(th.autograd.Function):
