@@ -51,14 +51,34 @@ struct EnvGraph {
   int a0, n, e_lo, E;
 };
 
-// Rows [a0, a0+n) x [0, W) of a row-major matrix -> LDS rows of stride lds_ld (coalesced along the row).
-__device__ __forceinline__ void stage_rows(const float* __restrict__ src, int ld, int a0, int n, int W,
+// Staging.  A wavefront owns one graph (a few KB), so what matters is the number of DEPENDENT global round trips,
+// not bytes: the first 8 rows x first 64 columns of every matrix are loaded back to back (row index clamped instead
+// of predicated: no branches) and only then written to LDS; whatever is left (more than 8 agents, rows wider than 64)
+// goes through the plain loop of stage_rest.
+constexpr int kRows = 8;
+
+__device__ __forceinline__ void load_rows(const float* __restrict__ src, int ld, int a0, int n, int W, int lane,
+                                          float (&r)[kRows]) {
+  const float* __restrict__ base = src + static_cast<size_t>(a0) * ld;   // wave-uniform base, 32-bit lane offsets
+  const int colc = lane < W ? lane : 0;
+#pragma unroll
+  for (int t = 0; t < kRows; ++t) r[t] = base[static_cast<unsigned>((t < n ? t : n - 1) * ld + colc)];
+}
+
+__device__ __forceinline__ void store_rows(float* __restrict__ dst, int lds_ld, int n, int W, int lane,
+                                           const float (&r)[kRows]) {
+#pragma unroll
+  for (int t = 0; t < kRows; ++t)
+    if (t < n && lane < W) dst[t * lds_ld + lane] = r[t];
+}
+
+__device__ __forceinline__ void stage_rest(const float* __restrict__ src, int ld, int a0, int n, int W,
                                            float* __restrict__ dst, int lds_ld, int lane) {
 #pragma unroll 1
   for (int i = 0; i < n; ++i) {
     const float* __restrict__ r = src + static_cast<size_t>(a0 + i) * ld;
-#pragma unroll 2
-    for (int k = lane; k < W; k += kWave) dst[i * lds_ld + k] = r[k];
+#pragma unroll 1
+    for (int k = (i < kRows ? kWave : 0) + lane; k < W; k += kWave) dst[i * lds_ld + k] = r[k];
   }
 }
 
@@ -97,39 +117,65 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_fwd_kern
   const bool x4 = x_copy != nullptr && (n_copy % 4 == 0) && (ld_x % 4 == 0) && (ld_c % 4 == 0) &&
                   ((reinterpret_cast<uintptr_t>(x_copy) & 15) == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0);
 
+  // blockIdx.y == 1: copy-only workgroups.  The x half of the [x || c] rows is a pure stream (2/3 of this kernel's
+  // bytes); giving it its own wavefronts lets it overlap the LDS phases of the attention wavefronts, which otherwise
+  // all load, compute and store in lock step (there is exactly one wavefront per graph in flight).
+  if (blockIdx.y == 1) {
+    for (int b = blockIdx.x * waves + wave; b < B; b += gridDim.x * waves) {
+      EnvGraph g;
+      g.a0 = graph_off[b];
+      g.n = graph_off[b + 1] - g.a0;
+      if (x_copy != nullptr) {
+#pragma unroll 1
+        for (int i = 0; i < g.n; ++i) {
+          const float* __restrict__ xs = x_copy + static_cast<size_t>(g.a0 + i) * ld_x;
+          float* __restrict__ xd = c + static_cast<size_t>(g.a0 + i) * ld_c - n_copy;
+          if (x4) {
+#pragma unroll 4
+            for (int k = lane * 4; k < n_copy; k += kWave * 4)
+              *reinterpret_cast<float4*>(xd + k) = *reinterpret_cast<const float4*>(xs + k);
+          } else {
+            for (int k = lane; k < n_copy; k += kWave) xd[k] = xs[k];
+          }
+        }
+      }
+    }
+    return;
+  }
+
   for (int b = blockIdx.x * waves + wave; b < B; b += gridDim.x * waves) {
     EnvGraph g;
     g.a0 = graph_off[b];
     g.n = graph_off[b + 1] - g.a0;
     const int toff = lane <= g.n ? talk_off[g.a0 + lane] : 0;
+    if (g.n == 0) continue;
+    float rv[kRows], rs[kRows], rq[kRows];    // issued before anything waits on toff
+    load_rows(v, ld_v, g.a0, g.n, M, lane, rv);
+    if (!uniform) {
+      load_rows(s, ld_s, g.a0, g.n, K, lane, rs);
+      load_rows(q, ld_q, g.a0, g.n, K, lane, rq);
+    }
     g.e_lo = __shfl(toff, 0);
     g.E = __shfl(toff, g.n < kWave ? g.n : kWave - 1) - g.e_lo;
     const bool ok = g.n <= dm.n_max && g.E <= dm.emax;
     const int first_src = (ok && lane < g.E) ? talk_src[g.e_lo + lane] : 0;
-    if (x_copy != nullptr) {   // the x half of the [x || c] rows of this graph
-#pragma unroll 1
-      for (int i = 0; i < g.n; ++i) {
-        const float* __restrict__ xs = x_copy + static_cast<size_t>(g.a0 + i) * ld_x;
-        float* __restrict__ xd = c + static_cast<size_t>(g.a0 + i) * ld_c - n_copy;
-        if (x4) {
-#pragma unroll 4
-          for (int k = lane * 4; k < n_copy; k += kWave * 4)
-            *reinterpret_cast<float4*>(xd + k) = *reinterpret_cast<const float4*>(xs + k);
-        } else {
-          for (int k = lane; k < n_copy; k += kWave) xd[k] = xs[k];
-        }
-      }
-    }
     if (!ok) {   // precondition violated: fail loudly
 #pragma unroll 1
       for (int i = 0; i < g.n; ++i)
         for (int ch = lane; ch < M; ch += kWave) c[static_cast<size_t>(g.a0 + i) * ld_c + ch] = NAN;
       continue;
     }
-    stage_rows(v, ld_v, g.a0, g.n, M, P, dm.ldp, lane);
+    store_rows(P, dm.ldp, g.n, M, lane, rv);
     if (!uniform) {
-      stage_rows(s, ld_s, g.a0, g.n, K, P + M, dm.ldp, lane);
-      stage_rows(q, ld_q, g.a0, g.n, K, P + M + K, dm.ldp, lane);
+      store_rows(P + M, dm.ldp, g.n, K, lane, rs);
+      store_rows(P + M + K, dm.ldp, g.n, K, lane, rq);
+    }
+    if (g.n > kRows || M > kWave) {
+      stage_rest(v, ld_v, g.a0, g.n, M, P, dm.ldp, lane);
+      if (!uniform) {
+        stage_rest(s, ld_s, g.a0, g.n, K, P + M, dm.ldp, lane);
+        stage_rest(q, ld_q, g.a0, g.n, K, P + M + K, dm.ldp, lane);
+      }
     }
     if (lane <= g.n) OFF[lane] = toff - g.e_lo;
     wave_sync_lds();
@@ -218,6 +264,14 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_bwd_kern
     g.a0 = graph_off[b];
     g.n = graph_off[b + 1] - g.a0;
     const int toff = lane <= g.n ? talk_off[g.a0 + lane] : 0;
+    if (g.n == 0) continue;
+    float rd[kRows], rv[kRows], rs[kRows], rq[kRows];    // issued before anything waits on toff
+    load_rows(d_c, ld_dc, g.a0, g.n, M, lane, rd);
+    load_rows(v, ld_v, g.a0, g.n, M, lane, rv);
+    if (!uniform) {
+      load_rows(s, ld_s, g.a0, g.n, K, lane, rs);
+      load_rows(q, ld_q, g.a0, g.n, K, lane, rq);
+    }
     g.e_lo = __shfl(toff, 0);
     g.E = __shfl(toff, g.n < kWave ? g.n : kWave - 1) - g.e_lo;
     const bool ok = g.n <= dm.n_max && g.E <= dm.emax;
@@ -229,11 +283,19 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_bwd_kern
         for (int ch = lane; ch < M; ch += kWave) d_v[static_cast<size_t>(g.a0 + i) * ld_dv + ch] = NAN;
       continue;
     }
-    stage_rows(d_c, ld_dc, g.a0, g.n, M, DC, dm.ldm, lane);
-    stage_rows(v, ld_v, g.a0, g.n, M, P, dm.ldp, lane);
+    store_rows(DC, dm.ldm, g.n, M, lane, rd);
+    store_rows(P, dm.ldp, g.n, M, lane, rv);
     if (!uniform) {
-      stage_rows(s, ld_s, g.a0, g.n, K, P + M, dm.ldp, lane);
-      stage_rows(q, ld_q, g.a0, g.n, K, P + M + K, dm.ldp, lane);
+      store_rows(P + M, dm.ldp, g.n, K, lane, rs);
+      store_rows(P + M + K, dm.ldp, g.n, K, lane, rq);
+    }
+    if (g.n > kRows || M > kWave) {
+      stage_rest(d_c, ld_dc, g.a0, g.n, M, DC, dm.ldm, lane);
+      stage_rest(v, ld_v, g.a0, g.n, M, P, dm.ldp, lane);
+      if (!uniform) {
+        stage_rest(s, ld_s, g.a0, g.n, K, P + M, dm.ldp, lane);
+        stage_rest(q, ld_q, g.a0, g.n, K, P + M + K, dm.ldp, lane);
+      }
     }
 #pragma unroll 1
     for (int i = 0; i < g.n; ++i) {
@@ -324,7 +386,7 @@ extern "C" int uavgnn_talk_attn_env_fwd(const float* s, int ld_s, const float* q
   const EnvDims d = env_dims(n_max, M, s ? K : 0);
   const int words = fwd_words(d);
   const int waves = waves_for(words);
-  hipLaunchKernelGGL(talk_attn_env_fwd_kernel, dim3(capped_grid(B, waves, 8192)), dim3(waves * kWave),
+  hipLaunchKernelGGL(talk_attn_env_fwd_kernel, dim3(capped_grid(B, waves, 8192), x_copy ? 2 : 1), dim3(waves * kWave),
                      static_cast<size_t>(words) * waves * sizeof(float), static_cast<hipStream_t>(stream), s, ld_s, q,
                      ld_q, v, ld_v, K, M, talk_off, talk_src, graph_off, B, n_max, scale, c, ld_c, a_save, x_copy,
                      ld_x, n_copy, words);
