@@ -3,13 +3,17 @@
 // Same arithmetic as talk_attn.hip (gnn_agents.py:261-267; uniform mode :130-133,:214-216) for the shape the
 // reference actually produces: dgl.batch of per-environment graphs with n_agents <= 16 whose talk edges never leave
 // their environment (env_wrappers.py:139-154, common.py:45).  The per-destination kernel keeps 7 of 64 lanes busy in
-// its score pass and chains four dependent global loads per destination; here a wavefront stages the projections of
-// its graph's agents in LDS once (coalesced), then lane <-> edge for scores / softmax and lane <-> channel for the
-// aggregation, all out of LDS.  The backward needs NO transpose of the CSC: gradients w.r.t. the sources are
-// accumulated in LDS while walking the graph's edges in CSC order (same summation order as the transposed gather).
+// its score pass and chains four dependent global loads per destination.  Here a wavefront stages the projections of
+// its graph's agents in LDS once, computes scores / softmax with lane <-> edge, scatters the weights into a dense
+// n x n attention matrix A (LDS) and then both directions are tiny dense products with lane <-> channel and the
+// operand rows held in registers:
+//     forward   c[d]   = sum_u A[d][u] v[u]
+//     backward  d_v[u] = sum_d A[d][u] d_c[d],   d_q[d] = sum_u dE[d][u] s[u],   d_s[u] = sum_d dE[d][u] q[d]
+// so the backward needs neither the transposed CSC nor a scratch array, and no loop has an LDS load whose address
+// depends on another LDS load.  Parallel edges add up in A (LDS atomics), as they do in the edge-wise formulation.
 //
 // Preconditions (checked per graph; a violating graph gets NaN outputs instead of silent corruption): agents of a
-// graph <= n_max <= 16, edges of a graph <= n_max^2 (simple graph), sources inside the graph.  Shapes outside
+// graph <= n_max <= 16, edges of a graph <= NMAX^2 (NMAX = 8 or 16), sources inside the graph.  Shapes outside
 // uavgnn_talk_attn_env_supported() (LDS budget) run on the per-destination kernels of talk_attn.hip.
 #include <math.h>
 
@@ -21,31 +25,31 @@ namespace {
 constexpr int kEnvMaxAgents = 16;
 constexpr int kEnvMaxWaves = 4;
 constexpr int kMaxK = 64;
-constexpr int kMaxMJ = 4;   // M <= 256
+constexpr int kMaxM = 256;
 
 struct EnvDims {
-  int n_max, emax, ldp, ldm, ldk;
+  int nmax, emax, ldp, ldm;
 };
 
-__host__ __device__ inline EnvDims env_dims(int n_max, int M, int K) {
+__host__ __device__ inline EnvDims env_dims(int nmax, int M, int K) {
   EnvDims d;
-  d.n_max = n_max;
-  d.emax = n_max * n_max;
+  d.nmax = nmax;
+  d.emax = nmax * nmax;
   d.ldp = (M + 2 * K) | 1;   // odd row strides: rows land in different LDS banks
   d.ldm = M | 1;
-  d.ldk = K | 1;
   return d;
 }
 
-inline int fwd_words(const EnvDims& d) { return d.n_max * d.ldp + (d.n_max + 1) + 4 * d.emax; }
-inline int bwd_words(const EnvDims& d) {
-  return d.n_max * d.ldp + 2 * d.n_max * d.ldm + d.n_max * d.ldk + (d.n_max + 1) + 5 * d.emax;
-}
+// words of LDS per wavefront: P | OFF | SC | AD | SRC | DST        (forward)
+//                             P | DC | OFF | A | DA | AD | DE | SRC | DST   (backward)
+inline int fwd_words(const EnvDims& d) { return d.nmax * d.ldp + (d.nmax + 1) + 4 * d.emax; }
+inline int bwd_words(const EnvDims& d) { return d.nmax * d.ldp + d.nmax * d.ldm + (d.nmax + 1) + 6 * d.emax; }
 inline int waves_for(int words) {
   const int per_block = 64 * 1024 / 4;   // default dynamic-LDS ceiling of a workgroup
   int w = per_block / words;
   return w > kEnvMaxWaves ? kEnvMaxWaves : w;
 }
+inline int pick_nmax(int n_max) { return n_max <= 8 ? 8 : 16; }
 
 struct EnvGraph {
   int a0, n, e_lo, E;
@@ -96,10 +100,33 @@ __device__ __forceinline__ void stage_edges(const EnvGraph& g, int lane, const i
   }
 }
 
+// out[r][ch] = sum_{t < NMAX} W[r, t] * X[t][ch] for r < n, one 64-channel block at a time, X rows in registers
+// (rows >= n are clamped copies multiplied by the zero padding of W).  TRANS: W[r, t] = Wm[t * NMAX + r], else
+// Wm[r * NMAX + t].  The Wm reads are wave-uniform (LDS broadcast) and independent of each other.
+template <int NMAX, bool TRANS>
+__device__ __forceinline__ void dense_rows(const float* __restrict__ Wm, const float* __restrict__ X, int ldx, int n,
+                                           int M, int lane, float* __restrict__ out, int ld_out) {
+#pragma unroll 1
+  for (int c0 = 0; c0 < M; c0 += kWave) {
+    const int ch = c0 + lane, chc = ch < M ? ch : M - 1;
+    float x[NMAX];
+#pragma unroll
+    for (int t = 0; t < NMAX; ++t) x[t] = X[(t < n ? t : n - 1) * ldx + chc];
+#pragma unroll 2
+    for (int r = 0; r < n; ++r) {
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < NMAX; ++t) acc = fmaf(TRANS ? Wm[t * NMAX + r] : Wm[r * NMAX + t], x[t], acc);
+      if (ch < M) out[static_cast<size_t>(r) * ld_out + ch] = acc;
+    }
+  }
+}
+
+template <int NMAX>
 __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_fwd_kernel(
     const float* __restrict__ s, int ld_s, const float* __restrict__ q, int ld_q, const float* __restrict__ v,
     int ld_v, int K, int M, const int32_t* __restrict__ talk_off, const int32_t* __restrict__ talk_src,
-    const int32_t* __restrict__ graph_off, int B, int n_max, float scale, float* __restrict__ c, int ld_c,
+    const int32_t* __restrict__ graph_off, int B, float scale, float* __restrict__ c, int ld_c,
     float* __restrict__ a_save, const float* __restrict__ x_copy, int ld_x, int n_copy, int words_per_wave) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & (kWave - 1);
@@ -107,36 +134,32 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_fwd_kern
   const int waves = blockDim.x >> 6;
   const bool uniform = (s == nullptr);
   if (uniform) K = 0;
-  const EnvDims dm = env_dims(n_max, M, K);
+  const EnvDims dm = env_dims(NMAX, M, K);
   float* __restrict__ P = lds + wave * words_per_wave;
-  int* __restrict__ OFF = reinterpret_cast<int*>(P + dm.n_max * dm.ldp);
-  float* __restrict__ SC = reinterpret_cast<float*>(OFF + dm.n_max + 1);
-  float* __restrict__ AW = SC + dm.emax;
-  int* __restrict__ SRC = reinterpret_cast<int*>(AW + dm.emax);
+  int* __restrict__ OFF = reinterpret_cast<int*>(P + NMAX * dm.ldp);
+  float* __restrict__ SC = reinterpret_cast<float*>(OFF + NMAX + 1);
+  float* __restrict__ AD = SC + dm.emax;
+  int* __restrict__ SRC = reinterpret_cast<int*>(AD + dm.emax);
   int* __restrict__ DST = SRC + dm.emax;
-  const bool x4 = x_copy != nullptr && (n_copy % 4 == 0) && (ld_x % 4 == 0) && (ld_c % 4 == 0) &&
-                  ((reinterpret_cast<uintptr_t>(x_copy) & 15) == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0);
 
   // blockIdx.y == 1: copy-only workgroups.  The x half of the [x || c] rows is a pure stream (2/3 of this kernel's
   // bytes); giving it its own wavefronts lets it overlap the LDS phases of the attention wavefronts, which otherwise
   // all load, compute and store in lock step (there is exactly one wavefront per graph in flight).
   if (blockIdx.y == 1) {
+    const bool x4 = (n_copy % 4 == 0) && (ld_x % 4 == 0) && (ld_c % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(x_copy) & 15) == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0);
     for (int b = blockIdx.x * waves + wave; b < B; b += gridDim.x * waves) {
-      EnvGraph g;
-      g.a0 = graph_off[b];
-      g.n = graph_off[b + 1] - g.a0;
-      if (x_copy != nullptr) {
+      const int a0 = graph_off[b], n = graph_off[b + 1] - a0;
 #pragma unroll 1
-        for (int i = 0; i < g.n; ++i) {
-          const float* __restrict__ xs = x_copy + static_cast<size_t>(g.a0 + i) * ld_x;
-          float* __restrict__ xd = c + static_cast<size_t>(g.a0 + i) * ld_c - n_copy;
-          if (x4) {
+      for (int i = 0; i < n; ++i) {
+        const float* __restrict__ xs = x_copy + static_cast<size_t>(a0 + i) * ld_x;
+        float* __restrict__ xd = c + static_cast<size_t>(a0 + i) * ld_c - n_copy;
+        if (x4) {
 #pragma unroll 4
-            for (int k = lane * 4; k < n_copy; k += kWave * 4)
-              *reinterpret_cast<float4*>(xd + k) = *reinterpret_cast<const float4*>(xs + k);
-          } else {
-            for (int k = lane; k < n_copy; k += kWave) xd[k] = xs[k];
-          }
+          for (int k = lane * 4; k < n_copy; k += kWave * 4)
+            *reinterpret_cast<float4*>(xd + k) = *reinterpret_cast<const float4*>(xs + k);
+        } else {
+          for (int k = lane; k < n_copy; k += kWave) xd[k] = xs[k];
         }
       }
     }
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_fwd_kern
     }
     g.e_lo = __shfl(toff, 0);
     g.E = __shfl(toff, g.n < kWave ? g.n : kWave - 1) - g.e_lo;
-    const bool ok = g.n <= dm.n_max && g.E <= dm.emax;
+    const bool ok = g.n <= NMAX && g.E <= dm.emax;
     const int first_src = (ok && lane < g.E) ? talk_src[g.e_lo + lane] : 0;
     if (!ok) {   // precondition violated: fail loudly
 #pragma unroll 1
@@ -177,6 +200,7 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_fwd_kern
         stage_rest(q, ld_q, g.a0, g.n, K, P + M + K, dm.ldp, lane);
       }
     }
+    for (int i = lane; i < dm.emax; i += kWave) AD[i] = 0.f;
     if (lane <= g.n) OFF[lane] = toff - g.e_lo;
     wave_sync_lds();
     stage_edges(g, lane, talk_src, first_src, OFF, SRC, DST);
@@ -207,38 +231,20 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_fwd_kern
         for (int j = j0; j < j1; ++j) den += expf(SC[j] - m);
         a = expf(SC[e] - m) / den;
       }
-      AW[e] = a;
       a_save[g.e_lo + e] = a;
+      atomicAdd(&AD[d * NMAX + SRC[e]], a);   // LDS; parallel edges add up
     }
     wave_sync_lds();
-#pragma unroll 1
-    for (int d = 0; d < g.n; ++d) {
-      float acc[kMaxMJ] = {0.f, 0.f, 0.f, 0.f};
-      const int j1 = OFF[d + 1];
-#pragma unroll 2
-      for (int j = OFF[d]; j < j1; ++j) {
-        const float aj = AW[j];
-        const float* __restrict__ vr = P + SRC[j] * dm.ldp;
-#pragma unroll
-        for (int jj = 0; jj < kMaxMJ; ++jj) {
-          const int ch = lane + kWave * jj;
-          if (ch < M) acc[jj] = fmaf(aj, vr[ch], acc[jj]);
-        }
-      }
-#pragma unroll
-      for (int jj = 0; jj < kMaxMJ; ++jj) {
-        const int ch = lane + kWave * jj;
-        if (ch < M) c[static_cast<size_t>(g.a0 + d) * ld_c + ch] = acc[jj];
-      }
-    }
+    dense_rows<NMAX, false>(AD, P, dm.ldp, g.n, M, lane, c + static_cast<size_t>(g.a0) * ld_c, ld_c);
     wave_sync_lds();   // the next graph restages the same LDS
   }
 }
 
+template <int NMAX>
 __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_bwd_kernel(
     const float* __restrict__ s, int ld_s, const float* __restrict__ q, int ld_q, const float* __restrict__ v,
     int ld_v, int K, int M, const int32_t* __restrict__ talk_off, const int32_t* __restrict__ talk_src,
-    const int32_t* __restrict__ graph_off, int B, int n_max, float scale, const float* __restrict__ a_save,
+    const int32_t* __restrict__ graph_off, int B, float scale, const float* __restrict__ a_save,
     const float* __restrict__ d_c, int ld_dc, float* __restrict__ d_s, int ld_ds, float* __restrict__ d_q, int ld_dq,
     float* __restrict__ d_v, int ld_dv, int words_per_wave) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -247,15 +253,14 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_bwd_kern
   const int waves = blockDim.x >> 6;
   const bool uniform = (s == nullptr);
   if (uniform) K = 0;
-  const EnvDims dm = env_dims(n_max, M, K);
+  const EnvDims dm = env_dims(NMAX, M, K);
   float* __restrict__ P = lds + wave * words_per_wave;
-  float* __restrict__ DC = P + dm.n_max * dm.ldp;
-  float* __restrict__ DV = DC + dm.n_max * dm.ldm;
-  float* __restrict__ DS = DV + dm.n_max * dm.ldm;
-  int* __restrict__ OFF = reinterpret_cast<int*>(DS + dm.n_max * dm.ldk);
-  float* __restrict__ A = reinterpret_cast<float*>(OFF + dm.n_max + 1);
+  float* __restrict__ DC = P + NMAX * dm.ldp;
+  int* __restrict__ OFF = reinterpret_cast<int*>(DC + NMAX * dm.ldm);
+  float* __restrict__ A = reinterpret_cast<float*>(OFF + NMAX + 1);
   float* __restrict__ DA = A + dm.emax;
-  float* __restrict__ DE = DA + dm.emax;
+  float* __restrict__ AD = DA + dm.emax;
+  float* __restrict__ DE = AD + dm.emax;
   int* __restrict__ SRC = reinterpret_cast<int*>(DE + dm.emax);
   int* __restrict__ DST = SRC + dm.emax;
 
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_bwd_kern
     }
     g.e_lo = __shfl(toff, 0);
     g.E = __shfl(toff, g.n < kWave ? g.n : kWave - 1) - g.e_lo;
-    const bool ok = g.n <= dm.n_max && g.E <= dm.emax;
+    const bool ok = g.n <= NMAX && g.E <= dm.emax;
     const int first_src = (ok && lane < g.E) ? talk_src[g.e_lo + lane] : 0;
     const float first_a = (ok && lane < g.E) ? a_save[g.e_lo + lane] : 0.f;
     if (!ok) {
@@ -297,19 +302,18 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_bwd_kern
         stage_rest(q, ld_q, g.a0, g.n, K, P + M + K, dm.ldp, lane);
       }
     }
-#pragma unroll 1
-    for (int i = 0; i < g.n; ++i) {
-      for (int ch = lane; ch < M; ch += kWave) DV[i * dm.ldm + ch] = 0.f;
-      if (!uniform && lane < K) DS[i * dm.ldk + lane] = 0.f;
+    for (int i = lane; i < dm.emax; i += kWave) {
+      AD[i] = 0.f;
+      DE[i] = 0.f;
     }
     for (int e = lane; e < g.E; e += kWave) A[e] = e < kWave ? first_a : a_save[g.e_lo + e];
     if (lane <= g.n) OFF[lane] = toff - g.e_lo;
     wave_sync_lds();
     stage_edges(g, lane, talk_src, first_src, OFF, SRC, DST);
     wave_sync_lds();
-    if (!uniform) {
-      // da_e = <d_c[dst_e], v[src_e]>
-      for (int e = lane; e < g.E; e += kWave) {
+    for (int e = lane; e < g.E; e += kWave) {
+      atomicAdd(&AD[DST[e] * NMAX + SRC[e]], A[e]);
+      if (!uniform) {   // da_e = <d_c[dst_e], v[src_e]>
         const float* __restrict__ dr = DC + DST[e] * dm.ldm;
         const float* __restrict__ vr = P + SRC[e] * dm.ldp;
         float acc = 0.f;
@@ -317,48 +321,39 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_bwd_kern
         for (int ch = 0; ch < M; ++ch) acc = fmaf(dr[ch], vr[ch], acc);
         DA[e] = acc;
       }
-      wave_sync_lds();
-      // de_e = a_e (da_e - sum_{e' into dst} a_e' da_e') scale
+    }
+    wave_sync_lds();
+    if (!uniform) {
+      // dE[dst][src] += a_e (da_e - sum_{e' into dst} a_e' da_e') scale
       for (int e = lane; e < g.E; e += kWave) {
         const int d = DST[e];
         const int j1 = OFF[d + 1];
         float T = 0.f;
 #pragma unroll 2
         for (int j = OFF[d]; j < j1; ++j) T = fmaf(A[j], DA[j], T);
-        DE[e] = A[e] * (DA[e] - T) * scale;
+        atomicAdd(&DE[d * NMAX + SRC[e]], A[e] * (DA[e] - T) * scale);
       }
       wave_sync_lds();
-      // d_q[d] = sum_{e into d} de_e s[src_e]
-      for (int idx = lane; idx < g.n * K; idx += kWave) {
-        const int d = idx / K, k = idx - d * K;
-        const int j1 = OFF[d + 1];
-        float acc = 0.f;
-#pragma unroll 2
-        for (int j = OFF[d]; j < j1; ++j) acc = fmaf(DE[j], P[SRC[j] * dm.ldp + M + k], acc);
-        d_q[static_cast<size_t>(g.a0 + d) * ld_dq + k] = acc;
-      }
-    }
-    // d_v[u] = sum_{e out of u} a_e d_c[dst_e],  d_s[u] = sum_{e out of u} de_e q[dst_e]: the graph's edges in CSC
-    // order, accumulators in LDS (a lane owns its channel column: no conflicts, in-order LDS traffic per wave)
-#pragma unroll 2
-    for (int e = 0; e < g.E; ++e) {
-      const int u = SRC[e], d = DST[e];
-      const float a = A[e];
+      // d_q[r][k] = sum_u dE[r][u] s[u][k],  d_s[r][k] = sum_d dE[d][r] q[d][k]:  lane = (row r, key column k)
+      const int rpp = kWave / K;                      // rows per pass (K <= 64)
+      const int lr = lane / K, k = lane - lr * K;
+      for (int r0 = 0; r0 < g.n; r0 += rpp) {
+        const int r = r0 + lr, rc = r < g.n ? r : g.n - 1;
+        float acc_q = 0.f, acc_s = 0.f;
 #pragma unroll
-      for (int jj = 0; jj < kMaxMJ; ++jj) {
-        const int ch = lane + kWave * jj;
-        if (ch < M) DV[u * dm.ldm + ch] = fmaf(a, DC[d * dm.ldm + ch], DV[u * dm.ldm + ch]);
+        for (int t = 0; t < NMAX; ++t) {
+          const float* __restrict__ row = P + (t < g.n ? t : g.n - 1) * dm.ldp + M;
+          acc_q = fmaf(DE[rc * NMAX + t], row[k], acc_q);
+          acc_s = fmaf(DE[t * NMAX + rc], row[K + k], acc_s);
+        }
+        if (lr < rpp && r < g.n) {
+          d_q[static_cast<size_t>(g.a0 + r) * ld_dq + k] = acc_q;
+          if (d_s != nullptr) d_s[static_cast<size_t>(g.a0 + r) * ld_ds + k] = acc_s;
+        }
       }
-      if (!uniform && lane < K)
-        DS[u * dm.ldk + lane] = fmaf(DE[e], P[d * dm.ldp + M + K + lane], DS[u * dm.ldk + lane]);
     }
-    wave_sync_lds();
-#pragma unroll 1
-    for (int i = 0; i < g.n; ++i) {
-      for (int ch = lane; ch < M; ch += kWave)
-        d_v[static_cast<size_t>(g.a0 + i) * ld_dv + ch] = DV[i * dm.ldm + ch];
-      if (!uniform && d_s != nullptr && lane < K) d_s[static_cast<size_t>(g.a0 + i) * ld_ds + lane] = DS[i * dm.ldk + lane];
-    }
+    // d_v[u] = sum_d A[d][u] d_c[d]
+    dense_rows<NMAX, true>(AD, DC, dm.ldm, g.n, M, lane, d_v + static_cast<size_t>(g.a0) * ld_dv, ld_dv);
     wave_sync_lds();
   }
 }
@@ -369,8 +364,8 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_bwd_kern
 using namespace uavgnn;
 
 extern "C" int uavgnn_talk_attn_env_supported(int n_max, int M, int K) {
-  if (n_max < 1 || n_max > kEnvMaxAgents || M < 1 || M > kWave * kMaxMJ || K < 0 || K > kMaxK) return 0;
-  const EnvDims d = env_dims(n_max, M, K);
+  if (n_max < 1 || n_max > kEnvMaxAgents || M < 1 || M > kMaxM || K < 0 || K > kMaxK) return 0;
+  const EnvDims d = env_dims(pick_nmax(n_max), M, K);
   return waves_for(bwd_words(d)) >= 1 ? 1 : 0;
 }
 
@@ -383,13 +378,19 @@ extern "C" int uavgnn_talk_attn_env_fwd(const float* s, int ld_s, const float* q
     return UAVGNN_EINVAL;
   if (!uavgnn_talk_attn_env_supported(n_max, M, s ? K : 0) || (s && K < 1)) return UAVGNN_EUNSUPPORTED;
   if (B == 0) return 0;
-  const EnvDims d = env_dims(n_max, M, s ? K : 0);
+  const int nmax = pick_nmax(n_max);
+  const EnvDims d = env_dims(nmax, M, s ? K : 0);
   const int words = fwd_words(d);
   const int waves = waves_for(words);
-  hipLaunchKernelGGL(talk_attn_env_fwd_kernel, dim3(capped_grid(B, waves, 8192), x_copy ? 2 : 1), dim3(waves * kWave),
-                     static_cast<size_t>(words) * waves * sizeof(float), static_cast<hipStream_t>(stream), s, ld_s, q,
-                     ld_q, v, ld_v, K, M, talk_off, talk_src, graph_off, B, n_max, scale, c, ld_c, a_save, x_copy,
-                     ld_x, n_copy, words);
+  const dim3 grid(capped_grid(B, waves, 8192), x_copy ? 2 : 1), block(waves * kWave);
+  const size_t lds_bytes = static_cast<size_t>(words) * waves * sizeof(float);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nmax == 8)
+    hipLaunchKernelGGL(talk_attn_env_fwd_kernel<8>, grid, block, lds_bytes, st, s, ld_s, q, ld_q, v, ld_v, K, M, talk_off,
+                       talk_src, graph_off, B, scale, c, ld_c, a_save, x_copy, ld_x, n_copy, words);
+  else
+    hipLaunchKernelGGL(talk_attn_env_fwd_kernel<16>, grid, block, lds_bytes, st, s, ld_s, q, ld_q, v, ld_v, K, M,
+                       talk_off, talk_src, graph_off, B, scale, c, ld_c, a_save, x_copy, ld_x, n_copy, words);
   return launch_status();
 }
 
@@ -403,12 +404,19 @@ extern "C" int uavgnn_talk_attn_env_bwd(const float* s, int ld_s, const float* q
   if (s && (!d_s || !d_q)) return UAVGNN_EINVAL;
   if (!uavgnn_talk_attn_env_supported(n_max, M, s ? K : 0) || (s && K < 1)) return UAVGNN_EUNSUPPORTED;
   if (B == 0) return 0;
-  const EnvDims d = env_dims(n_max, M, s ? K : 0);
+  const int nmax = pick_nmax(n_max);
+  const EnvDims d = env_dims(nmax, M, s ? K : 0);
   const int words = bwd_words(d);
   const int waves = waves_for(words);
-  hipLaunchKernelGGL(talk_attn_env_bwd_kernel, dim3(capped_grid(B, waves, 8192)), dim3(waves * kWave),
-                     static_cast<size_t>(words) * waves * sizeof(float), static_cast<hipStream_t>(stream), s, ld_s, q,
-                     ld_q, v, ld_v, K, M, talk_off, talk_src, graph_off, B, n_max, scale, a_save, d_c, ld_dc, d_s,
-                     ld_ds, d_q, ld_dq, d_v, ld_dv, words);
+  const dim3 grid(capped_grid(B, waves, 8192)), block(waves * kWave);
+  const size_t lds_bytes = static_cast<size_t>(words) * waves * sizeof(float);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nmax == 8)
+    hipLaunchKernelGGL(talk_attn_env_bwd_kernel<8>, grid, block, lds_bytes, st, s, ld_s, q, ld_q, v, ld_v, K, M, talk_off,
+                       talk_src, graph_off, B, scale, a_save, d_c, ld_dc, d_s, ld_ds, d_q, ld_dq, d_v, ld_dv, words);
+  else
+    hipLaunchKernelGGL(talk_attn_env_bwd_kernel<16>, grid, block, lds_bytes, st, s, ld_s, q, ld_q, v, ld_v, K, M,
+                       talk_off, talk_src, graph_off, B, scale, a_save, d_c, ld_dc, d_s, ld_ds, d_q, ld_dq, d_v, ld_dv,
+                       words);
   return launch_status();
 }
