@@ -30,7 +30,8 @@ th.manual_seed(0)
 hb = synth_batch_gpu(a.B, 8, 80, a.dist, dev, gen)
 FS = 4 if a.rel == "seen" else 2
 x_src, off = hb.relation_segments(a.rel)
-ORDER = hb.relation_order(a.rel).data_ptr()
+_o = hb.relation_order(a.rel)
+ORDER = _o.data_ptr() if _o is not None else None
 x_a = hb.agent_feat()
 N, E = x_a.shape[0], x_src.shape[0]
 conv = GATv2Conv((FS, 2), 64, 4).to(dev)

@@ -51,7 +51,8 @@ def main():
         N = x_a.shape[0]
         for et, FS in (("seen", 4), ("near", 2)):
             x_src, off = hb.relation_segments(et)
-            ORDER = hb.relation_order(et).data_ptr() if a.order else None
+            _o = hb.relation_order(et)
+            ORDER = _o.data_ptr() if (a.order and _o is not None) else None
             E = x_src.shape[0]
             conv = GATv2Conv((FS, 2), 64, 4).to(dev)
             with th.no_grad():

@@ -287,14 +287,15 @@ class GnnAgent(nn.Module):
         launch per relation over (T+1) N_a destinations instead of T+1 small ones."""
         return self.enc(g, None).view(g.num_nodes("agent"), -1)
 
-    def step(self, g: HeteroBatch, x, h):
-        """Communication block (or plain GRU) + Q head on pre-encoded observations x."""
+    def step(self, g: HeteroBatch, x, h, dx_out=None):
+        """Communication block (or plain GRU) + Q head on pre-encoded observations x.  dx_out: optional slice of a
+        ``ops.time_split`` gradient buffer that the fused step's backward writes d x into."""
         n = x.shape[0]
         if h.shape[0] != n:
             h = h.expand(n, -1)
         h = h.contiguous()
         if self._comm_protocol == "tarmac" and self.f_comm._n_rounds == 1 and isinstance(self.f_out, nn.Linear):
-            return self._tarmac_step(g, x, h)          # headline configuration: one fused autograd node per step
+            return self._tarmac_step(g, x, h, dx_out)  # headline configuration: one fused autograd node per step
         if self._comm_protocol is not None:
             h = self.f_comm(g["talk"], x, h)
         else:
@@ -303,15 +304,15 @@ class GnnAgent(nn.Module):
             return self.f_out(h), h
         return ops.linear(h, self.f_out.weight, self.f_out.bias), h
 
-    def _tarmac_step(self, g, x, h):
+    def _tarmac_step(self, g, x, h, dx_out=None):
         comm = self.f_comm
         needs = th.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if needs and ops.GRAD_SINK is None:
             # no sink: the stacked projection weight must be part of the autograd graph
             Wp = th.cat((comm.f_val.weight, comm.f_sign.weight, comm.f_que.weight), 0)
             bp = th.cat((comm.f_val.bias, comm.f_sign.bias, comm.f_que.bias), 0)
-            return ops.tarmac_step(x, h, g, comm, self.f_out, stacked=(Wp, bp))
-        return ops.tarmac_step(x, h, g, comm, self.f_out)
+            return ops.tarmac_step(x, h, g, comm, self.f_out, stacked=(Wp, bp), dx_out=dx_out)
+        return ops.tarmac_step(x, h, g, comm, self.f_out, dx_out=dx_out)
 
     def forward(self, g: HeteroBatch, h):
         return self.step(g, self.encode(g), h)

@@ -148,15 +148,16 @@ class MultiAgentQLearner:
             x_pol = self.policy_net.encode(obs_all)
             with th.no_grad():
                 x_tgt = self.target_net.encode(batch.get("obs_all_next") or obs_all.slice_agents(N, (T + 1) * N))
-            xs = x_pol.view(T + 1, N, -1).unbind(0)     # unbind: its backward is ONE stack, not T+1 padded adds
+            # per-step views + the slices of ONE gradient buffer the steps' backward passes write into (no stack)
+            xs, slots = ops.time_split(x_pol, T + 1)
             xt = x_tgt.view(T, N, -1)
             for t in range(T):
-                logits, h = self.policy_net.step(obs[t], xs[t], h)
+                logits, h = self.policy_net.step(obs[t], xs[t], h, slots[t])
                 agent_out.append(logits)
                 with th.no_grad():
                     nxt, h_targ = self.target_net.step(obs[t + 1], xt[t], h_targ)
                     target_out.append(nxt)
-            logits, h = self.policy_net.step(obs[T], xs[T], h)
+            logits, h = self.policy_net.step(obs[T], xs[T], h, slots[T])
             agent_out.append(logits)
         else:
             for t in range(T):

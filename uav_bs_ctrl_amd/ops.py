@@ -429,6 +429,42 @@ def _add_grad_cols(p, g, start):
     p.grad[start:start + g.shape[0]].add_(g)
 
 
+class _TimeSplit(th.autograd.Function):
+    """x_all [T1 * N, H] -> T1 per-step views, with a gradient buffer the steps' backward passes write INTO.
+
+    ``unbind`` would make autograd stack the T1 step gradients at the end (1.7 GB of copies for C3, T = 50); here the
+    [T1, N, H] buffer is allocated up front, ``slots[t]`` (its t-th slice) is handed to the consumer of x_t (the fused
+    recurrent step writes d x_t with ``out=``) and the backward of the split returns the buffer as it is when every
+    incoming gradient is its own slice - otherwise it falls back to copying the strays in."""
+
+    @staticmethod
+    def forward(ctx, x_all, T1, holder):
+        N = x_all.shape[0] // T1
+        buf = th.empty((T1, N, x_all.shape[1]), dtype=x_all.dtype, device=x_all.device)
+        holder.append(buf)
+        ctx.buf = buf
+        return tuple(x_all.detach().view(T1, N, -1).unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        buf = ctx.buf
+        for t, g in enumerate(grads):
+            if g is None:
+                buf[t].zero_()
+            elif g.data_ptr() != buf[t].data_ptr() or g.stride() != buf[t].stride():
+                buf[t].copy_(g)
+        return buf.view(-1, buf.shape[2]), None, None
+
+
+def time_split(x_all, T1):
+    """(xs, slots): per-step views of the time-batched encoder output and the slices of its gradient buffer."""
+    holder = []
+    xs = _TimeSplit.apply(x_all, T1, holder)
+    if not holder:      # no grad mode
+        return xs, [None] * T1
+    return xs, list(holder[0].unbind(0))
+
+
 class _TarmacStep(th.autograd.Function):
     """q, h' = head(GRU([x || c], h)), c = targeted attention over `talk` of the projections of [x || stopgrad(h)]
     (gnn_agents.py:248-271 with n_rounds = 1, then :56).  Forward: 5 vendor GEMMs + K3b + K4, the projection of the two
@@ -437,7 +473,7 @@ class _TarmacStep(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, h, Wp, bp, W_ih, b_ih, W_hh, b_hh, W_out, b_out, M, K, talk_off, talk_src, t_off, t_dst, t_pos,
-                split, env=None):
+                split, env=None, dx_out=None):
         L.require_gpu(x, h, Wp, W_ih, talk_off)
         N, H = x.shape
         x, h = L.f32c(x), L.f32c(h)
@@ -458,7 +494,7 @@ class _TarmacStep(th.autograd.Function):
         L.check(rc, "uavgnn_gru_gates_fwd")
         q = th.addmm(b_out, h2, W_out.t())
         ctx.dims = (M, K)
-        ctx.split, ctx.env = split, env
+        ctx.split, ctx.env, ctx.dx_out = split, env, dx_out
         ctx.save_for_backward(x, h, proj, inp, gi, gh, h2, a_save, Wp, W_ih, W_hh, W_out, talk_off, talk_src, t_off,
                               t_dst, t_pos)
         return q, h2
@@ -471,7 +507,14 @@ class _TarmacStep(th.autograd.Function):
         N, H = x.shape
         sink = GRAD_SINK
         dq = L.f32c(dq) if dq is not None else th.zeros((N, W_out.shape[0]), dtype=th.float32, device=x.device)
-        dh2_tot = th.mm(dq, W_out) if dh2 is None else th.addmm(dh2, dq, W_out)
+        if dh2 is None:
+            dh2_tot = th.mm(dq, W_out)
+        elif sink is not None and dh2.is_contiguous():
+            # inside the learner's BPTT the incoming d h' is the buffer the next step's backward produced for exactly
+            # this purpose: accumulate in place instead of copying 33 MB into a fresh output first
+            dh2_tot = dh2.addmm_(dq, W_out)
+        else:
+            dh2_tot = th.addmm(dh2, dq, W_out)
         d_gi, d_gh, dh = th.empty_like(gi), th.empty_like(gh), th.empty_like(h)
         with KERNEL_TIMER.span("gru_gates_bwd"):
             rc = L.lib().uavgnn_gru_gates_bwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), dh2_tot.data_ptr(), N, H,
@@ -485,7 +528,11 @@ class _TarmacStep(th.autograd.Function):
                          K, M, talk_off, talk_src, (t_off, t_dst, t_pos), N, 1.0 / K, a_save, d_inp.data_ptr() + 4 * H,
                          H + M, d_proj.data_ptr() + 4 * M, ld, d_proj.data_ptr() + 4 * (M + K), ld, d_proj.data_ptr(),
                          ld)
-        dx = th.addmm(d_inp[:, :H], d_proj, Wp[:, :H])                    # h enters the projections stop-gradded
+        dx = ctx.dx_out                                                    # slice of the time-split gradient buffer
+        if dx is not None:
+            th.addmm(d_inp[:, :H], d_proj, Wp[:, :H], out=dx)
+        else:
+            dx = th.addmm(d_inp[:, :H], d_proj, Wp[:, :H])                # h enters the projections stop-gradded
         if sink is not None:
             split = ctx.split
             sink.weight(("Wp_x", id(Wp)), d_proj, x, lambda g: split("Wp", g, 0))
@@ -505,10 +552,10 @@ class _TarmacStep(th.autograd.Function):
             gWih, gbih = _wgrad(d_gi, inp), _colsum(d_gi)
             gWhh, gbhh = _wgrad(d_gh, h), th.cat((gbih[:2 * H], _colsum(d_gh[:, 2 * H:])))
             gWo, gbo = _wgrad(dq, h2), _colsum(dq)
-        return (dx, dh, gWp, gbp, gWih, gbih, gWhh, gbhh, gWo, gbo) + (None,) * 9
+        return (dx, dh, gWp, gbp, gWih, gbih, gWhh, gbhh, gWo, gbo) + (None,) * 10
 
 
-def tarmac_step(x, h, g, comm, f_out, stacked=None):
+def tarmac_step(x, h, g, comm, f_out, stacked=None, dx_out=None):
     """comm: the TarMAC module (f_val / f_sign / f_que / f_udt), f_out: nn.Linear head.  Returns (q, h').
     ``stacked`` = (Wp, bp) built WITH autograd history when no GRAD_SINK will collect the weight gradients."""
     M, K = comm._msg_size, comm._key_size
@@ -547,7 +594,7 @@ def tarmac_step(x, h, g, comm, f_out, stacked=None):
             _add_grad(params[name], grad)
 
     return _TarmacStep.apply(x, h, Wp, bp, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, f_out.weight,
-                             f_out.bias, M, K, off, src, t_off, t_dst, t_pos, split, env)
+                             f_out.bias, M, K, off, src, t_off, t_dst, t_pos, split, env, dx_out)
 
 
 class _DiscComm(th.autograd.Function):
