@@ -147,6 +147,13 @@ int uavgnn_talk_degrees(const float* d_u2u, int n, int B, float r_comm, int32_t*
 int uavgnn_talk_compact(const float* d_u2u, int n, int B, float r_comm, const int32_t* talk_off,
                         const int32_t* env_base, int32_t* talk_src, int32_t* talk_eid, uavgnn_stream_t stream);
 
+/* ---- bias gradients ---------------------------------------------------------------------------------------------
+ * acc[s, :] += column sums of the rows [s*R, (s+1)*R) of x[N, C] (row stride ld, unit column stride), R = ceil(N / S).
+ * The db = dY.sum(0) of the Linear / GRUCell backward (gnn_agents.py:43-46,:237-246 under learner.py:157), accumulated
+ * across the BPTT steps in the caller's acc[S, C]; the caller folds the S partials once per update.  Deterministic.
+ */
+int uavgnn_colsum_acc(const float* x, long long ld, int N, int C, float* acc, int S, uavgnn_stream_t stream);
+
 /* ---- K3b, per-graph formulation ---------------------------------------------------------------------------------
  * Same contract and arithmetic as uavgnn_talk_attn_fwd / _bwd for a batch of B SMALL graphs (what dgl.batch of
  * per-environment graphs gives: common.py:45, env_wrappers.py:139-154): graph_off[B+1] = agent-node boundaries, every

@@ -748,3 +748,30 @@ def test_agent_paths_per_graph_and_per_destination_agree():
     assert_close(res[0][2], res[1][2], 1e-5, "d_h", floor=1e-7)
     for k in res[0][1]:
         assert_close(res[0][1][k], res[1][1][k], 1e-5, k, floor=1e-7)
+
+
+@pytest.mark.parametrize("N,C,S,view", [(32768, 768, 256, None), (32768, 768, 256, (512, 768)), (32768, 96, 256, None),
+                                        (32768, 9, 256, None), (1000, 7, 8, None), (77, 300, 4, None),
+                                        (4096, 66, 16, (1, 64)), (130, 9, 64, None), (5, 1, 8, None)])
+def test_colsum_accumulate_kernel(N, C, S, view):
+    """uavgnn_colsum_acc: acc[S, C] += row-blocked column sums; wide (float4 and scalar), narrow and strided layouts,
+    ragged last block, repeated accumulation, bit-reproducible."""
+    from uav_bs_ctrl_amd import _lib as L
+    gen = th.Generator(device="cuda").manual_seed(N + C)
+    x = th.randn(N, C, device="cuda", generator=gen)
+    xv = x if view is None else x[:, view[0]:view[1]]
+    Cv = xv.shape[1]
+    outs = []
+    for rep in range(2):
+        acc = th.zeros(S, Cv, device="cuda")
+        for _ in range(3):
+            L.check(L.lib().uavgnn_colsum_acc(xv.data_ptr(), xv.stride(0), N, Cv, acc.data_ptr(), S, L.stream()), "colsum")
+        outs.append(acc)
+    assert th.equal(outs[0], outs[1])
+    R = (N + S - 1) // S
+    ref = th.zeros(S, Cv, dtype=th.float64)
+    xd = xv.double().cpu()
+    for s_ in range(S):
+        ref[s_] = 3 * xd[s_ * R:(s_ + 1) * R].sum(0)
+    assert_close(outs[0], ref, 1e-5, "partials", floor=1e-5)
+    assert_close(outs[0].sum(0), 3 * xd.sum(0), 1e-5, "column sums", floor=1e-4)

@@ -1,0 +1,117 @@
+// Bias gradients of the recurrent step: column sums of a [N, C] gradient matrix, accumulated IN PLACE into row-blocked
+// partials acc[S, C] (acc[s] += sum of the rows of block s).
+//
+// Replaces `db = dY.sum(0)` of the nn.Linear / nn.GRUCell backward reached from
+// /root/reference/algos/madrqn/learner.py:157 (loss.backward()) for the layers at gnn_agents.py:43-46,:237-246, once per
+// BPTT step.  The caller keeps one acc per parameter for the whole backward and folds the S partials once per update
+// (ops.WeightGradSink), so a step costs one streaming pass per matrix - no temporary, no separate `+=` launch.  A
+// (row block, column tile) cell has exactly one owner workgroup and a fixed summation order: deterministic.
+#include "common.h"
+
+namespace uavgnn {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / kWave;
+
+// C >= 64 (or strided narrow matrices).  grid (S, column tiles of 64 * V); wave w of the block takes rows
+// lo + w, lo + w + 4, ...; a lane owns V consecutive columns.
+template <int V>
+__global__ __launch_bounds__(kThreads) void colsum_wide_kernel(const float* __restrict__ x, long long ld, int N, int C,
+                                                               int rows_per_block, float* __restrict__ acc) {
+  __shared__ float part[kWaves][kWave * V];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = blockIdx.x;
+  const int c = blockIdx.y * (kWave * V) + lane * V;
+  const int lo = s * rows_per_block, hi = min(N, lo + rows_per_block);
+  float a[V];
+#pragma unroll
+  for (int t = 0; t < V; ++t) a[t] = 0.f;
+  if (c < C) {
+    const float* __restrict__ p = x + c;
+    int r = lo + wave;
+    for (; r + 3 * kWaves < hi; r += 4 * kWaves) {   // four rows in flight per lane
+      float v[4][V];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* __restrict__ q = p + static_cast<long long>(r + u * kWaves) * ld;
+        if constexpr (V == 4) {
+          const float4 t4 = *reinterpret_cast<const float4*>(q);
+          v[u][0] = t4.x; v[u][1] = t4.y; v[u][2] = t4.z; v[u][3] = t4.w;
+        } else {
+          v[u][0] = *q;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < V; ++t) a[t] += v[u][t];
+    }
+    for (; r < hi; r += kWaves) {
+      const float* __restrict__ q = p + static_cast<long long>(r) * ld;
+#pragma unroll
+      for (int t = 0; t < V; ++t) a[t] += q[t];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < V; ++t) part[wave][lane * V + t] = a[t];
+  __syncthreads();
+  if (wave == 0 && c < C) {
+#pragma unroll
+    for (int t = 0; t < V; ++t) {
+      float tot = part[0][lane * V + t];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) tot += part[w][lane * V + t];
+      acc[static_cast<size_t>(s) * C + c + t] += tot;
+    }
+  }
+}
+
+// C < 64, rows contiguous (ld == C): the block's rows are one flat run of rows * C floats; thread t < L (L = the largest
+// multiple of C <= 256) walks it with stride L, so it always sees column t % C.
+__global__ __launch_bounds__(kThreads) void colsum_narrow_kernel(const float* __restrict__ x, int N, int C,
+                                                                 int rows_per_block, float* __restrict__ acc) {
+  __shared__ float part[kThreads];
+  const int t = threadIdx.x;
+  const int L = (kThreads / C) * C;
+  const int s = blockIdx.x;
+  const int lo = s * rows_per_block, hi = min(N, lo + rows_per_block);
+  const float* __restrict__ p = x + static_cast<size_t>(lo) * C;
+  const int total = (hi > lo ? hi - lo : 0) * C;
+  float a = 0.f;
+  if (t < L)
+    for (int i = t; i < total; i += L) a += p[i];
+  part[t] = a;
+  __syncthreads();
+  if (t < C) {
+    float tot = 0.f;
+    for (int g = t; g < L; g += C) tot += part[g];
+    acc[static_cast<size_t>(s) * C + t] += tot;
+  }
+}
+
+}  // namespace
+}  // namespace uavgnn
+
+using namespace uavgnn;
+
+extern "C" int uavgnn_colsum_acc(const float* x, long long ld, int N, int C, float* acc, int S,
+                                 uavgnn_stream_t stream) {
+  if (N < 0 || C < 1 || S < 1 || !acc || (N > 0 && !x) || ld < C) return UAVGNN_EINVAL;
+  if (N == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rows = (N + S - 1) / S;
+  if (C < kWave && ld == C) {
+    hipLaunchKernelGGL(colsum_narrow_kernel, dim3(S), dim3(kThreads), 0, st, x, N, C, rows, acc);
+    return launch_status();
+  }
+  const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (v4)
+    hipLaunchKernelGGL(colsum_wide_kernel<4>, dim3(S, (C + 4 * kWave - 1) / (4 * kWave)), dim3(kThreads), 0, st, x, ld,
+                       N, C, rows, acc);
+  else
+    hipLaunchKernelGGL(colsum_wide_kernel<1>, dim3(S, (C + kWave - 1) / kWave), dim3(kThreads), 0, st, x, ld, N, C,
+                       rows, acc);
+  return launch_status();
+}
