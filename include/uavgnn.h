@@ -58,9 +58,15 @@ int uavgnn_gatv2_fwd(const float* x_src, int E, int F_src, const float* x_dst, i
                      const float* W_r, const float* b_r, int nh, int D, float slope, float* out, int ld_out,
                      float* attn_save, uavgnn_stream_t stream);
 
-/* Same contract, always the plain-VALU kernel (every (nh, D) instantiation; uavgnn_gatv2_fwd prefers the fp32-MFMA
- * kernel when nh == 4 and D in {16,32,64}).  Kept exported as the in-library A/B reference of the MFMA kernel. */
+/* uavgnn_gatv2_fwd picks the kernel: nh == 4, D in {16,32,64}: the low-degree kernel for two-feature relations whose
+ * mean in-degree is <= 8 (`near`), else the fp32-MFMA row-tile kernel; any other (nh, D): the plain-VALU kernel.
+ * Same contract, fixed kernel, exported as in-library A/B references: _valu = always the VALU kernel,
+ * _mfma = the MFMA kernel whenever it is instantiated (never the low-degree kernel). */
 int uavgnn_gatv2_fwd_valu(const float* x_src, int E, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
+                          const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
+                          const float* W_r, const float* b_r, int nh, int D, float slope, float* out, int ld_out,
+                          float* attn_save, uavgnn_stream_t stream);
+int uavgnn_gatv2_fwd_mfma(const float* x_src, int E, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
                           const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
                           const float* W_r, const float* b_r, int nh, int D, float slope, float* out, int ld_out,
                           float* attn_save, uavgnn_stream_t stream);

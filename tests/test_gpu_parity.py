@@ -775,3 +775,45 @@ def test_colsum_accumulate_kernel(N, C, S, view):
         ref[s_] = 3 * xd[s_ * R:(s_ + 1) * R].sum(0)
     assert_close(outs[0], ref, 1e-5, "partials", floor=1e-5)
     assert_close(outs[0].sum(0), 3 * xd.sum(0), 1e-5, "column sums", floor=1e-4)
+
+
+@pytest.mark.parametrize("D,maxdeg,N", [(64, 7, 4000), (64, 3, 257), (32, 8, 1000), (16, 7, 300), (64, 20, 3000)])
+def test_low_degree_k1_kernel_agrees_with_mfma_and_valu(D, maxdeg, N):
+    """K1 forward on a two-feature relation: the low-degree kernel (what uavgnn_gatv2_fwd dispatches to when the mean
+    in-degree is <= 8) against the MFMA and the VALU kernels of the same library - outputs and saved attention weights;
+    in-degrees above 8 exercise its multi-pass online softmax; zero-degree destinations included."""
+    from uav_bs_ctrl_amd import _lib as L
+    from uav_bs_ctrl_amd.agents.gnn_agents import GATv2Conv
+    gen = th.Generator().manual_seed(D + maxdeg)
+    deg = th.randint(0, maxdeg + 1, (N,), generator=gen)
+    if maxdeg > 8:                      # keep the mean at or below 8 so that the dispatcher picks the low-degree kernel
+        deg[th.rand(N, generator=gen) < 0.5] = 1
+    deg[0], deg[1] = maxdeg, 0
+    off = th.zeros(N + 1, dtype=th.int32)
+    off[1:] = th.cumsum(deg, 0)
+    E = int(off[-1])
+    assert E <= 8 * N
+    x_src = (th.rand(E, 2, generator=gen) * 2 - 1).cuda()
+    x_a = th.rand(N, 2, generator=gen).cuda()
+    off = off.cuda()
+    th.manual_seed(1)
+    conv = GATv2Conv((2, 2), D, 4).cuda()
+    p = [t.detach().contiguous() for t in (conv.fc_src.weight, conv.fc_src.bias + 0.1, conv.fc_dst.weight,
+                                           conv.fc_dst.bias - 0.05, conv.attn, conv.res_fc.weight, conv.res_fc.bias)]
+    H = 4 * D
+    outs = []
+    for fn in (L.lib().uavgnn_gatv2_fwd, L.lib().uavgnn_gatv2_fwd_mfma, L.lib().uavgnn_gatv2_fwd_valu):
+        out = th.full((N, H), float("nan"), device="cuda")
+        a_save = th.full((max(E, 1), 4), float("nan"), device="cuda")
+        rc = fn(x_src.data_ptr(), E, 2, x_a.data_ptr(), 2, off.data_ptr(), None, N, *[t.data_ptr() for t in p], 4, D, 0.2,
+                out.data_ptr(), H, a_save.data_ptr(), L.stream())
+        assert rc == 0
+        outs.append((out, a_save))
+    for i, nm in ((1, "mfma"), (2, "valu")):
+        assert_close(outs[0][0], outs[i][0], 2e-6, f"low-degree vs {nm}: out")
+        assert_close(outs[0][1], outs[i][1], 2e-6, f"low-degree vs {nm}: attention weights", floor=1e-7)
+    # inference mode (no attention weights saved) gives the same rows
+    out2 = th.empty(N, H, device="cuda")
+    rc = L.lib().uavgnn_gatv2_fwd(x_src.data_ptr(), E, 2, x_a.data_ptr(), 2, off.data_ptr(), None, N,
+                                  *[t.data_ptr() for t in p], 4, D, 0.2, out2.data_ptr(), H, None, L.stream())
+    assert rc == 0 and th.equal(out2, outs[0][0])

@@ -77,13 +77,15 @@ def main():
             erra = float((a_save - a_save2).abs().max())
             bytes_inf = 4 * FS * E + N * (8 + 4 + 1024)
             flops = E * (3360 if FS == 4 else 2320) + N * 3584
-            for name, fn, sv in (("mfma", lib.uavgnn_gatv2_fwd, None), ("valu", lib.uavgnn_gatv2_fwd_valu, None),
-                                 ("mfma+save", lib.uavgnn_gatv2_fwd, a_save.data_ptr())):
+            # auto = what uavgnn_gatv2_fwd dispatches to (low-degree kernel for `near`, MFMA row tiles for `seen`)
+            for name, fn, sv in (("auto", lib.uavgnn_gatv2_fwd, None), ("mfma", lib.uavgnn_gatv2_fwd_mfma, None),
+                                 ("valu", lib.uavgnn_gatv2_fwd_valu, None),
+                                 ("auto+save", lib.uavgnn_gatv2_fwd, a_save.data_ptr())):
                 ms = time_ms(lambda: call(fn, out, sv), a.reps)
                 by = bytes_inf + (16 * E if sv else 0)
                 print(f"fwd {dist:5s} {et:4s} F={FS} {name:10s}      {ms:8.4f} {by / ms / 1e6:9.1f} "
                       f"{by / ms / 1e6 / 80:6.2f} {flops / ms / 1e9:8.2f} {flops / ms / 1e9 / 1.573:6.2f}")
-            print(f"    max rel diff mfma vs valu: out {err:.2e}  attn {erra:.2e}")
+            print(f"    max rel diff auto vs valu: out {err:.2e}  attn {erra:.2e}")
             # backward
             d_out = th.randn(N, a.ld, device=dev)
             g = [th.empty_like(t) for t in p]

@@ -27,6 +27,8 @@ SIGNATURES = {
                                   _c_fp, _c_fp, _c_int, _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_st]),
     "uavgnn_gatv2_fwd_valu": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                        _c_fp, _c_fp, _c_int, _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_st]),
+    "uavgnn_gatv2_fwd_mfma": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
+                                       _c_fp, _c_fp, _c_int, _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_st]),
     "uavgnn_gatv2_bwd_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
     "uavgnn_gatv2_bwd": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                   _c_int, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,

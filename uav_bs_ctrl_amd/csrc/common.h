@@ -55,4 +55,11 @@ int gatv2_fwd_mfma(int F_src, int nh, int D, const float* x_src, int E, const fl
                    const float* W_r, const float* b_r, float slope, float* out, int ld_out, float* a_save,
                    hipStream_t st);
 
+// gatv2_small.hip: K1 forward for two-feature relations with mean in-degree <= 8 (nh = 4, D in {16,32,64}); returns
+// UAVGNN_EUNSUPPORTED otherwise.
+int gatv2_fwd_small(int F_src, int nh, int D, const float* x_src, int E, const float* x_dst, const int32_t* seg_off,
+                    const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d,
+                    const float* b_d, const float* attn, const float* W_r, const float* b_r, float slope, float* out,
+                    int ld_out, float* a_save, hipStream_t st);
+
 }  // namespace uavgnn

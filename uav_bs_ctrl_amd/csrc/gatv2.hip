@@ -594,7 +594,9 @@ using namespace uavgnn;
   UAVGNN_DISPATCH(4, 1, 64, CALL)    \
   UAVGNN_DISPATCH(2, 1, 64, CALL)
 
-static int gatv2_fwd_checked(bool allow_mfma, const float* x_src, int E, int F_src, const float* x_dst, int F_dst,
+// variant: 0 = VALU kernel only, 1 = MFMA (row-tile) kernel when instantiated, 2 = automatic (low-degree kernel for
+// two-feature relations with mean in-degree <= 8, else MFMA, else VALU)
+static int gatv2_fwd_checked(int variant, const float* x_src, int E, int F_src, const float* x_dst, int F_dst,
                              const int32_t* seg_off, const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d,
                              const float* b_d, const float* attn, const float* W_r, const float* b_r, int nh, int D,
                              float slope, float* out, int ld_out, float* attn_save, uavgnn_stream_t stream) {
@@ -604,7 +606,12 @@ static int gatv2_fwd_checked(bool allow_mfma, const float* x_src, int E, int F_s
   if (F_dst != 2) return UAVGNN_EUNSUPPORTED;
   if (N == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (allow_mfma) {
+  if (variant == 2) {
+    const int rc = gatv2_fwd_small(F_src, nh, D, x_src, E, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r,
+                                   slope, out, ld_out, attn_save, st);
+    if (rc != UAVGNN_EUNSUPPORTED) return rc;
+  }
+  if (variant >= 1) {
     const int rc = gatv2_fwd_mfma(F_src, nh, D, x_src, E, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, slope,
                                   out, ld_out, attn_save, st);
     if (rc != UAVGNN_EUNSUPPORTED) return rc;
@@ -618,7 +625,16 @@ extern "C" int uavgnn_gatv2_fwd(const float* x_src, int E, int F_src, const floa
                                 const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d,
                                 const float* attn, const float* W_r, const float* b_r, int nh, int D, float slope,
                                 float* out, int ld_out, float* attn_save, uavgnn_stream_t stream) {
-  return gatv2_fwd_checked(true, x_src, E, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
+  return gatv2_fwd_checked(2, x_src, E, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
+                           slope, out, ld_out, attn_save, stream);
+}
+
+extern "C" int uavgnn_gatv2_fwd_mfma(const float* x_src, int E, int F_src, const float* x_dst, int F_dst,
+                                     const int32_t* seg_off, const int32_t* dst_order, int N, const float* W_s, const float* b_s,
+                                     const float* W_d, const float* b_d, const float* attn, const float* W_r,
+                                     const float* b_r, int nh, int D, float slope, float* out, int ld_out,
+                                     float* attn_save, uavgnn_stream_t stream) {
+  return gatv2_fwd_checked(1, x_src, E, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
                            slope, out, ld_out, attn_save, stream);
 }
 
@@ -627,7 +643,7 @@ extern "C" int uavgnn_gatv2_fwd_valu(const float* x_src, int E, int F_src, const
                                      const float* W_d, const float* b_d, const float* attn, const float* W_r,
                                      const float* b_r, int nh, int D, float slope, float* out, int ld_out,
                                      float* attn_save, uavgnn_stream_t stream) {
-  return gatv2_fwd_checked(false, x_src, E, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
+  return gatv2_fwd_checked(0, x_src, E, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, W_r, b_r, nh, D,
                            slope, out, ld_out, attn_save, stream);
 }
 
