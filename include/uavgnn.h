@@ -153,6 +153,14 @@ int uavgnn_talk_degrees(const float* d_u2u, int n, int B, float r_comm, int32_t*
 int uavgnn_talk_compact(const float* d_u2u, int n, int B, float r_comm, const int32_t* talk_off,
                         const int32_t* env_base, int32_t* talk_src, int32_t* talk_eid, uavgnn_stream_t stream);
 
+/* ---- rollout: epsilon-greedy selection --------------------------------------------------------------------------
+ * acts[a] = u_team[a / n_agents] <= eps ? min(floor(u_agent[a] * A), A - 1) : argmax_j q[a, j]   (first maximum).
+ * MultiAgentQLearner.act, learner.py:73-80: one exploration draw per team of n_agents consecutive agents; u_team
+ * [N / n_agents] and u_agent [N] are uniforms in [0, 1) supplied by the caller.  acts: int64 [N].
+ */
+int uavgnn_eps_greedy(const float* q, int ld_q, int N, int A, int n_agents, const float* u_team, const float* u_agent,
+                      float eps, long long* acts, uavgnn_stream_t stream);
+
 /* ---- bias gradients ---------------------------------------------------------------------------------------------
  * acc[s, :] += column sums of the rows [s*R, (s+1)*R) of x[N, C] (row stride ld, unit column stride), R = ceil(N / S).
  * The db = dY.sum(0) of the Linear / GRUCell backward (gnn_agents.py:43-46,:237-246 under learner.py:157), accumulated

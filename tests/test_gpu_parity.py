@@ -535,7 +535,17 @@ def test_degree_order_is_the_stable_descending_sort(n, maxdeg, seed):
     off[1:] = th.cumsum(deg, 0)
     E = int(off[-1])
     g = HeteroBatch.from_arrays(x_a=th.zeros(n, 2), x_gt=th.zeros(E, 4), seen_off=off, device="cuda")
-    order = g.relation_order("seen").cpu().long()
+    if n <= 2048:
+        assert g.relation_order("seen") is None      # no more destinations than persistent wavefronts: no order built
+    from uav_bs_ctrl_amd import _lib as L
+    offd = off.cuda()
+    od = th.empty(n, dtype=th.int32, device="cuda")
+    nb = L.lib().uavgnn_degree_order_workspace_bytes(n)
+    ws = th.empty(nb // 4, dtype=th.int32, device="cuda")
+    L.check(L.lib().uavgnn_degree_order(offd.data_ptr(), n, od.data_ptr(), ws.data_ptr(), nb, L.stream()), "order")
+    order = od.cpu().long()
+    if n > 2048:
+        assert th.equal(g.relation_order("seen").cpu().long(), order)
     assert sorted(order.tolist()) == list(range(n))
     ref = th.sort(deg.clamp(max=255), descending=True, stable=True)[1]
     assert th.equal(order, ref)
@@ -817,3 +827,22 @@ def test_low_degree_k1_kernel_agrees_with_mfma_and_valu(D, maxdeg, N):
     rc = L.lib().uavgnn_gatv2_fwd(x_src.data_ptr(), E, 2, x_a.data_ptr(), 2, off.data_ptr(), None, N,
                                   *[t.data_ptr() for t in p], 4, D, 0.2, out2.data_ptr(), H, None, L.stream())
     assert rc == 0 and th.equal(out2, outs[0][0])
+
+
+@pytest.mark.parametrize("B,n,A,eps", [(4096, 8, 9, 0.05), (3, 5, 4, 1.0), (7, 1, 2, 0.0), (1000, 4, 13, 0.5)])
+def test_eps_greedy_selection_kernel(B, n, A, eps):
+    """uavgnn_eps_greedy == argmax / one draw per team / uniform random action, on the same uniforms."""
+    from uav_bs_ctrl_amd import _lib as L
+    gen = th.Generator(device="cuda").manual_seed(B + A)
+    N = B * n
+    q = th.randn(N, A + 3, device="cuda", generator=gen)[:, :A]           # row stride A + 3
+    u = th.rand(B + N, device="cuda", generator=gen)
+    acts = th.empty(N, dtype=th.int64, device="cuda")
+    L.check(L.lib().uavgnn_eps_greedy(q.data_ptr(), q.stride(0), N, A, n, u.data_ptr(), u.data_ptr() + 4 * B, float(eps),
+                                      acts.data_ptr(), L.stream()), "eps_greedy")
+    explore = (u[:B] <= eps).repeat_interleave(n)
+    rand = (u[B:] * A).long().clamp(max=A - 1)
+    ref = th.where(explore, rand, q.argmax(1))
+    assert th.equal(acts, ref)
+    if eps == 0.0:
+        assert th.equal(acts, q.argmax(1))

@@ -158,8 +158,13 @@ def test_slice_agents_views_and_relation_order():
         assert th.equal(off, offr) and th.equal(xs, xr)
         assert xs.data_ptr() >= big.relation_segments(et)[0].data_ptr()      # a view, not a copy
     assert th.equal(mid.agent_feat(), gs[1].agent_feat()) and not mid.has_relation("talk")
-    order = big.relation_order("seen")
-    _, off = big.relation_segments("seen")
-    deg = (off[1:] - off[:-1])[order.long()]
-    assert sorted(order.tolist()) == list(range(12)) and bool((deg[1:] <= deg[:-1]).all())
+    assert big.relation_order("seen") is None          # fewer destinations than persistent wavefronts: no order needed
+    N = 3000
+    deg = th.as_tensor(rng.integers(0, 40, N))
+    off = th.zeros(N + 1, dtype=th.int32)
+    off[1:] = th.cumsum(deg, 0)
+    wide = HeteroBatch.from_arrays(x_a=th.zeros(N, 2), x_gt=th.zeros(int(off[-1]), 4), seen_off=off)
+    order = wide.relation_order("seen")
+    d = deg[order.long()]
+    assert sorted(order.tolist()) == list(range(N)) and bool((d[1:] <= d[:-1]).all())
     assert big.graph_off.tolist() == [0, 4, 8, 12]

@@ -373,7 +373,9 @@ __global__ __launch_bounds__(kThreads) void csc_transpose_env_kernel(const int32
 
 inline int order_blocks(int N) {
   const int b = (N + kOrderThreads - 1) / kOrderThreads;
-  return b < 1 ? 1 : (b > kOrderMaxBlocks ? kOrderMaxBlocks : b);
+  // up to 65536 destinations: 16 blocks -> 4096 (bin, block) cells = ONE scan tile, i.e. three launches in total
+  const int cap = N <= 65536 ? kScanTile / kOrderBins : kOrderMaxBlocks;
+  return b < 1 ? 1 : (b > cap ? cap : b);
 }
 
 }  // namespace

@@ -246,8 +246,9 @@ class HeteroBatch:
         key = "ord:" + etype
         if key not in self._cache:
             off = self._rels[self._canon(etype)].off
-            if self.hints.get("max_deg:" + etype, 1 << 30) <= 16:
-                # every destination costs one 16-edge row tile whatever its degree: nothing to balance
+            if self.hints.get("max_deg:" + etype, 1 << 30) <= 16 or off.numel() - 1 <= 2048:
+                # every destination costs one 16-edge row tile whatever its degree, or there are no more destinations
+                # than persistent wavefronts (one each): nothing to balance
                 self._cache[key] = None
             elif off.is_cuda:     # HIP counting sort (csrc/build_graph.hip): 3 launches, no host sync
                 from . import _lib as L

@@ -23,6 +23,7 @@ import torch as th
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import _lib as L
 from . import ops
 from .agents import REGISTRY as agent_REGISTRY
 
@@ -122,8 +123,19 @@ class MultiAgentQLearner:
         team, as in learner.py:75-78."""
         obs, h = obs.to(self.device), h.to(self.device)
         logits, h = self.policy_net(obs, h)
+        N = logits.shape[0]
+        B = N // self.n_agents
+        if logits.is_cuda:
+            # one uniform per team + one per agent in ONE generator call, then argmax / compare / select in one HIP
+            # launch (csrc/act_select.hip) instead of six tiny ones
+            u = th.rand(B + N, device=self.device, generator=self._gen)
+            acts = th.empty(N, dtype=th.int64, device=self.device)
+            logits = logits if logits.stride(1) == 1 else logits.contiguous()
+            L.check(L.lib().uavgnn_eps_greedy(logits.data_ptr(), logits.stride(0), N, self.n_actions, self.n_agents,
+                                              u.data_ptr(), u.data_ptr() + 4 * B, float(eps_thres), acts.data_ptr(),
+                                              L.stream()), "uavgnn_eps_greedy")
+            return acts, h
         greedy = logits.argmax(1)
-        B = greedy.shape[0] // self.n_agents
         explore = th.rand(B, device=self.device, generator=self._gen) <= eps_thres
         rand = th.randint(self.n_actions, greedy.shape, device=self.device, generator=self._gen)
         acts = th.where(explore.repeat_interleave(self.n_agents), rand, greedy)
