@@ -168,3 +168,14 @@ def test_slice_agents_views_and_relation_order():
     d = deg[order.long()]
     assert sorted(order.tolist()) == list(range(N)) and bool((d[1:] <= d[:-1]).all())
     assert big.graph_off.tolist() == [0, 4, 8, 12]
+
+
+def test_tuned_gemm_selection_is_inert_without_a_gpu():
+    """The recorded vendor-GEMM solutions ship with the package; selecting them is a no-op on a CPU-only host."""
+    import os
+    from uav_bs_ctrl_amd import tuned
+    assert os.path.exists(tuned.CSV)
+    head = open(tuned.CSV).read().splitlines()
+    assert head[0].startswith("Validator,PT_VERSION") and any(l.startswith("Gemm") for l in head)
+    if not th.cuda.is_available():
+        assert tuned.enable_tuned_gemms() is False

@@ -85,6 +85,10 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
         _LIB = handle
+        # first use of the library = first HIP op of this process, on its own device: the moment to select the recorded
+        # vendor-GEMM solutions for the dense half of the path (selection only, see uav_bs_ctrl_amd/tuned)
+        from .tuned import enable_tuned_gemms
+        enable_tuned_gemms()
     return _LIB
 
 
