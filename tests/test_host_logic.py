@@ -179,3 +179,49 @@ def test_tuned_gemm_selection_is_inert_without_a_gpu():
     assert head[0].startswith("Validator,PT_VERSION") and any(l.startswith("Gemm") for l in head)
     if not th.cuda.is_available():
         assert tuned.enable_tuned_gemms() is False
+
+
+def test_time_split_gradient_buffer_matches_unbind():
+    """ops.time_split: per-step views whose gradients land in one buffer.  A consumer that writes into its slot
+    (as the fused step does) and one that returns a fresh tensor (any other step) must both give unbind's gradient."""
+    from uav_bs_ctrl_amd import ops
+
+    class _WritesIntoSlot(th.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, slot):
+            ctx.save_for_backward(w)
+            ctx.slot = slot
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            (w,) = ctx.saved_tensors
+            th.mul(g, w, out=ctx.slot)
+            return ctx.slot, None, None
+
+    T1, N, H = 5, 7, 3
+    gen = th.Generator().manual_seed(0)
+    x_all = th.randn(T1 * N, H, generator=gen, requires_grad=True)
+    w = th.randn(T1, N, H, generator=gen)
+    ref = th.autograd.grad(sum(((xt * w[t]) ** 2).sum() for t, xt in enumerate(x_all.view(T1, N, H).unbind(0))), x_all)[0]
+    xs, slots = ops.time_split(x_all, T1)
+    assert all(s is not None for s in slots)
+    terms = []
+    for t in range(T1):
+        y = _WritesIntoSlot.apply(xs[t], w[t], slots[t]) if t % 2 == 0 else xs[t] * w[t]     # slot writer / stray
+        terms.append((y ** 2).sum())
+    got = th.autograd.grad(sum(terms[:-1]), x_all)[0]        # the last step is unused: its slice must come back zero
+    ref2 = ref.clone().view(T1, N, H)
+    ref2[-1] = 0
+    assert th.allclose(got, ref2.view(-1, H), rtol=1e-6, atol=1e-7)
+    with th.no_grad():
+        xs2, slots2 = ops.time_split(x_all, T1)
+    assert slots2 == [None] * T1 and th.equal(xs2[2], x_all.view(T1, N, H)[2])
+
+
+def test_row_blocked_column_sums():
+    from uav_bs_ctrl_amd import ops
+    assert ops._row_blocks(32768) == 256 and ops._row_blocks(96) == 2 and ops._row_blocks(7) == 1
+    x = th.randn(640, 11, generator=th.Generator().manual_seed(1))
+    assert th.allclose(ops._colsum(x), x.sum(0), rtol=1e-5, atol=1e-5)
+    assert th.allclose(ops._colsum(x[:, 3:9]), x[:, 3:9].sum(0), rtol=1e-5, atol=1e-5)

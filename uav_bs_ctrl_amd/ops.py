@@ -462,10 +462,10 @@ class _TimeSplit(th.autograd.Function):
 
 def time_split(x_all, T1):
     """(xs, slots): per-step views of the time-batched encoder output and the slices of its gradient buffer."""
+    if not (th.is_grad_enabled() and x_all.requires_grad):
+        return x_all.view(T1, x_all.shape[0] // T1, -1).unbind(0), [None] * T1
     holder = []
     xs = _TimeSplit.apply(x_all, T1, holder)
-    if not holder:      # no grad mode
-        return xs, [None] * T1
     return xs, list(holder[0].unbind(0))
 
 
