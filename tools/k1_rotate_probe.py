@@ -71,3 +71,25 @@ for rep in range(20):
 th.cuda.synchronize()
 t = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
 print(f"after 6 GEMMs     median {t[len(t) // 2]:7.1f} us  min {t[0]:7.1f}")
+
+
+def bracket(pre, n=40):
+    ev = []
+    for i in range(n):
+        pre(i)
+        a, b = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        a.record()
+        k1(i % 16)
+        b.record()
+        ev.append((a, b))
+    th.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+    return t[len(t) // 2], t[0]
+
+
+tiny = th.zeros(4, device=dev)
+big = th.empty(64 << 20, device=dev)      # 256 MB
+print("event-bracketed K1 after: nothing          median %7.1f  min %7.1f" % bracket(lambda i: None))
+print("event-bracketed K1 after: a 16-byte fill    median %7.1f  min %7.1f" % bracket(lambda i: tiny.fill_(1.0)))
+print("event-bracketed K1 after: a 256 MB fill     median %7.1f  min %7.1f" % bracket(lambda i: big.fill_(1.0)))
+print("event-bracketed K1 after: one GEMM          median %7.1f  min %7.1f" % bracket(lambda i: th.mm(A, B.t())))

@@ -66,7 +66,7 @@ class _HeteroGATv2(th.autograd.Function):
     PER_REL = 10
 
     @staticmethod
-    def forward(ctx, x_dst, nh, *rel_args):
+    def forward(ctx, x_dst, nh, train, *rel_args):
         R = len(rel_args) // _HeteroGATv2.PER_REL
         L.require_gpu(x_dst, *[t for t in rel_args if isinstance(t, th.Tensor)])
         x_dst = L.f32c(x_dst)
@@ -83,7 +83,9 @@ class _HeteroGATv2(th.autograd.Function):
                 raise L.UavGnnError("hetero_gatv2: inconsistent relation shapes")
             p = [L.f32c(t.detach()) for t in (W_s, b_s, W_d, b_d, attn, W_r)]
             b_r_c = None if b_r is None else L.f32c(b_r.detach())
-            need = any(ctx.needs_input_grad[2 + i * 10 + 3: 2 + i * 10 + 10])
+            # ctx.needs_input_grad stays True for parameters under torch.no_grad(): `train` (grad mode at the call site)
+            # decides whether the attention weights are saved - a rollout / target-network forward must not pay for them
+            need = train and any(ctx.needs_input_grad[3 + i * 10 + 3: 3 + i * 10 + 10])
             a_save = th.empty((max(x_src.shape[0], 1), nh), dtype=th.float32, device=x_dst.device) if need else None
             with KERNEL_TIMER.span(f"gatv2_fwd[F={FS}]", (x_src.shape[0], N, int(need))):
                 rc = L.lib().uavgnn_gatv2_fwd(L.ptr(x_src), x_src.shape[0], FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off),
@@ -106,7 +108,7 @@ class _HeteroGATv2(th.autograd.Function):
         R = len(ctx.meta)
         N, dev = x_dst.shape[0], x_dst.device
         d_out = L.f32c(d_out)
-        grads = [None, None]
+        grads = [None, None, None]
         for i, (FS, need, has_br, has_ord) in enumerate(ctx.meta):
             x_src, seg_off, order, W_s, b_s, W_d, b_d, attn, W_r, a_save = saved[1 + i * 10: 1 + (i + 1) * 10]
             if not need or N == 0:
@@ -135,7 +137,7 @@ def hetero_gatv2(x_dst, nh, relations):
     for x_src, seg_off, order, conv in relations:
         flat += [x_src, seg_off, order, conv.attn, conv.fc_src.weight, conv.fc_src.bias, conv.fc_dst.weight,
                  conv.fc_dst.bias, conv.res_fc.weight, conv.res_fc.bias]
-    return _HeteroGATv2.apply(x_dst, nh, *flat)
+    return _HeteroGATv2.apply(x_dst, nh, th.is_grad_enabled(), *flat)
 
 
 def _talk_transpose_if_needed(g, *tensors):
