@@ -211,8 +211,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
-    from uav_bs_ctrl_amd import ops
+    from uav_bs_ctrl_amd import enable_tuned_gemms, ops
     from uav_bs_ctrl_amd.learner import MultiAgentQLearner, params_checksum
+    tuned = enable_tuned_gemms()    # recorded vendor-GEMM solutions (selection only; opt-in, process-wide)
 
     th.manual_seed(0)
     env_info = dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=9, n_agents=a.n, episode_limit=a.T)

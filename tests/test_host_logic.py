@@ -225,3 +225,112 @@ def test_row_blocked_column_sums():
     x = th.randn(640, 11, generator=th.Generator().manual_seed(1))
     assert th.allclose(ops._colsum(x), x.sum(0), rtol=1e-5, atol=1e-5)
     assert th.allclose(ops._colsum(x[:, 3:9]), x[:, 3:9].sum(0), rtol=1e-5, atol=1e-5)
+
+
+def _reference_style_env_graph(obs, d, r_comm):
+    """The reference's construction spelled with this package's dgl-like calls (env_wrappers.py:65-89,:122-154)."""
+    n = len(obs)
+    locs = []
+    for o in obs:
+        gi, ui = o["gt"][:, 0] == 1, o["ubs"][:, 0] == 1
+        g = heterograph({("gt", "seen", "agent"): (np.arange(gi.sum()), np.zeros(gi.sum(), dtype=np.int64)),
+                         ("ubs", "near", "agent"): (np.arange(ui.sum()), np.zeros(ui.sum(), dtype=np.int64)),
+                         ("agent", "talk", "agent"): ([], [])},
+                        num_nodes_dict={"gt": gi.sum(), "ubs": ui.sum(), "agent": 1})
+        g.ndata["feat"] = {"gt": th.as_tensor(o["gt"][gi, 1:]), "ubs": th.as_tensor(o["ubs"][ui, 1:]),
+                           "agent": th.as_tensor(o["agent"]).unsqueeze(0)}
+        locs.append(g)
+    u, v = [], []
+    for i in range(n):
+        for j in range(n):
+            if d[i, j] <= r_comm:
+                u.append(i), v.append(j)
+    comm = heterograph({("gt", "seen", "agent"): ([], []), ("ubs", "near", "agent"): ([], []),
+                        ("agent", "talk", "agent"): (u, v)}, num_nodes_dict={"gt": 0, "ubs": 0, "agent": n})
+    return merge([batch(locs), comm])
+
+
+def test_merge_takes_graph_boundaries_from_the_talk_holder():
+    """dgl.merge([dgl.batch(per-agent graphs), comm_graph]) must yield ONE graph of n agents - the
+    per-agent boundaries [0,1,..,n] of the observation operand do not delimit the talk relation."""
+    rng = np.random.default_rng(4)
+    n = 5
+    g = _reference_style_env_graph(_obs(rng, n, 9), np.zeros((n, n)), 1.0)
+    assert g.graph_off.tolist() == [0, n] and g.hints["max_graph_agents"] == n
+    fast = from_obs_dicts(_obs(np.random.default_rng(4), n, 9), np.zeros((n, n)), 1.0)
+    assert fast.graph_off.tolist() == g.graph_off.tolist() and fast.hints["max_graph_agents"] == n
+    b = batch([g, g, g])
+    assert b.graph_off.tolist() == [0, n, 2 * n, 3 * n] and b.hints["max_graph_agents"] == n
+    # every talk source lies inside the graph of its destination
+    off, src = b.talk_csc()
+    dst = th.repeat_interleave(th.arange(3 * n), (off[1:] - off[:-1]).long())
+    assert th.equal(src.long() // n, dst // n)
+
+
+def test_fused_projection_follows_data_inplace_polyak():
+    """the reference's polyak update is ``p_targ.data.mul_() / .data.add_()`` (learner.py:165-166),
+    which bumps no version counter; the stacked projection weight of the fused TarMAC step must see it."""
+    pol = GnnAgent(dict(agent=2, ubs=2, gt=4), 9, _args())
+    tgt = GnnAgent(dict(agent=2, ubs=2, gt=4), 9, _args())
+    tgt.load_state_dict(pol.state_dict())
+    W0 = tgt.f_comm.fused_projection()[0].clone()
+    with th.no_grad():
+        for p in pol.parameters():
+            p.add_(1.0)
+    for p, p_targ in zip(pol.parameters(), tgt.parameters()):          # the reference's loop, verbatim
+        p_targ.data.mul_(0.9)
+        p_targ.data.add_((1 - 0.9) * p.data)
+    W1, b1 = tgt.f_comm.fused_projection()
+    c = tgt.f_comm
+    assert th.equal(W1, th.cat((c.f_val.weight, c.f_sign.weight, c.f_que.weight), 0))
+    assert th.equal(b1, th.cat((c.f_val.bias, c.f_sign.bias, c.f_que.bias), 0))
+    assert float((W1 - (W0 + 0.1)).abs().max()) < 1e-6
+    c.f_que.weight.data = c.f_que.weight.data.clone() * 2.0             # storage REPLACED: caught by the pointer check
+    assert th.equal(c.fused_projection()[0][-c.f_que.weight.shape[0]:], c.f_que.weight)
+    sd = {k: v.clone() for k, v in pol.state_dict().items()}
+    tgt.load_state_dict(sd)
+    assert th.equal(tgt.f_comm.fused_projection()[0][:c.f_val.weight.shape[0]], pol.f_comm.f_val.weight)
+
+
+def test_weight_grad_sink_keeps_partials_when_the_chunk_count_changes():
+    """a change of N (hence of the row-chunk count S) between two accumulations must not drop the
+    gradient accumulated so far."""
+    from uav_bs_ctrl_amd.ops import WeightGradSink
+    gen = th.Generator().manual_seed(0)
+    sink, got = WeightGradSink(), []
+    parts = []
+    for n in (4096, 8192, 4096, 100):
+        dy, x = th.randn(n, 6, generator=gen), th.randn(n, 5, generator=gen)
+        parts.append(dy.t() @ x)
+        sink.weight("W", dy, x, lambda g: got.append(g))
+    assert len({k[1] for k in sink.slots}) == 3
+    sink.flush()
+    assert th.allclose(sum(got), sum(parts), rtol=1e-4, atol=1e-3)
+
+
+def test_checkpoint_carries_the_lr_scheduler_like_the_reference(tmp_path):
+    """learner.py:50-56,:183-184,:198-199: anneal_lr (default True in madrqn/config.py:36) adds a LambdaLR
+    max(0.4, 1 - epoch/100) and its state to the checkpoint."""
+    from uav_bs_ctrl_amd.learner import MultiAgentQLearner
+    args = types.SimpleNamespace(device="cpu", hidden_size=32, c="tarmac", n_heads=4, n_layers=2, msg_size=8, key_size=4,
+                                 n_rounds=1, dueling=False, mixer=False, double_q=True, lr=5e-4, gamma=0.99,
+                                 polyak=0.999, max_seq_len=5, seed=0, anneal_lr=True)
+    info = dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=9, n_agents=3, episode_limit=5)
+    L = MultiAgentQLearner(info, args)
+    for _ in range(70):
+        L.lr_scheduler.step()
+    assert abs(L.optimizer.param_groups[0]["lr"] - 5e-4 * 0.4) < 1e-12       # floor of the schedule
+    path = str(tmp_path / "ck.pt")
+    L.save_checkpoint(path, dict(epoch=70, t=123))
+    ck = th.load(path, weights_only=False)
+    assert {"epoch", "t", "model_state_dict", "optimizer_state_dict", "lr_scheduler_state_dict"} <= set(ck)
+    L2 = MultiAgentQLearner(info, args)
+    assert L2.load_checkpoint(path) == dict(epoch=70, t=123)
+    assert L2.lr_scheduler.last_epoch == 70
+    for (k, a), (_, b) in zip(L.policy_net.state_dict().items(), L2.policy_net.state_dict().items()):
+        assert th.equal(a, b), k
+
+
+def test_heterobatch_to_same_device_keeps_the_object():
+    g = from_obs_dicts(_obs(np.random.default_rng(0), 3, 5), np.zeros((3, 3)), 1.0)
+    assert g.to("cpu") is g and g.to(th.device("cpu")) is g

@@ -5,6 +5,7 @@ Drop-in for the reference's ``REGISTRY['gnn']`` (algos/madrqn/agents/__init__.py
 the C-ABI of ``include/uavgnn.h``.  There is no CPU fallback.
 """
 from .agents import REGISTRY, GnnAgent  # noqa: F401
+from .tuned import enable_tuned_gemms  # noqa: F401  (opt-in, process-wide: see uav_bs_ctrl_amd/tuned)
 from .graph import HeteroBatch, batch, cat, from_obs_dicts, from_padded_obs, heterograph, merge  # noqa: F401
 
 __version__ = "0.1.0"

@@ -85,10 +85,13 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
         _LIB = handle
-        # first use of the library = first HIP op of this process, on its own device: the moment to select the recorded
-        # vendor-GEMM solutions for the dense half of the path (selection only, see uav_bs_ctrl_amd/tuned)
-        from .tuned import enable_tuned_gemms
-        enable_tuned_gemms()
+        # Recorded vendor-GEMM solutions for the dense half of the path (uav_bs_ctrl_amd/tuned) are OPT-IN: PyTorch's
+        # TunableOp switch is process-wide and would change GEMM selection for every other model of the host
+        # application.  UAVGNN_TUNED_GEMM=1 or an explicit uav_bs_ctrl_amd.enable_tuned_gemms() turns it on
+        # (bench.py does).
+        if os.environ.get("UAVGNN_TUNED_GEMM", "0") == "1":
+            from .tuned import enable_tuned_gemms
+            enable_tuned_gemms()
     return _LIB
 
 

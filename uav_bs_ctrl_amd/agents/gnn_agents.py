@@ -127,18 +127,39 @@ class TarMAC(nn.Module):
         self.f_que = nn.Linear(2 * H, self._key_size)
         self.f_udt = nn.GRUCell(H + self._msg_size, H)
 
+    def _projection_params(self):
+        return ((self.f_val.weight, self.f_sign.weight, self.f_que.weight),
+                (self.f_val.bias, self.f_sign.bias, self.f_que.bias))
+
     def fused_projection(self):
-        """[f_val; f_sign; f_que] stacked into one [M+2K, 2H] weight (+ bias), rebuilt only when a parameter changed
-        (one optimiser step per update, 151 uses per cycle).  The stacked tensors carry no autograd history: the fused
-        step (ops.tarmac_step) returns / sinks the gradient of the stack and splits it back itself."""
-        ps = (self.f_val.weight, self.f_sign.weight, self.f_que.weight, self.f_val.bias, self.f_sign.bias,
-              self.f_que.bias)
-        key = tuple((p.data_ptr(), p._version) for p in ps)
-        if getattr(self, "_fused_key", None) != key:
-            with th.no_grad():
-                self._fused = (th.cat(ps[:3], 0), th.cat(ps[3:], 0))
-            self._fused_key = key
-        return self._fused
+        """[f_val; f_sign; f_que] as ONE [M+2K, 2H] weight (+ bias) without a per-call ``cat``: the three Linear layers'
+        parameters are re-pointed (``p.data = view``) at row blocks of one stacked buffer, so the stack IS their
+        storage.  Every in-place update - optimizer steps, ``p.data.mul_()/.add_()`` polyak averaging as the
+        reference's learner does it (learner.py:165-166, which bumps no version counter), ``load_state_dict`` - lands in
+        the stack by construction; anything that REPLACES a parameter's storage (``module.to()``, ``p.data = ...``,
+        deepcopy) is caught by the pointer check below and the stack is rebuilt from the current values.  The stacked
+        tensors carry no autograd history: the fused step (ops.tarmac_step) returns / sinks the gradient of the stack
+        and splits it back itself."""
+        ws, bs = self._projection_params()
+        st = getattr(self, "_stacked", None)
+        if st is not None:
+            Wst, bst = st
+            ok, r = Wst.device == ws[0].device and Wst.dtype == ws[0].dtype, 0
+            for w, b in zip(ws, bs):
+                ok = ok and w.data_ptr() == Wst.data_ptr() + r * Wst.stride(0) * Wst.element_size() \
+                    and b.data_ptr() == bst.data_ptr() + r * bst.element_size() and w.is_contiguous()
+                r += w.shape[0]
+            if ok:
+                return st
+        with th.no_grad():
+            Wst, bst = th.cat([w.detach() for w in ws], 0), th.cat([b.detach() for b in bs], 0)
+            r = 0
+            for w, b in zip(ws, bs):
+                w.data = Wst[r:r + w.shape[0]]
+                b.data = bst[r:r + b.shape[0]]
+                r += w.shape[0]
+        self._stacked = (Wst, bst)
+        return self._stacked
 
     def forward(self, g, x, h):
         g = _parent(g)

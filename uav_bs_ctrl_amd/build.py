@@ -1,6 +1,11 @@
 """Builds ``libuavgnn.so`` (the C-ABI of include/uavgnn.h) for gfx950 with hipcc.  No GPU is needed to compile.
 
     python -m uav_bs_ctrl_amd.build [--force]
+
+Every ``csrc/*.hip`` is compiled to its own object (in parallel, ``csrc/build/*.o``) and the objects are linked into the
+shared library; without ``--force`` only the objects older than their source (or than any header) are recompiled.
+``__graft_entry__.build()`` always forces a full compile so that "it builds" is checked against the sources on disk
+and never against a shipped binary.
 """
 from __future__ import annotations
 
@@ -8,31 +13,65 @@ import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 OUT = os.path.join(CSRC, "libuavgnn.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
+
+
+def _stale_objects(force: bool):
+    hdr_t = max((os.path.getmtime(h) for h in headers()), default=0.0)
+    out = []
+    for s in sources():
+        o = _obj(s)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
+            out.append(s)
+    return out
+
+
 def stale() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in sources() + headers())
 
 
 def build_lib(force: bool = False, verbose: bool = True) -> str:
-    if not force and not stale():
+    os.makedirs(OBJ, exist_ok=True)
+    todo = _stale_objects(force)
+    if not todo and os.path.exists(OUT) and not stale():
         return OUT
-    cmd = [HIPCC, *FLAGS, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *sources(), "-o", OUT]
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+    def compile_one(src):
+        cmd = [HIPCC, *CFLAGS, *inc, "-c", src, "-o", _obj(src)]
+        if verbose:
+            print("[uav_bs_ctrl_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1) or 1) as ex:
+        list(ex.map(compile_one, todo))
+    for o in glob.glob(os.path.join(OBJ, "*.o")):       # objects of deleted sources must not be linked
+        if not os.path.exists(os.path.join(CSRC, os.path.splitext(os.path.basename(o))[0] + ".hip")):
+            os.remove(o)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *[_obj(s) for s in sources()], "-o", OUT]
     if verbose:
         print("[uav_bs_ctrl_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -86,18 +86,30 @@ __device__ __forceinline__ void stage_rest(const float* __restrict__ src, int ld
   }
 }
 
-// local source / destination of every edge of the graph (OFF already in LDS)
-__device__ __forceinline__ void stage_edges(const EnvGraph& g, int lane, const int32_t* __restrict__ talk_src,
+// local source / destination of every edge of the graph (OFF already in LDS).  Returns true (wave-uniform) when some
+// edge's source lies outside the graph's agents [a0, a0 + n): graph_off then does not delimit the talk relation (e.g. a
+// container assembled by hand with the offsets of another relation) and the caller poisons the graph's output with NaN
+// - a wrong precondition must fail loudly, never fall back to a self loop.
+__device__ __forceinline__ bool stage_edges(const EnvGraph& g, int lane, const int32_t* __restrict__ talk_src,
                                             int first_src, const int* __restrict__ OFF, int* __restrict__ SRC,
                                             int* __restrict__ DST) {
+  bool bad = false;
   for (int e = lane; e < g.E; e += kWave) {
     const int u = (e < kWave ? first_src : talk_src[g.e_lo + e]) - g.a0;
+    bad |= (u < 0) | (u >= g.n);
     SRC[e] = u < 0 ? 0 : (u >= g.n ? g.n - 1 : u);
     int d = 0;
 #pragma unroll 4
     for (int j = 1; j < g.n; ++j) d += e >= OFF[j];
     DST[e] = d;
   }
+  return __any(bad);
+}
+
+__device__ __forceinline__ void poison_rows(float* __restrict__ dst, int ld, int a0, int n, int W, int lane) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i)
+    for (int ch = lane; ch < W; ch += kWave) dst[static_cast<size_t>(a0 + i) * ld + ch] = NAN;
 }
 
 // out[r][ch] = sum_{t < NMAX} W[r, t] * X[t][ch] for r < n, one 64-channel block at a time, X rows in registers
@@ -203,8 +215,12 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_fwd_kern
     for (int i = lane; i < dm.emax; i += kWave) AD[i] = 0.f;
     if (lane <= g.n) OFF[lane] = toff - g.e_lo;
     wave_sync_lds();
-    stage_edges(g, lane, talk_src, first_src, OFF, SRC, DST);
+    const bool foreign = stage_edges(g, lane, talk_src, first_src, OFF, SRC, DST);
     wave_sync_lds();
+    if (foreign) {   // an edge enters from outside the graph: precondition violated, fail loudly
+      poison_rows(c, ld_c, g.a0, g.n, M, lane);
+      continue;
+    }
     if (!uniform) {
       for (int e = lane; e < g.E; e += kWave) {
         const float* __restrict__ sr = P + SRC[e] * dm.ldp + M;
@@ -309,8 +325,12 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_bwd_kern
     for (int e = lane; e < g.E; e += kWave) A[e] = e < kWave ? first_a : a_save[g.e_lo + e];
     if (lane <= g.n) OFF[lane] = toff - g.e_lo;
     wave_sync_lds();
-    stage_edges(g, lane, talk_src, first_src, OFF, SRC, DST);
+    const bool foreign = stage_edges(g, lane, talk_src, first_src, OFF, SRC, DST);
     wave_sync_lds();
+    if (foreign) {
+      poison_rows(d_v, ld_dv, g.a0, g.n, M, lane);
+      continue;
+    }
     for (int e = lane; e < g.E; e += kWave) {
       atomicAdd(&AD[DST[e] * NMAX + SRC[e]], A[e]);
       if (!uniform) {   // da_e = <d_c[dst_e], v[src_e]>

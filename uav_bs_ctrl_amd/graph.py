@@ -208,8 +208,9 @@ class HeteroBatch:
 
     def to(self, device, non_blocking: bool = True) -> "HeteroBatch":
         device = th.device(device)
-        if self.device == device:
-            return self
+        cur = self.device
+        if cur.type == device.type and (device.index is None or device.index == cur.index):
+            return self       # 'cuda' names the current 'cuda:i': no copy, derived indexes stay cached
         feat = {nt: {k: v.to(device, non_blocking=non_blocking) for k, v in fr.items()}
                 for nt, fr in self._feat.items()}
         rels = {c: r.to(device) for c, r in self._rels.items()}
@@ -442,11 +443,26 @@ def merge(graphs: Sequence[HeteroBatch]) -> HeteroBatch:
             if g._num_nodes.get(nt, 0) == num_nodes[nt]:
                 for k, v in g._feat.get(nt, {}).items():
                     feat[nt].setdefault(k, v)
-    go = next((g.graph_off for g in graphs if g.graph_off is not None), None)
+    # graph_off delimits the TALK relation (talk edges never cross it), so it - and the max_graph_agents hint - may only
+    # be inherited from the graph that carries the talk edges.  In the reference's flow (env_wrappers.py:137) the
+    # other operand is dgl.batch of n ONE-agent observation graphs (graph_off = [0,1,..,n]) whose boundaries the
+    # communication edges cross: the merged graph is ONE graph of n agents.
+    n_ag = num_nodes.get("agent", 0)
+    dev = next((fr["feat"].device for nt, fr in feat.items() if nt == "agent" and "feat" in fr),
+               graphs[0]._rels[next(iter(graphs[0]._rels))].off.device if graphs[0]._rels else None)
+    talk_holder = next((g for g in graphs if TALK in g._rels and g._rels[TALK].num_edges > 0), None)
     hints: Dict[str, int] = {}
     for g in graphs:
         for k, v in g.hints.items():
-            hints[k] = max(v, hints.get(k, v))
+            if k != "max_graph_agents":
+                hints[k] = max(v, hints.get(k, v))
+    if talk_holder is not None and talk_holder.graph_off is not None:
+        go = talk_holder.graph_off
+        if "max_graph_agents" in talk_holder.hints:
+            hints["max_graph_agents"] = talk_holder.hints["max_graph_agents"]
+    else:
+        go = th.tensor([0, n_ag], dtype=th.int32, device=dev)
+        hints["max_graph_agents"] = n_ag
     return HeteroBatch(num_nodes, rels, feat, go, hints)
 
 

@@ -105,6 +105,13 @@ class MultiAgentQLearner:
         self.batch_size = getattr(args, "batch_size", None)
         self.double_q = args.double_q
         self.optimizer = th.optim.AdamW(self.params, lr=args.lr)
+        # lr annealing (learner.py:51-54; `anneal_lr` defaults to True in madrqn/config.py:36): the caller steps
+        # ``learner.lr_scheduler`` once per epoch as run.py:107-108 does.  (The reference passes verbose=True, which
+        # torch >= 2.7 rejects; the schedule itself is identical.)
+        self.anneal_lr = bool(getattr(args, "anneal_lr", False))
+        if self.anneal_lr:
+            self.lr_scheduler = th.optim.lr_scheduler.LambdaLR(self.optimizer,
+                                                               lr_lambda=lambda epoch: max(0.4, 1 - epoch / 100))
         self.grads = FlatGradBuffer(self.params)
         self.n_policy = sum(p.numel() for p in self.policy_net.parameters())
         self._gen = th.Generator(device=self.device)
@@ -231,6 +238,8 @@ class MultiAgentQLearner:
         ck["optimizer_state_dict"] = self.optimizer.state_dict()
         if self.mixer is not None:
             ck["mixer_state_dict"] = self.mixer.state_dict()
+        if self.anneal_lr:
+            ck["lr_scheduler_state_dict"] = self.lr_scheduler.state_dict()
         th.save(ck, path)
 
     def load_checkpoint(self, path: str) -> dict:
@@ -242,6 +251,8 @@ class MultiAgentQLearner:
         if self.mixer is not None and "mixer_state_dict" in ck:
             self.mixer.load_state_dict(ck["mixer_state_dict"])
             self.target_mixer.load_state_dict(self.mixer.state_dict())
+        if self.anneal_lr and "lr_scheduler_state_dict" in ck:
+            self.lr_scheduler.load_state_dict(ck["lr_scheduler_state_dict"])
         return dict(epoch=ck.get("epoch"), t=ck.get("t"))
 
 

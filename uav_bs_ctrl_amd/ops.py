@@ -370,7 +370,8 @@ class WeightGradSink:
     accumulators into ``param.grad`` once, in a fixed order (deterministic)."""
 
     def __init__(self):
-        self.slots = {}      # key -> (buffer, flush_fn)
+        self.slots = {}      # (key, chunk count) -> (buffer, flush_fn)
+        self.owned = set()   # data_ptr of the d h buffers the fused step's backward handed to autograd (private)
 
     @staticmethod
     def _chunks(n):
@@ -382,8 +383,9 @@ class WeightGradSink:
     def weight(self, key, dy, x, flush_fn):
         """buffer[S, out, in] += chunked dy^T x"""
         n, S = x.shape[0], self._chunks(x.shape[0])
+        key = (key, S)          # one slot per chunk count: a change of N mid-accumulation never drops a partial sum
         slot = self.slots.get(key)
-        if slot is None or slot[0].shape[0] != S:
+        if slot is None:
             buf = th.zeros((S, dy.shape[1], x.shape[1]), dtype=th.float32, device=x.device)
             self.slots[key] = slot = (buf, flush_fn)
         if S == 1:
@@ -396,8 +398,9 @@ class WeightGradSink:
         place (torch: a reduction into a temporary plus an add per step; a transposed GEMV was 20x slower still)"""
         n, C = dy.shape
         S = _row_blocks(n)
+        key = (key, S)
         slot = self.slots.get(key)
-        if slot is None or slot[0].shape != (S, C):
+        if slot is None:
             self.slots[key] = slot = (th.zeros((S, C), dtype=th.float32, device=dy.device), flush_fn)
         if dy.dtype != th.float32 or dy.stride(1) != 1:
             dy = dy.float().contiguous()
@@ -515,9 +518,12 @@ class _TarmacStep(th.autograd.Function):
         dq = L.f32c(dq) if dq is not None else th.zeros((N, W_out.shape[0]), dtype=th.float32, device=x.device)
         if dh2 is None:
             dh2_tot = th.mm(dq, W_out)
-        elif sink is not None and dh2.is_contiguous():
-            # inside the learner's BPTT the incoming d h' is the buffer the next step's backward produced for exactly
-            # this purpose: accumulate in place instead of copying 33 MB into a fresh output first
+        elif sink is not None and dh2.is_contiguous() and dh2.data_ptr() in sink.owned:
+            # inside the learner's BPTT the incoming d h' is the buffer the NEXT step's backward of this very op
+            # allocated and returned (registered in sink.owned): nobody else holds it, so accumulate in place instead of
+            # copying 33 MB into a fresh output first.  Any other gradient tensor (a hook's, retain_grad's, one autograd
+            # summed from several consumers) is left untouched.
+            sink.owned.discard(dh2.data_ptr())
             dh2_tot = dh2.addmm_(dq, W_out)
         else:
             dh2_tot = th.addmm(dh2, dq, W_out)
@@ -528,6 +534,8 @@ class _TarmacStep(th.autograd.Function):
         L.check(rc, "uavgnn_gru_gates_bwd")
         d_inp = th.mm(d_gi, W_ih)                                          # [N, H + M]: d x | d c
         dh.addmm_(d_gh, W_hh)
+        if sink is not None:
+            sink.owned.add(dh.data_ptr())
         ld = M + 2 * K
         d_proj = th.empty((N, ld), dtype=th.float32, device=x.device)
         _launch_talk_bwd(ctx.env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld,

@@ -4,12 +4,14 @@ The dense half of the path (f_aggr, TarMAC projections, GRU W_ih / W_hh, Q head 
 fp32 GEMM (hipBLASLt / rocBLAS through PyTorch).  The library's default heuristic is 10-30 % off the best solution it
 ships for several of the backward shapes (e.g. the 16-way batched weight-gradient GEMM [768 x 2048] x [2048 x 256]:
 127-140 us by default, 92 us tuned), so the solutions PyTorch's TunableOp found on an MI355X for the C3 / exp3 shapes are
-recorded in ``gemm_gfx950.csv`` and selected at import - selection only: tuning stays OFF at run time, shapes that are
+recorded in ``gemm_gfx950.csv`` and selected ON REQUEST (``uav_bs_ctrl_amd.enable_tuned_gemms()``, as bench.py does, or
+``UAVGNN_TUNED_GEMM=1`` in the environment: TunableOp is a process-wide PyTorch switch, so a library import must not
+flip it behind the host application's back) - selection only: tuning stays OFF at run time, shapes that are
 not in the file use the default heuristic, and PyTorch ignores the file when its validator lines (PyTorch / ROCm /
 hipBLASLt / rocBLAS versions, gfx arch) do not match the running stack.
 
 Re-tune:  python tools/tune_gemms.py   (on the GPU box; rewrites the csv)
-Opt out:  UAVGNN_TUNED_GEMM=0
+Opt out of an explicit call:  UAVGNN_TUNED_GEMM=0
 """
 from __future__ import annotations
 
