@@ -218,6 +218,8 @@ def main():
     th.manual_seed(0)
     env_info = dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=9, n_agents=a.n, episode_limit=a.T)
     learner = MultiAgentQLearner(env_info, exp3_args(str(device)))
+    if use_dist and a.force_dist:
+        learner.grads.force_collective = True    # world size 1: still push the flat gradient buffer through RCCL
     batch = make_sequence(a.B, a.n, a.M, a.T, a.dist, device, seed=1234 + rank, distinct=a.distinct)
 
     def step():

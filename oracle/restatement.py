@@ -155,7 +155,7 @@ def segment_mean(m, dst, n):
     return s / deg.clamp(min=1).unsqueeze(1)
 
 
-def segment_max_first(m, dst, n, key=None):
+def segment_max_first(m, dst, n, key=None, return_owner=False):
     """UDF reduce ``nodes.mailbox['m'].max(1)[0]`` (gnn_agents.py:177).  torch.max(dim) routes the gradient to ONE
     index - the first maximal entry in mailbox order (= edge-id order within the in-edges of the node, which the
     stable CSC sort preserves) - so ties, which are the norm for one-hot messages, must not be split."""
@@ -169,7 +169,8 @@ def segment_max_first(m, dst, n, key=None):
     cand = th.where(md == mx.index_select(0, dst), pos, th.full_like(pos, E))
     first = th.full((n, Fm), E, dtype=th.long, device=m.device).scatter_reduce(0, idxe, cand, reduce="amin")
     has = first < E
-    return th.where(has, m.gather(0, first.clamp(max=E - 1)), th.zeros((), dtype=m.dtype, device=m.device))
+    out = th.where(has, m.gather(0, first.clamp(max=E - 1)), th.zeros((), dtype=m.dtype, device=m.device))
+    return (out, first) if return_owner else out      # first: the edge that owns (value and gradient of) each entry
 
 
 # a6: BaseComm.forward (gnn_agents.py:135-148)

@@ -98,13 +98,17 @@ def test_exp3_sizes_vs_oracle(dist, talk, B, n, M):
         assert err_hip <= max(1e-4, 4 * err_cpu32), f"grad {k}: rel err {err_hip:.3e} (cpu fp32 oracle {err_cpu32:.3e})"
 
 
-def test_exp3_disc_comm_vs_oracle():
-    """DiscreteComm at exp3 sizes (msg = 64 bit pairs) with injected noise, oracle in exact-tie mode (the rule K5
-    implements; identical to the literal rule whenever (1 - s) + s rounds to exactly 1)."""
-    cfg = dict(EXP3, c="disc", exact_ties=True)
+@pytest.mark.parametrize("exact_ties,talk", [(True, "sparse"), (False, "sparse"), (False, "complete")])
+def test_exp3_disc_comm_vs_oracle(exact_ties, talk):
+    """DiscreteComm at exp3 sizes (msg = 64 bit pairs) with injected noise.  exact_ties=True: the oracle applies the rule
+    K5 implements (first in-edge whose hard bit is set owns the channel); exact_ties=False: the LITERAL reference rule
+    (max over the floating-point values (y_hard - y_soft) + y_soft, gnn_agents.py:166-178) - with up to 8 competing
+    in-edges per destination (complete graph) forward AND gradients still agree: (1 - s) + s rounds to exactly 1 so the
+    literal max also picks the first set bit (tests/test_oracle_kats.py counts the disagreements: none)."""
+    cfg = dict(EXP3, c="disc", exact_ties=exact_ties)
     p64 = default_init_params(cfg, seed=4)
     B, n = 24, 8
-    g = synth_graph(B, n, 80, "env", seed=8, talk="sparse")
+    g = synth_graph(B, n, 80, "env", seed=8, talk=talk)
     gen = th.Generator().manual_seed(17)
     N, E = B * n, g["talk_src"].numel()
     h = 0.5 * th.randn(N, 256, generator=gen)
@@ -880,7 +884,8 @@ def test_reference_style_merge_graph_runs_the_same_as_the_vectorised_builder():
             x, off = fast.relation_segments(et)
             g[kx], g[ko] = x.cpu().double(), off.cpu()
         g["x_a"] = fast.agent_feat().cpu().double()
-        q_ref, _ = R.gnn_agent_forward(g, h.cpu().double(), {k: v.double() for k, v in net.state_dict().items()}, cfg)
+        q_ref, _ = R.gnn_agent_forward(g, h.cpu().double(),
+                                        {k: v.detach().cpu().double() for k, v in net.state_dict().items()}, cfg)
         assert_close(q1, q_ref, 1e-5, f"merge-built graph, c={c}")
 
 
@@ -925,3 +930,95 @@ def test_reference_style_data_polyak_reaches_the_fused_target_step():
                                     if k != "graph_off"}, h.cpu().double(), p_new, cfg)
     assert_close(q1, q_ref, 1e-5, "target net after .data polyak")
     assert float((q1 - q0).abs().max()) > 1e-3
+
+
+def test_qmix_learner_update_reproduces_reference_update():
+    """Row f4 on the GPU: learner.update with mixer=True (HIP agent + QMixer + target mixer; clip on the agent only,
+    learner.py:145-148,:159) against the state the REFERENCE learner reached from the same parameters / batch
+    (tests/golden/learner_update_qmix.npz, captured from algos/madrqn/learner.py + mixers.py)."""
+    from tests.test_replay_mixer import _qmix_learner
+    L, batch, cfg, z = _qmix_learner("cuda", th.float32)
+    out = L.update(batch)
+    assert_close(out["LossQ"], th.as_tensor(z["loss"]).double(), 1e-5, "QMIX LossQ")
+    for tag, mod, tmod in (("policy", L.policy_net, L.target_net), ("mixer", L.mixer, L.target_mixer)):
+        for k, prm in mod.named_parameters():
+            g_ref = th.as_tensor(z[f"grad:{tag}:{k}"])
+            assert_close(prm.grad, g_ref, 1e-4, f"{tag} grad {k}", floor=2e-6)
+            sure = g_ref.abs() > 1e-4          # Adam's first step is lr * sign-like(g): only where g is above noise
+            after = th.as_tensor(z[f"after:{tag}:{k}"])
+            assert float(((prm.detach().cpu().double() - after).abs() * sure).max()) < 2e-6, f"{tag} param {k}"
+        for k, prm in tmod.named_parameters():
+            assert float((prm.detach().cpu().double() - th.as_tensor(z[f"target_after:{tag}:{k}"])).abs().max()) < 1e-6, k
+    # the mixer's gradients are NOT clipped (learner.py:159 clips policy_net only), the agent's are
+    assert float(max(p.grad.abs().max() for p in L.policy_net.parameters())) <= 1.0
+
+
+def _nccl_ws1_worker(port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from uav_bs_ctrl_amd import HeteroBatch
+    from uav_bs_ctrl_amd.learner import MultiAgentQLearner
+    th.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=th.device("cuda", 0))
+    try:
+        import types
+        batch, p, cfg, z = load_learner_golden(dtype=th.float32)
+        args = types.SimpleNamespace(device="cuda", hidden_size=32, c="tarmac", n_heads=4, n_layers=2, msg_size=8,
+                                     key_size=4, n_rounds=1, dueling=False, mixer=False, double_q=True, lr=cfg["lr"],
+                                     gamma=cfg["gamma"], polyak=cfg["polyak"], max_seq_len=cfg["T"], seed=0)
+        env_info = dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=cfg["n_actions"], n_agents=cfg["n_agents"],
+                        episode_limit=10)
+        dev = th.device("cuda")
+        b = dict(obs=[HeteroBatch.from_arrays(**g).to(dev) for g in batch["obs"]], h0=batch["h0"].to(dev),
+                 h1=batch["h1"].to(dev), acts=batch["acts"].to(dev), rews=batch["rews"].to(dev),
+                 dones=batch["dones"].to(dev))
+        res = []
+        for group in ("none", "world"):
+            L = MultiAgentQLearner(env_info, args, process_group=None)
+            L.policy_net.load_state_dict(p)
+            L.target_net.load_state_dict(p)
+            if group == "none":     # reference arm: the collective path switched off entirely
+                L.grads.all_reduce_mean_ = lambda g=None: None
+            else:                   # the real thing: broadcast + RCCL all-reduce on the flat buffer, forced at world size 1
+                from uav_bs_ctrl_amd import learner as LM
+                LM.broadcast_parameters(L.policy_net, 0, None, force=True)
+                L.grads.force_collective = True
+            out = L.update(b)
+            th.cuda.synchronize()
+            res.append((float(out["LossQ"]), th.cat([p_.detach().reshape(-1) for p_ in L.policy_net.parameters()]).cpu(),
+                        L.grads.flat.detach().cpu().clone()))
+        q.put(("ok", res[0][0] == res[1][0], bool(th.equal(res[0][1], res[1][1])), bool(th.equal(res[0][2], res[1][2])),
+               float(z["loss"]), res[1][0]))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put(("err", traceback.format_exc() + repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_path_at_world_size_one_equals_the_non_distributed_step():
+    """the nccl (= RCCL) branch has never run on hardware.  One process, world size 1: start-up
+    broadcast of the flat parameter copy + all-reduce of the flat gradient buffer through RCCL around a real HIP-agent
+    update must leave loss, gradients and parameters BIT-identical to the update with the collective switched off."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_nccl_ws1_worker, args=(port, q))
+    pr.start()
+    try:
+        res = q.get(timeout=300)
+    finally:
+        pr.join(timeout=60)
+        if pr.is_alive():
+            pr.kill()
+    assert res[0] == "ok", res[1]
+    _, same_loss, same_params, same_grads, loss_ref, loss = res
+    assert same_loss and same_params and same_grads
+    assert abs(loss - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))

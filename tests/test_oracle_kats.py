@@ -213,3 +213,26 @@ def test_gradcheck_gatv2_and_tarmac():
     def ft(x, *ws):
         return R.tarmac(dict(talk_off=off, talk_src=src), x, h, dict(zip(kt, ws)), key)
     assert th.autograd.gradcheck(ft, (x,) + tuple(pt.values()), eps=1e-6, atol=1e-7)
+
+
+def test_disc_comm_literal_and_exact_tie_rules_pick_the_same_owner():
+    """how often does the literal reference rule (max over (y_hard - y_soft) + y_soft in floating
+    point, gnn_agents.py:166-178) route a channel's gradient to another in-edge than the exact rule K5 implements (first
+    in-edge whose hard bit is set)?  Counted over complete 8-agent graphs (8 competing in-edges per destination) in
+    float32 and float64: never - (1 - s) + s rounds to exactly 1.0 for every softmax output s drawn here, so both maxima
+    are ties at 1.0 resolved towards the first edge."""
+    import torch.nn.functional as F
+    gen = th.Generator().manual_seed(0)
+    for dt in (th.float32, th.float64):
+        N, n, msg = 64, 8, 64
+        src = (th.arange(N) // n * n).repeat_interleave(n) + th.arange(n).repeat(N)
+        dst = th.arange(N).repeat_interleave(n)
+        logits = th.randn(N, msg, 2, generator=gen).to(dt)[src]
+        gum = -th.empty(N * n, msg, 2).exponential_(generator=gen).log().to(dt)
+        y_soft = th.softmax((logits + gum) / 0.5, -1)
+        y_hard = th.zeros_like(y_soft).scatter_(-1, y_soft.max(-1, keepdim=True)[1], 1.0)
+        m = ((y_hard - y_soft) + y_soft).flatten(1)
+        own_lit = R.segment_max_first(m, dst, N, return_owner=True)[1]
+        own_exact = R.segment_max_first(m, dst, N, key=y_hard.flatten(1), return_owner=True)[1]
+        assert int((own_lit != own_exact).sum()) == 0
+        assert bool((m[y_hard.flatten(1) == 1] == 1).all())        # the rounding fact the equality rests on

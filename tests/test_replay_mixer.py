@@ -71,3 +71,105 @@ def test_qmixer_matches_reference_fixture():
     grads = th.autograd.grad((y * th.as_tensor(z["w"])).sum(), list(mix.parameters()) + [qs])
     for k, g in zip(names + ["__qs__"], grads):
         assert_close(g, th.as_tensor(z["grad:" + k]), 1e-10, f"grad {k}", floor=1e-14)
+
+
+def test_sequence_replay_reproduces_the_reference_replay_buffer():
+    """Row f2 against the reference's own ReplayBuffer (buffer.py:7-42) as filled by its learner.cache
+    (learner.py:82-92) in a rollout crossing an episode end (tests/golden/replay_buffer.npz, make_golden.py `replay`):
+    the same pushed transitions must leave the same sequences - cut every T pushes whatever the episode does, T+1
+    observations / hidden states / states per sequence, next_h zeroed at the episode end, reference graphs per step."""
+    import ast
+    z = np.load(f"{GOLDEN}/replay_buffer.npz")
+    meta = ast.literal_eval(str(z["meta"]))
+    T, H, n, M = meta["T"], meta["H"], meta["n_agents"], meta["n_gts"]
+    rb = SequenceReplay(capacity=10, max_seq_len=T, n_agents=n, n_gts=M, hidden_size=H, n_envs=1,
+                        state_dim=meta["state_dim"], r_comm=float(z["r_comm"]), rew_dim=n, device="cpu")
+    f = lambda k: th.as_tensor(z[k])  # noqa: E731
+    for i in range(meta["n_pushes"]):
+        tr = {}
+        for k in ("gt", "ubs", "agent", "d_u2u", "h", "state"):
+            tr[k] = f(f"push{i}:{k}").unsqueeze(0) if k != "state" else f(f"push{i}:{k}").reshape(1, -1)
+            nk = f(f"push{i}:next_{k}")
+            tr["next_" + k] = nk.unsqueeze(0) if k != "state" else nk.reshape(1, -1)
+        tr["act"] = f(f"push{i}:act").reshape(1, n)
+        tr["rew"] = f(f"push{i}:rew").reshape(1, n)
+        tr["done"] = f(f"push{i}:done").reshape(1, 1)
+        rb.push(tr)
+    assert len(rb) == meta["n_seqs"] == 4 and rb.ptr == meta["n_pushes"] - 4 * T
+    b = rb.gather(th.arange(4))
+    for si in range(4):
+        for t in range(T + 1):
+            g = b["obs"][t]
+            lo, hi = si * n, (si + 1) * n
+            ref = {k.split(":")[-1]: z[k] for k in z.files if k.startswith(f"seq{si}:obs{t}:")}
+            assert np.array_equal(g.agent_feat()[lo:hi].numpy(), ref["x_a"].astype(np.float32))
+            for et, kx, ko in (("seen", "x_gt", "seen_off"), ("near", "x_ubs", "near_off")):
+                x, off = g.relation_segments(et)
+                e0, e1 = int(off[lo]), int(off[hi])
+                assert np.array_equal((off[lo:hi + 1] - off[lo]).numpy(), ref[ko]), (si, t, et)
+                assert np.array_equal(x[e0:e1].numpy(), ref[kx].astype(np.float32)), (si, t, et)
+            off, src = g.talk_csc()
+            e0, e1 = int(off[lo]), int(off[hi])
+            assert np.array_equal((off[lo:hi + 1] - off[lo]).numpy(), ref["talk_off"])
+            assert np.array_equal((src[e0:e1] - lo).numpy(), ref["talk_src"])
+        h_ref, T1 = z[f"seq{si}:h"], T + 1
+        assert np.array_equal(rb.mem["h"][si].numpy(), h_ref.astype(np.float32)) and h_ref.shape[0] == T1
+        assert np.array_equal(rb.mem["state"][si].numpy(), z[f"seq{si}:state"])
+        assert np.array_equal(b["acts"][:, si * n:(si + 1) * n].numpy(), z[f"seq{si}:act"])
+        assert np.array_equal(b["rews"][:, si].numpy(), z[f"seq{si}:rew"].reshape(T, n))
+        assert np.array_equal(b["dones"][:, si].numpy(), z[f"seq{si}:done"].reshape(T, 1))
+    # h0 / h1 = the stored hidden states of the first two steps of every sequence (learner.py:113)
+    assert np.array_equal(b["h0"].numpy().reshape(4, n, H), np.stack([z[f"seq{s}:h"][0] for s in range(4)]).astype(np.float32))
+    assert np.array_equal(b["h1"].numpy().reshape(4, n, H), np.stack([z[f"seq{s}:h"][1] for s in range(4)]).astype(np.float32))
+    # the episode ended inside sequence 3 (push 10 of 14): the hidden state after it is zero, the observation a reset
+    assert float(np.abs(z["seq3:h"][1]).max()) == 0.0 and float(np.abs(z["seq3:h"][0]).max()) > 0.0
+
+
+def _qmix_learner(device, dtype):
+    """uav_bs_ctrl_amd learner with mixer=True loaded with the closed-form weights of learner_update_qmix.npz."""
+    import ast
+    from uav_bs_ctrl_amd import HeteroBatch
+    from uav_bs_ctrl_amd.learner import MultiAgentQLearner
+    z = np.load(f"{GOLDEN}/learner_update_qmix.npz")
+    cfg = ast.literal_eval(str(z["cfg"]))
+    args = types.SimpleNamespace(device=device, hidden_size=32, c="tarmac", n_heads=4, n_layers=2, msg_size=8, key_size=4,
+                                 n_rounds=1, dueling=False, mixer=True, embed_dim=cfg["embed_dim"], double_q=True,
+                                 lr=cfg["lr"], gamma=cfg["gamma"], polyak=cfg["polyak"], max_seq_len=cfg["T"], seed=0)
+    env_info = dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=cfg["n_actions"], n_agents=cfg["n_agents"],
+                    episode_limit=10, state_shape=cfg["state_dim"])
+    L = MultiAgentQLearner(env_info, args)
+
+    def fill(mod, names, shapes):
+        assert [k.removeprefix("inner.") for k, _ in mod.named_parameters()] == [str(k) for k in names]
+        with th.no_grad():
+            for i, (k, p) in enumerate(mod.named_parameters()):
+                assert repr(tuple(p.shape)) == str(shapes[i])
+                p.copy_(closed_form_tensor(p.shape, 1.0 + i * math.pi / 7, 0.1 if p.dim() == 1 else 0.25, th.float64))
+    fill(L.policy_net, z["param_names"], z["param_shapes"])
+    fill(L.mixer, z["mixer_param_names"], z["mixer_param_shapes"])
+    L.target_net.load_state_dict(L.policy_net.state_dict())
+    L.target_mixer.load_state_dict(L.mixer.state_dict())
+    obs = []
+    for t in range(cfg["T"] + 1):
+        g = {k.split(":")[1]: th.as_tensor(z[k]) for k in z.files if k.startswith(f"t{t}:")}
+        g = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in g.items()}
+        obs.append(HeteroBatch.from_arrays(**g).to(device))
+    f = lambda k: th.as_tensor(z[k]).to(dtype).to(device)  # noqa: E731
+    batch = dict(obs=obs, h0=f("h0"), h1=f("h1"), acts=th.as_tensor(z["acts"]).long().to(device), rews=f("rews"),
+                 dones=f("dones"), states=f("states"))
+    return L, batch, cfg, z
+
+
+def test_qmix_learner_fixture_is_consistent_with_the_oracle_on_cpu():
+    """The mixer=True update fixture captured from the reference learner: the torch QMixer + the CPU oracle agent
+    reproduce its loss (the -m gpu twin runs the HIP agent against the same fixture)."""
+    import uav_bs_ctrl_amd.learner as LM
+    from tests.test_dp_gloo import OracleAgent
+    saved = LM.agent_REGISTRY
+    LM.agent_REGISTRY = {"gnn": OracleAgent}
+    try:
+        L, batch, cfg, z = _qmix_learner("cpu", th.float32)
+        loss, _, _ = L.loss(batch)
+        assert_close(loss, th.as_tensor(z["loss"]).double(), 1e-5, "QMIX LossQ (oracle agent)")
+    finally:
+        LM.agent_REGISTRY = saved

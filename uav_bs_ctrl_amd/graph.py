@@ -238,7 +238,9 @@ class HeteroBatch:
                 raise KeyError(f"no 'feat' on node type {c[0]}")
             if r.src is not None:                      # general graphs: gather once into segment order
                 x = x.index_select(0, r.src.long())
-            self._cache[key] = (x.float().contiguous(), r.off)
+            # floating features keep their dtype (the HIP ops insist on float32 themselves; float64 containers serve
+            # the CPU checkers), anything else becomes float32
+            self._cache[key] = ((x if x.is_floating_point() else x.float()).contiguous(), r.off)
         return self._cache[key]
 
     def relation_order(self, etype: str) -> th.Tensor:

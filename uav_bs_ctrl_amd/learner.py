@@ -37,6 +37,7 @@ class FlatGradBuffer:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = th.zeros(n, dtype=th.float32, device=dev)
+        self.force_collective = False   # run the collective even at world size 1 (RCCL smoke test / bench --force-dist)
         o = 0
         for p in self.params:
             p.grad = self.flat[o:o + p.numel()].view_as(p)
@@ -51,15 +52,16 @@ class FlatGradBuffer:
             o += p.numel()
 
     def all_reduce_mean_(self, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.force_collective):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+            if dist.get_world_size(group) > 1:
+                self.flat.div_(dist.get_world_size(group))
 
 
-def broadcast_parameters(module: th.nn.Module, src: int = 0, group=None) -> None:
+def broadcast_parameters(module: th.nn.Module, src: int = 0, group=None, force: bool = False) -> None:
     """Start-up sync (counterpart of the reference's unused ``sync_params``, utils/mpi_pytorch.py:29-35): one broadcast
     of a flat copy of every parameter and buffer."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return
     tensors = [t.data for t in list(module.parameters()) + list(module.buffers())]
     flat = th.cat([t.reshape(-1) for t in tensors])
