@@ -948,7 +948,11 @@ def test_qmix_learner_update_reproduces_reference_update():
             after = th.as_tensor(z[f"after:{tag}:{k}"])
             assert float(((prm.detach().cpu().double() - after).abs() * sure).max()) < 2e-6, f"{tag} param {k}"
         for k, prm in tmod.named_parameters():
-            assert float((prm.detach().cpu().double() - th.as_tensor(z[f"target_after:{tag}:{k}"])).abs().max()) < 1e-6, k
+            # where the gradient is rounding noise (e.g. f_sign.bias: analytically zero) Adam moves the policy parameter
+            # by +-lr whatever the sign of the noise, and polyak carries (1 - polyak) of that into the target
+            sure = th.as_tensor(z[f"grad:{tag}:{k}"]).abs() > 1e-4
+            diff = (prm.detach().cpu().double() - th.as_tensor(z[f"target_after:{tag}:{k}"])).abs()
+            assert float((diff * sure).max()) < 1e-6 and float(diff.max()) < 2.1 * cfg["lr"] * (1 - cfg["polyak"]) + 1e-6, k
     # the mixer's gradients are NOT clipped (learner.py:159 clips policy_net only), the agent's are
     assert float(max(p.grad.abs().max() for p in L.policy_net.parameters())) <= 1.0
 
