@@ -71,6 +71,30 @@ int uavgnn_gatv2_fwd_mfma(const float* x_src, int E, int F_src, const float* x_d
                           const float* W_r, const float* b_r, int nh, int D, float slope, float* out, int ld_out,
                           float* attn_save, uavgnn_stream_t stream);
 
+/* K1 forward, BOTH relations of GraphObservationEncoder.forward in ONE launch (reference: the two GATv2Conv calls and the
+ * th.cat of algos/madrqn/agents/gnn_agents.py:103-106).  `seen` (x_gt [E_seen,4], seen_off, optional hand-out order
+ * seen_order) fills out[:, 0:H), `near` (x_ubs [E_near,2], near_off) fills out[:, H:2H); ld_out >= 2H, 16-byte aligned.
+ * seen_params / near_params: HOST arrays of 7 device pointers each, in DGL's GATv2Conv layout
+ * {fc_src.weight, fc_src.bias, fc_dst.weight, fc_dst.bias, attn, res_fc.weight, res_fc.bias (may be NULL)}, 16-byte
+ * aligned.  attn_save_* as in uavgnn_gatv2_fwd (NULL for inference).  `seen` runs on 16-edge MFMA row tiles per
+ * destination, `near` packs two destinations per row tile with [x_u ; x_v] in the K = 4 contraction (any in-degree is
+ * correct; <= 8 is one pass).  uavgnn_gatv2_hetero_supported: 1 when (F_seen, F_near, F_dst, nh, D) = (4, 2, 2, 4, 64),
+ * else callers use uavgnn_gatv2_fwd per relation (same results up to summation order). */
+int uavgnn_gatv2_hetero_supported(int F_seen, int F_near, int F_dst, int nh, int D);
+int uavgnn_gatv2_hetero_fwd(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order,
+                            const float* x_ubs, int E_near, const int32_t* near_off, const float* x_dst, int N,
+                            const float* const* seen_params, const float* const* near_params, int nh, int D, float slope,
+                            float* out, int ld_out, float* attn_save_seen, float* attn_save_near,
+                            uavgnn_stream_t stream);
+/* Same contract with only some phases of the kernel executed (bit 0: `seen` row tiles of the non-isolated destinations,
+ * bit 1: `near` + residual-only `seen` rows); phases = 3 is uavgnn_gatv2_hetero_fwd.  In-library ablation reference for
+ * benchmarks - output rows of the skipped phase are left untouched. */
+int uavgnn_gatv2_hetero_fwd_phases(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order,
+                                   const float* x_ubs, int E_near, const int32_t* near_off, const float* x_dst, int N,
+                                   const float* const* seen_params, const float* const* near_params, int nh, int D,
+                                   float slope, float* out, int ld_out, float* attn_save_seen, float* attn_save_near,
+                                   int phases, uavgnn_stream_t stream);
+
 /* K1 backward: parameter gradients only (observations are leaves: the reference never needs d/dx, Appendix A.4).
  * out / d_out are the forward output and its gradient (same ld).  Gradients are OVERWRITTEN.  Deterministic: per
  * workgroup partials in `workspace` are combined in a fixed order by a second launch (no float atomics).

@@ -1026,3 +1026,78 @@ def test_rccl_path_at_world_size_one_equals_the_non_distributed_step():
     _, same_loss, same_params, same_grads, loss_ref, loss = res
     assert same_loss and same_params and same_grads
     assert abs(loss - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))
+
+
+@pytest.mark.parametrize("B,n,M,dist,seed", [(16, 8, 80, "dense", 0), (64, 8, 80, "env", 1), (9, 5, 40, "ragged", 2),
+                                             (7, 16, 30, "ragged", 3), (1, 1, 12, "ragged", 4), (33, 3, 100, "env", 5)])
+def test_fused_hetero_k1_equals_per_relation_kernels(B, n, M, dist, seed):
+    """gatv2_hetero.hip (both relations, one launch; `near` two destinations per MFMA row tile with [x_u ; x_v] in the
+    K = 4 contraction) against the per-relation kernels on the same inputs: outputs, saved attention weights and - through
+    them - the parameter gradients.  Covers odd N (last pair half empty), near degrees above 8 (n = 16: two passes),
+    isolated `near` destinations, and destinations isolated in `seen` with / without a hand-out order."""
+    from uav_bs_ctrl_amd import ops
+    from uav_bs_ctrl_amd.agents.gnn_agents import GraphObservationEncoder
+    import types
+    g = synth_graph(B, n, M, dist, seed=seed)
+    N = B * n
+    if n > 2:      # make some `near` destinations isolated / low-degree: drop a random subset of near edges
+        gen = th.Generator().manual_seed(seed)
+        keep = th.rand(g["x_ubs"].shape[0], generator=gen) < 0.8
+        keep[: n - 1] = False                                 # destination 0 keeps nothing
+        deg = th.zeros(N, dtype=th.int64).index_add_(0, th.repeat_interleave(th.arange(N), n - 1), keep.long())
+        g["x_ubs"] = g["x_ubs"][keep]
+        g["near_off"] = th.cat([th.zeros(1, dtype=th.int64), th.cumsum(deg, 0)]).to(th.int32)
+    th.manual_seed(seed)
+    enc = GraphObservationEncoder(dict(agent=2, ubs=2, gt=4), types.SimpleNamespace(n_heads=4, hidden_size=256)).cuda()
+    with th.no_grad():
+        for p in enc.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * th.randn_like(p))
+    w = th.randn(N, 256, generator=th.Generator().manual_seed(7)).cuda()
+    res = {}
+    for fused in (True, False):
+        ops.HETERO_FUSED = fused
+        try:
+            hb = to_batch(g)
+            enc.zero_grad(set_to_none=True)
+            ops.KERNEL_TIMER.reset(enabled=True)
+            x = enc(hb)
+            names = set(ops.KERNEL_TIMER.summary())
+            ops.KERNEL_TIMER.enabled = False
+            assert ("gatv2_hetero_fwd" in names) == fused, names
+            (x * w).sum().backward()
+            with th.no_grad():
+                xi = enc(to_batch(g))                          # inference launch (no attention saving)
+            res[fused] = (x.detach(), xi, {k: p.grad.clone() for k, p in enc.named_parameters()})
+        finally:
+            ops.HETERO_FUSED = True
+    (xf, xif, gf), (xp, xip, gp) = res[True], res[False]
+    assert th.equal(xf, xif) and th.equal(xp, xip)
+    assert_close(xf, xp, 2e-6, "fused vs per-relation encoder output")
+    for k in gf:
+        assert_close(gf[k], gp[k], 2e-5, f"grad {k} through fused-forward attention weights", floor=1e-6)
+
+
+def test_fused_hetero_k1_raw_rows_vs_oracle():
+    """The [N, 2H] row block of the fused launch against the float64 oracle, relation by relation (before f_aggr)."""
+    from uav_bs_ctrl_amd import ops
+    from uav_bs_ctrl_amd.agents.gnn_agents import GATv2Conv
+    g = synth_graph(40, 8, 80, "ragged", seed=11)
+    hb = to_batch(g)
+    th.manual_seed(3)
+    convs = [GATv2Conv((4, 2), 64, 4).cuda(), GATv2Conv((2, 2), 64, 4).cuda()]
+    with th.no_grad():
+        for c in convs:
+            for p in c.parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * th.randn_like(p))
+    rels = []
+    for et, c in zip(("seen", "near"), convs):
+        xs, off = hb.relation_segments(et)
+        rels.append((xs, off, hb.relation_order(et), c))
+    with th.no_grad():
+        out = ops.hetero_gatv2(hb.agent_feat(), 4, rels)
+    for i, (et, kx, ko, c) in enumerate((("seen", "x_gt", "seen_off", convs[0]), ("near", "x_ubs", "near_off", convs[1]))):
+        p64 = {k: v.detach().cpu().double() for k, v in c.state_dict().items()}
+        ref = R.gatv2_conv_seg(g[kx].double(), g["x_a"].double(), g[ko], p64, 4).reshape(320, -1)
+        assert_close(out[:, 256 * i:256 * (i + 1)], ref, 1e-5, f"fused rows, relation {et}")

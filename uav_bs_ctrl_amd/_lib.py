@@ -29,6 +29,13 @@ SIGNATURES = {
                                        _c_fp, _c_fp, _c_int, _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_st]),
     "uavgnn_gatv2_fwd_mfma": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                        _c_fp, _c_fp, _c_int, _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_st]),
+    "uavgnn_gatv2_hetero_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "uavgnn_gatv2_hetero_fwd": (_c_int, [_c_fp, _c_int, _c_ip, _c_ip, _c_fp, _c_int, _c_ip, _c_fp, _c_int,
+                                         ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int,
+                                         _c_f32, _c_fp, _c_int, _c_fp, _c_fp, _c_st]),
+    "uavgnn_gatv2_hetero_fwd_phases": (_c_int, [_c_fp, _c_int, _c_ip, _c_ip, _c_fp, _c_int, _c_ip, _c_fp, _c_int,
+                                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _c_int,
+                                                _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_st]),
     "uavgnn_gatv2_bwd_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
     "uavgnn_gatv2_bwd": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                   _c_int, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
@@ -67,6 +74,7 @@ SIGNATURES = {
 }
 
 _LIB = None
+UAVGNN_EUNSUPPORTED = -1001
 
 
 class UavGnnError(RuntimeError):
@@ -104,6 +112,11 @@ def check(code: int, what: str) -> None:
 def ptr(t: th.Tensor | None):
     """Raw device pointer of a tensor (None -> NULL)."""
     return None if t is None else t.data_ptr()
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (NULL for None) for the entry points that take a parameter block."""
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
 def stream() -> int:

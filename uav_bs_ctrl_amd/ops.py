@@ -10,6 +10,7 @@ import torch as th
 from . import _lib as L
 
 NEG_SLOPE = 0.2  # DGL GATv2Conv default, not overridden at gnn_agents.py:93-96
+HETERO_FUSED = True   # K1 forward of both encoder relations in one launch (csrc/gatv2_hetero.hip); False: per relation
 
 
 class _KernelTimer:
@@ -75,6 +76,10 @@ class _HeteroGATv2(th.autograd.Function):
         D = H // nh
         out = th.empty((N, R * H), dtype=th.float32, device=x_dst.device)
         saved, meta, has_order = [x_dst], [], []
+        # both relations of the observation encoder in ONE launch when the shape has a fused instantiation
+        fused = (HETERO_FUSED and R == 2 and N > 0 and rel_args[4].shape[1] == 4 and rel_args[14].shape[1] == 2 and
+                 bool(L.lib().uavgnn_gatv2_hetero_supported(4, 2, x_dst.shape[1], nh, D)))
+        prepared = []
         for i in range(R):
             x_src, seg_off, order, attn, W_s, b_s, W_d, b_d, W_r, b_r = rel_args[i * 10:(i + 1) * 10]
             x_src = L.f32c(x_src)
@@ -87,15 +92,31 @@ class _HeteroGATv2(th.autograd.Function):
             # decides whether the attention weights are saved - a rollout / target-network forward must not pay for them
             need = train and any(ctx.needs_input_grad[3 + i * 10 + 3: 3 + i * 10 + 10])
             a_save = th.empty((max(x_src.shape[0], 1), nh), dtype=th.float32, device=x_dst.device) if need else None
-            with KERNEL_TIMER.span(f"gatv2_fwd[F={FS}]", (x_src.shape[0], N, int(need))):
-                rc = L.lib().uavgnn_gatv2_fwd(L.ptr(x_src), x_src.shape[0], FS, L.ptr(x_dst), x_dst.shape[1], L.ptr(seg_off),
-                                              L.ptr(order), N, *[L.ptr(t) for t in p], L.ptr(b_r_c), nh, D, NEG_SLOPE,
-                                              out.data_ptr() + 4 * i * H, R * H, L.ptr(a_save), L.stream())
-            L.check(rc, "uavgnn_gatv2_fwd")
+            prepared.append((x_src, seg_off, order, p, b_r_c, need, a_save, FS, b_r is not None))
+            fused = fused and all(t.data_ptr() % 16 == 0 for t in p + ([b_r_c] if b_r_c is not None else []))
+        if fused:
+            (xs, so, oo, pS, brS, needS, aS, _, _), (xn, no, _, pN, brN, needN, aN, _, _) = prepared
+            with KERNEL_TIMER.span("gatv2_hetero_fwd", (xs.shape[0], xn.shape[0], N, int(needS), int(needN))):
+                rc = L.lib().uavgnn_gatv2_hetero_fwd(L.ptr(xs), xs.shape[0], L.ptr(so), L.ptr(oo), L.ptr(xn), xn.shape[0],
+                                                     L.ptr(no), L.ptr(x_dst), N, L.ptr_array(pS + [brS]),
+                                                     L.ptr_array(pN + [brN]), nh, D, NEG_SLOPE, out.data_ptr(), R * H,
+                                                     L.ptr(aS), L.ptr(aN), L.stream())
+            if rc == L.UAVGNN_EUNSUPPORTED:
+                fused = False
+            else:
+                L.check(rc, "uavgnn_gatv2_hetero_fwd")
+        for i in range(R):
+            x_src, seg_off, order, p, b_r_c, need, a_save, FS, has_br = prepared[i]
+            if not fused:
+                with KERNEL_TIMER.span(f"gatv2_fwd[F={FS}]", (x_src.shape[0], N, int(need))):
+                    rc = L.lib().uavgnn_gatv2_fwd(L.ptr(x_src), x_src.shape[0], FS, L.ptr(x_dst), x_dst.shape[1],
+                                                  L.ptr(seg_off), L.ptr(order), N, *[L.ptr(t) for t in p], L.ptr(b_r_c), nh,
+                                                  D, NEG_SLOPE, out.data_ptr() + 4 * i * H, R * H, L.ptr(a_save), L.stream())
+                L.check(rc, "uavgnn_gatv2_fwd")
             saved += [x_src, seg_off, order if order is not None else seg_off, *p,
                       a_save if a_save is not None else x_dst]
             has_order.append(order is not None)
-            meta.append((FS, need, b_r is not None, has_order[-1]))
+            meta.append((FS, need, has_br, has_order[-1]))
         ctx.nh, ctx.meta, ctx.H = nh, meta, H
         ctx.save_for_backward(*saved, out)
         return out
