@@ -16,8 +16,8 @@ Such a cycle advances B*T environment steps, so  value = N * B * T * K / elapsed
 B per GPU fixed).  The simulator itself is out of scope: graphs are synthetic and resident in HBM
 before the timed region, exactly as the reference's sampled batch is when ``update`` starts its forward passes.
 
-Extra objects: ``roofline`` for the dominant message-passing kernel (K1 forward, `seen` relation), measured live with
-HIP events around every one of its launches inside the timed region - reported against the roof that binds at the
+Extra objects: ``roofline`` for the dominant message-passing kernel (K1 forward, BOTH relations in one fused launch),
+measured live with HIP events around every one of its launches inside the timed region - reported against the roof that binds at the
 launch mix's arithmetic intensity (fp32 MFMA peak for the dense workload, HBM for env-realistic degrees), with both
 fractions kept side by side (``hbm``, ``mfma_fp32``); ``cpu_baseline`` = the CPU oracle
 (oracle/restatement.py, kind "port": the reference's DGL path cannot run here or on the GPU box) timed on the host
@@ -97,37 +97,47 @@ def make_sequence(B, n, M, T, dist_name, device, seed, distinct):
     return batch
 
 
-def alg_bytes_k1_seen(E, N, training):
-    """ALGORITHMIC bytes / flops of one K1-forward launch on the `seen` relation:
-    16 B per edge (x_gt) + per agent 8 (x_a) + 4 (offset) + 4*H (output row) [+ 16 B per edge of saved attention
-    weights when the launch is part of a training forward]; 3360 flop per edge + 3584 per agent."""
-    b = 16 * E + N * (8 + 4 + 4 * 256)
-    if training:
-        b += 16 * E
-    return b, E * 3360 + N * 3584
+def alg_k1_fwd(E_s, E_n, N, save_s, save_n):
+    """ALGORITHMIC bytes / flops of one K1-forward launch over BOTH relations: per
+    `seen` edge 16 B (x_gt row) and 3360 flop, per `near` edge 8 B and 2320 flop, per agent 8 B (x_a) + 8 B (two
+    offsets) + 2048 B (the [2H] output row) and 7168 flop; + 16 B per edge of saved attention weights when the launch is
+    part of a training forward."""
+    b = 16 * E_s + 8 * E_n + N * (8 + 8 + 2048)
+    if save_s:
+        b += 16 * E_s
+    if save_n:
+        b += 16 * E_n
+    return b, 3360 * E_s + 2320 * E_n + 7168 * N
 
 
 def measured_traffic(dist_name, n_inf, n_tr, B, n, M):
-    """HBM bytes per K1-seen launch from the committed rocprofv3 PMC passes (profiles/r01_k1_fwd_traffic.json; method and
-    gfx950 correction are documented there), averaged over the inference/training launches of a step like
-    ``achieved``.  None when the workload is not the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_k1_fwd_traffic.json")
+    """HBM bytes per fused K1 launch from the committed rocprofv3 PMC passes (profiles/r02_k1_hetero_traffic.json; method
+    and gfx950 correction are documented there), averaged over the inference / training launches of a step like
+    ``achieved``.  (None, None) when the workload is not the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r02_k1_hetero_traffic.json")
     if not os.path.exists(path) or (B, n, M) != (4096, 8, 80):
-        return None
+        return None, None
     t = json.load(open(path)).get(dist_name)
     if not t:
-        return None
+        return None, None
     by = {k: (2.0 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0 for k, v in t.items()}
-    return (n_inf * by["inference"] + n_tr * by["training"]) / (n_inf + n_tr)
+    src = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/k1_run.py on this workload, stamped in "
+           "profiles/r02_k1_hetero_traffic.json (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not "
+           "collected inside this run")
+    return (n_inf * by["inference"] + n_tr * by["training"]) / (n_inf + n_tr), src
 
 
-def cpu_baseline(n, M, T_s=2, budget_s=20.0):
-    """The oracle timed on the host cores, on a bounded sample of the same cycle (T_s rollout forwards + one update on
-    B_s sequences of T_s steps).  B_s is calibrated so that the whole leg stays within ~budget_s seconds."""
+def cpu_baseline(n, M, dist_name, T_s=2, budget_s=24.0):
+    """The oracle timed on the host cores (SURVEY 8d protocol) on a bounded sample of the same cycle - T_s rollout
+    forwards + one update (2 T_s + 1 forwards + BPTT backward) on B_s env graphs of the SAME degree distribution as the
+    GPU leg: per thread count 2 warm-ups + median of 5 timed cycles, swept over {1, 8, 32, all} host threads; ``value`` is
+    the best multi-thread figure (``cores`` = its thread count), the 1-thread figure and the whole sweep are reported
+    next to it.  B_s is calibrated per thread count so that the leg stays within ~budget_s seconds."""
+    import statistics
+
     from oracle import restatement as R
     from uav_bs_ctrl_amd import GnnAgent
-    threads = min(os.cpu_count() or 1, 32)   # more threads than this only adds contention on these small ops
-    th.set_num_threads(threads)
+    ncpu = os.cpu_count() or 1
     cfg = dict(enc="gnn", c="tarmac", n_heads=4, key_size=16, msg_size=64, n_rounds=1, dueling=False)
     net = GnnAgent(dict(agent=2, ubs=2, gt=4), 9, exp3_args("cpu"))
     p = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
@@ -136,12 +146,20 @@ def cpu_baseline(n, M, T_s=2, budget_s=20.0):
 
     def make(B_s):
         N = B_s * n
-        Es, En = N * M, N * (n - 1)
+        En = N * (n - 1)
         base = (th.arange(N) // n * n).repeat_interleave(n)
 
         def graph():
-            return dict(x_a=th.rand(N, 2, generator=gen), x_gt=th.rand(Es, 4, generator=gen) * 2 - 1,
-                        seen_off=th.arange(0, Es + 1, M, dtype=th.int32),
+            if dist_name == "dense":
+                d_seen = th.full((N,), M, dtype=th.int64)
+            else:   # D-env: no GT in sight w.p. 0.94, else U{1..0.65 M}
+                hi = max(1, int(0.65 * M))
+                d_seen = th.where(th.rand(N, generator=gen) < 0.94, th.zeros(N, dtype=th.int64),
+                                  th.randint(1, hi + 1, (N,), generator=gen))
+            so = th.zeros(N + 1, dtype=th.int32)
+            so[1:] = th.cumsum(d_seen, 0)
+            Es = int(so[-1])
+            return dict(x_a=th.rand(N, 2, generator=gen), x_gt=th.rand(Es, 4, generator=gen) * 2 - 1, seen_off=so,
                         x_ubs=th.rand(En, 2, generator=gen) * 2 - 1,
                         near_off=th.arange(0, En + 1, n - 1, dtype=th.int32),
                         talk_off=th.arange(0, N * n + 1, n, dtype=th.int32),
@@ -164,25 +182,37 @@ def cpu_baseline(n, M, T_s=2, budget_s=20.0):
         cycle()
         return time.perf_counter() - t0
 
-    B_s = 8
-    c = make(B_s)
-    timed(c)                      # warm-up (thread pool, allocator)
-    dt = timed(c)
-    spent = 2 * dt
-    while B_s < 256 and dt * 4 * 2.5 < budget_s - spent:   # grow the sample while 2 more cycles still fit
-        B_s *= 4
+    counts = sorted({c for c in (1, 8, 32, ncpu) if c <= ncpu})
+    per_count_budget = budget_s / len(counts)
+    sweep = {}
+    for threads in counts:
+        th.set_num_threads(threads)
+        t_start = time.perf_counter()
+        B_s = 2
         c = make(B_s)
-        dt = timed(c)
-        spent += dt
-    reps = 1
-    if dt * 1.2 < budget_s - spent:
-        dt = min(dt, timed(c))
-        reps = 2
-    return dict(value=B_s * T_s / dt, unit="env-steps/s", cores=threads, kind="port",
-                sample=f"oracle/restatement.py (PyTorch CPU fp32, {threads} of {os.cpu_count()} host threads): best of "
-                       f"{reps} cycle(s) of {T_s} rollout forwards + 1 update ({2 * T_s + 1} forwards + BPTT "
-                       f"backward) on {B_s} env graphs of {n}x{M} dense; the reference's DGL path is not installable "
-                       f"on either box", sec_per_cycle=dt)
+        timed(c)                                            # warm-up 1 (thread pool, allocator)
+        dt = timed(c)                                       # warm-up 2, doubles as the calibration probe
+        # grow the sample while 2 warm-ups + 5 timed cycles at twice the size still fit into this thread count's share
+        while B_s < 512 and 2.0 * dt * 7.5 < per_count_budget - (time.perf_counter() - t_start):
+            B_s *= 2
+            c = make(B_s)
+            timed(c)
+            dt = timed(c)
+        ts = [timed(c) for _ in range(5)]
+        med = statistics.median(ts)
+        sweep[str(threads)] = dict(env_steps_per_s=B_s * T_s / med, sec_per_cycle_median=med, env_graphs=B_s,
+                                   sec_min=min(ts), sec_max=max(ts))
+    multi = {k: v for k, v in sweep.items() if int(k) > 1} or sweep
+    best = max(multi, key=lambda k: multi[k]["env_steps_per_s"])
+    return dict(value=sweep[best]["env_steps_per_s"], unit="env-steps/s", cores=int(best), kind="port",
+                host_threads_available=ncpu, one_thread=sweep["1"]["env_steps_per_s"], thread_sweep=sweep,
+                protocol="per thread count: 2 warm-up cycles, median of 5 timed cycles; value = best multi-thread count",
+                torch_parallel_info=th.__config__.parallel_info().split("\n")[0],
+                sample=f"oracle/restatement.py (PyTorch CPU fp32): cycles of {T_s} rollout forwards + 1 update "
+                       f"({2 * T_s + 1} forwards + BPTT backward) on {sweep[best]['env_graphs']} env graphs of {n}x{M}, "
+                       f"D-{dist_name} degrees (same distribution as the GPU leg); the reference's real DGL-CPU path is "
+                       f"not installable on either box, so this is the build's CPU restatement (kind 'port')",
+                sec_per_cycle=sweep[best]["sec_per_cycle_median"])
 
 
 def main():
@@ -284,33 +314,31 @@ def main():
             "loss": loss,
             "step_ms_device": [round(marks[i - 1].elapsed_time(marks[i]), 1) for i in range(1, len(marks))],
         }
-        # ---- roofline of the dominant message-passing kernel (K1 forward, seen relation) -------------------------
+        # ---- roofline of the dominant message-passing kernel: K1 forward, BOTH relations (one fused launch) ----------
         ktimes = ops.KERNEL_TIMER.summary()
-        k = ktimes.get("gatv2_fwd[F=4]")
+        k = ktimes.get("gatv2_hetero_fwd")
         if k:
-            # every K1-seen launch of the timed region (rollout launches over N_a destinations, the two time-batched
-            # encoder launches of the update over (T+1) N_a / T N_a): achieved = sum(bytes) / sum(time)
-            tot_b = tot_f = 0
-            for (E, N, tr) in k["work"]:
-                b_, f_ = alg_bytes_k1_seen(E, N, tr)
-                tot_b, tot_f = tot_b + b_, tot_f + f_
+            # every K1 launch of the timed region (rollout launches over N_a destinations, the two time-batched encoder
+            # launches of the update over (T+1) N_a / T N_a): achieved = sum(bytes) / sum(time)
+            work = [(Es, En, N, ss, sn) for (Es, En, N, ss, sn) in k["work"]]
+            tot_b = sum(alg_k1_fwd(*w)[0] for w in work)
+            tot_f = sum(alg_k1_fwd(*w)[1] for w in work)
             sec = k["total_ms"] * 1e-3
             ach = tot_b / sec / 1e9
-            # the same figure per launch class: rollout launches (one env-step batch) vs time-batched update launches
             by_class = {}
             for cls, sel in (("rollout", lambda N: N <= a.B * a.n), ("update_time_batched", lambda N: N > a.B * a.n)):
-                ms_c = [m for m, (E, N, tr) in zip(k["ms"], k["work"]) if sel(N)]
-                by_c = [alg_bytes_k1_seen(E, N, tr)[0] for (E, N, tr) in k["work"] if sel(N)]
-                fl_c = [alg_bytes_k1_seen(E, N, tr)[1] for (E, N, tr) in k["work"] if sel(N)]
+                ms_c = [m for m, w in zip(k["ms"], work) if sel(w[2])]
+                by_c = [alg_k1_fwd(*w)[0] for w in work if sel(w[2])]
+                fl_c = [alg_k1_fwd(*w)[1] for w in work if sel(w[2])]
                 if ms_c:
                     g = sum(by_c) / (sum(ms_c) * 1e-3) / 1e9
                     tf = sum(fl_c) / (sum(ms_c) * 1e-3) / 1e12
                     by_class[cls] = {"launches": len(ms_c), "avg_launch_ms": sum(ms_c) / len(ms_c), "achieved": g,
                                      "frac": g / HBM_PEAK_GBS, "hbm_frac": g / HBM_PEAK_GBS, "tflops": tf,
                                      "mfma_fp32_frac": tf / FP32_PEAK_TFLOPS}
-            n_units = sum(N for _, N, _ in k["work"]) / (a.B * a.n)        # launches in units of one env-step batch
-            n_tr = sum(N for _, N, tr in k["work"] if tr) / (a.B * a.n)
-            traffic = measured_traffic(a.dist, n_units - n_tr, n_tr, a.B, a.n, a.M)
+            n_units = sum(w[2] for w in work) / (a.B * a.n)                # launches in units of one env-step batch
+            n_tr = sum(w[2] for w in work if w[3]) / (a.B * a.n)
+            traffic, traffic_src = measured_traffic(a.dist, n_units - n_tr, n_tr, a.B, a.n, a.M)
             tfl = tot_f / sec / 1e12
             # The roof that binds is the lower one at this launch mix's arithmetic intensity (classic roofline):
             # AI = algorithmic FLOP / algorithmic byte vs the machine balance fp32-MFMA peak / HBM peak (~19.7 FLOP/B).
@@ -320,10 +348,12 @@ def main():
             mfma = {"achieved": tfl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP32_PEAK_TFLOPS}
             bound = "mfma" if ai > balance else "hbm"
             top = mfma if bound == "mfma" else hbm
-            res["roofline"] = {"bound": bound, "kernel": "gatv2_fwd_mfma_kernel<4,64> (K1 forward, seen relation)",
+            res["roofline"] = {"bound": bound,
+                               "kernel": "gatv2_hetero_fwd_kernel (K1 forward, `seen` + `near` relations in one launch)",
                                "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
                                "frac": top["frac"],
                                "traffic": None if traffic is None else traffic * n_units / k["count"],
+                               "traffic_source": traffic_src,
                                "arithmetic_intensity": ai, "machine_balance": balance,
                                "hbm": hbm, "mfma_fp32": mfma,
                                "avg_launch_ms": k["avg_ms"], "launches": k["count"],
@@ -338,7 +368,7 @@ def main():
                                         "bound by HBM (output-row writes)")}
         res["kernel_ms_per_launch"] = {n: round(v["avg_ms"], 4) for n, v in ktimes.items()}
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.n, a.M)
+            res["cpu_baseline"] = cpu_baseline(a.n, a.M, a.dist)
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()

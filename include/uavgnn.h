@@ -237,6 +237,16 @@ int uavgnn_csc_transpose(const int32_t* talk_off, const int32_t* talk_src, int N
 int uavgnn_csc_transpose_env(const int32_t* talk_off, const int32_t* talk_src, const int32_t* graph_off, int B, int N,
                              int32_t* t_off, int32_t* t_dst, int32_t* t_pos, uavgnn_stream_t stream);
 
+/* Tail of the learner's update in one launch over FLAT fp32 buffers of n elements (reference:
+ * algos/madrqn/learner.py:157-166): g[i] clamped to [-clip, clip] for i < n_clip (clip_grad_value_ on the policy network
+ * only; clip <= 0: none; the clamped gradient is written back), torch.optim.AdamW step on (p, exp_avg, exp_avg_sq) with
+ * decoupled weight decay, then p_targ <- polyak p_targ + (1 - polyak) p (p_targ may be NULL).  hyper: DEVICE array
+ * {lr, t} (t = 1-based count of this step) so that a captured graph replays with current values.  16-byte aligned
+ * buffers. */
+int uavgnn_adamw_polyak(float* p, float* g, float* exp_avg, float* exp_avg_sq, float* p_targ, long long n,
+                        long long n_clip, const float* hyper, float beta1, float beta2, float eps, float weight_decay,
+                        float clip, float polyak, uavgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1101,3 +1101,67 @@ def test_fused_hetero_k1_raw_rows_vs_oracle():
         p64 = {k: v.detach().cpu().double() for k, v in c.state_dict().items()}
         ref = R.gatv2_conv_seg(g[kx].double(), g["x_a"].double(), g[ko], p64, 4).reshape(320, -1)
         assert_close(out[:, 256 * i:256 * (i + 1)], ref, 1e-5, f"fused rows, relation {et}")
+
+
+def test_fused_adamw_clip_polyak_kernel_matches_torch_and_checkpoints_interchange():
+    """uavgnn_adamw_polyak over flat buffers == clip_grad_value_ + torch.optim.AdamW.step + the polyak loop of
+    learner.py:157-166, over several steps with a changing learning rate (LambdaLR), odd sizes (tail path, padding) and a
+    clip boundary inside the buffer; FusedAdamW's state_dict loads into torch.optim.AdamW and vice versa."""
+    import torch.nn as nn
+    from uav_bs_ctrl_amd.learner import FlatGradBuffer
+    from uav_bs_ctrl_amd.optim import FlatParams, FusedAdamW
+
+    def make():
+        th.manual_seed(5)
+        a = nn.Sequential(nn.Linear(7, 13), nn.Linear(13, 3)).cuda()       # odd sizes: 91+13+39+3
+        b = nn.Linear(5, 9).cuda()                                          # "mixer": not clipped
+        return a, b
+    (pa, pb), (ta, tb), (ra, rb), (rta, rtb) = make(), make(), make(), make()
+    fp = FlatParams([pa, pb])
+    tflat = fp.mirror([ta, tb])
+    grads = FlatGradBuffer(fp.params, fp.index_of, fp.numel)
+    opt = FusedAdamW(fp, grads.flat, lr=3e-3, clip=0.05, n_clip=fp.span(1), target_flat=tflat, polyak=0.9)
+    sched = th.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: max(0.4, 1 - e / 4))
+    rparams = list(ra.parameters()) + list(rb.parameters())
+    ropt = th.optim.AdamW(rparams, lr=3e-3)
+    rsched = th.optim.lr_scheduler.LambdaLR(ropt, lr_lambda=lambda e: max(0.4, 1 - e / 4))
+    gen = th.Generator(device="cuda").manual_seed(1)
+    for it in range(6):
+        gs = [0.2 * th.randn(p.shape, device="cuda", generator=gen) for p in rparams]
+        grads.zero_()
+        for p, g_ in zip(fp.params, gs):
+            p.grad.copy_(g_)
+        for p, g_ in zip(rparams, gs):
+            p.grad = g_.clone()
+        opt.step()
+        nn.utils.clip_grad_value_(ra.parameters(), 0.05)
+        ropt.step()
+        with th.no_grad():
+            for p, pt in zip(rparams, list(rta.parameters()) + list(rtb.parameters())):
+                pt.data.mul_(0.9)
+                pt.data.add_((1 - 0.9) * p.data)
+        sched.step(), rsched.step()
+        for p, q in zip(fp.params, rparams):
+            assert_close(p, q, 2e-6, f"param after step {it}", floor=1e-7)
+            assert_close(p.grad, q.grad, 1e-7, "clipped gradient written back")
+        for p, q in zip(list(ta.parameters()) + list(tb.parameters()), list(rta.parameters()) + list(rtb.parameters())):
+            assert_close(p, q, 2e-6, f"target after step {it}", floor=1e-7)
+    assert fp.intact() and abs(opt.param_groups[0]["lr"] - ropt.param_groups[0]["lr"]) < 1e-12
+    # checkpoints: fused -> torch and torch -> fused continue identically
+    import copy
+    sd_f, sd_r = copy.deepcopy(opt.state_dict()), copy.deepcopy(ropt.state_dict())   # what torch.save / load would hand over
+    assert set(sd_f["state"][0]) == set(sd_r["state"][0]) and float(sd_f["state"][0]["step"]) == 6.0
+    ropt2 = th.optim.AdamW(rparams, lr=1.0)
+    ropt2.load_state_dict(sd_f)
+    opt.load_state_dict(sd_r)
+    gs = [0.2 * th.randn(p.shape, device="cuda", generator=gen) for p in rparams]
+    grads.zero_()
+    for p, g_ in zip(fp.params, gs):
+        p.grad.copy_(g_)
+    for p, g_ in zip(rparams, gs):
+        p.grad = g_.clone()
+    opt.step()
+    nn.utils.clip_grad_value_(ra.parameters(), 0.05)
+    ropt2.step()
+    for p, q in zip(fp.params, rparams):
+        assert_close(p, q, 2e-6, "param after checkpoint interchange", floor=1e-7)

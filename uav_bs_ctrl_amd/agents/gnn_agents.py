@@ -133,32 +133,41 @@ class TarMAC(nn.Module):
 
     def fused_projection(self):
         """[f_val; f_sign; f_que] as ONE [M+2K, 2H] weight (+ bias) without a per-call ``cat``: the three Linear layers'
-        parameters are re-pointed (``p.data = view``) at row blocks of one stacked buffer, so the stack IS their
-        storage.  Every in-place update - optimizer steps, ``p.data.mul_()/.add_()`` polyak averaging as the
-        reference's learner does it (learner.py:165-166, which bumps no version counter), ``load_state_dict`` - lands in
-        the stack by construction; anything that REPLACES a parameter's storage (``module.to()``, ``p.data = ...``,
-        deepcopy) is caught by the pointer check below and the stack is rebuilt from the current values.  The stacked
-        tensors carry no autograd history: the fused step (ops.tarmac_step) returns / sinks the gradient of the stack
-        and splits it back itself."""
+        parameters live back to back in one buffer - either the learner's flat parameter buffer (optim.FlatParams lays
+        the members of ``_projection_params()`` out consecutively) or a private stack this method creates by re-pointing
+        them (``p.data = view``) - and the stacked tensors are strided views of that memory.  Every in-place update -
+        optimizer steps, ``p.data.mul_()/.add_()`` polyak averaging as the reference's learner does it
+        (learner.py:165-166, which bumps no version counter), ``load_state_dict`` - is seen by construction; anything
+        that REPLACES a parameter's storage (``module.to()``, ``p.data = ...``, deepcopy) breaks the adjacency, which
+        the pointer check below detects, and the stack is rebuilt from the current values.  The stacked tensors carry no
+        autograd history: the fused step (ops.tarmac_step) returns / sinks the gradient of the stack and splits it
+        back itself."""
         ws, bs = self._projection_params()
-        st = getattr(self, "_stacked", None)
-        if st is not None:
-            Wst, bst = st
-            ok, r = Wst.device == ws[0].device and Wst.dtype == ws[0].dtype, 0
-            for w, b in zip(ws, bs):
-                ok = ok and w.data_ptr() == Wst.data_ptr() + r * Wst.stride(0) * Wst.element_size() \
-                    and b.data_ptr() == bst.data_ptr() + r * bst.element_size() and w.is_contiguous()
-                r += w.shape[0]
-            if ok:
-                return st
-        with th.no_grad():
-            Wst, bst = th.cat([w.detach() for w in ws], 0), th.cat([b.detach() for b in bs], 0)
-            r = 0
-            for w, b in zip(ws, bs):
-                w.data = Wst[r:r + w.shape[0]]
-                b.data = bst[r:r + b.shape[0]]
-                r += w.shape[0]
-        self._stacked = (Wst, bst)
+
+        def adjacent(ts):
+            nxt = ts[0].data_ptr()
+            for t in ts:
+                if t.data_ptr() != nxt or not t.is_contiguous() or t.dtype != ts[0].dtype or t.device != ts[0].device:
+                    return False
+                nxt += t.numel() * t.element_size()
+            end = ts[0].untyped_storage().data_ptr() + ts[0].untyped_storage().nbytes()
+            return nxt <= end and all(t.untyped_storage().data_ptr() == ts[0].untyped_storage().data_ptr() for t in ts)
+
+        if not (adjacent(ws) and adjacent(bs)):
+            with th.no_grad():
+                Wst, bst = th.cat([w.detach() for w in ws], 0), th.cat([b.detach() for b in bs], 0)
+                r = 0
+                for w, b in zip(ws, bs):
+                    w.data = Wst[r:r + w.shape[0]]
+                    b.data = bst[r:r + b.shape[0]]
+                    r += w.shape[0]
+        key = (ws[0].data_ptr(), bs[0].data_ptr(), ws[0].dtype)
+        if getattr(self, "_stacked_key", None) != key:
+            rows = sum(w.shape[0] for w in ws)
+            w0, b0 = ws[0].data, bs[0].data
+            self._stacked = (w0.as_strided((rows, w0.shape[1]), (w0.shape[1], 1), w0.storage_offset()),
+                             b0.as_strided((rows,), (1,), b0.storage_offset()))
+            self._stacked_key = key
         return self._stacked
 
     def forward(self, g, x, h):

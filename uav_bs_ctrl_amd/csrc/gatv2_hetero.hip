@@ -102,6 +102,9 @@ struct RelParams {   // one GATv2Conv: fc_src, fc_dst, attn, res_fc (DGL layout,
 
 // The MFMA + |z| FMA block shared by both phases: 16 channel tiles of one row tile -> log2-domain score of
 // (column j, head g) in every lane, up to a per-(destination, head) constant that cancels in the softmax.
+// The instruction order is PINNED (sched_barrier): MFMA ct+1 is issued, then the four |z| FMAs of tile ct run in its
+// shadow.  Left to itself hipcc hoists / sinks the FMAs around the MFMAs and the tile takes ~10 % longer
+// (tools/ubench/tile_sched.hip: 510 vs 455-463 ns per tile per SIMD at two waves per SIMD).
 #define UAVGNN_TILE_SCORE(WA, ATT, CINIT, WLIN, XB, E_OUT)                                              \
   {                                                                                                     \
     float pe[NH][2];                                                                                    \
@@ -109,13 +112,21 @@ struct RelParams {   // one GATv2Conv: fc_src, fc_dst, attn, res_fc (DGL layout,
       pe[k][0] = WLIN[k] * (XB);                                                                        \
       pe[k][1] = 0.f;                                                                                   \
     }                                                                                                   \
+    f32x4 z_cur = __builtin_amdgcn_mfma_f32_16x16x4f32(WA[0], (XB), CINIT[0], 0, 0, 0);                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
     _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                 \
-      const f32x4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(WA[ct], (XB), CINIT[ct], 0, 0, 0);           \
+      f32x4 z_nxt = z_cur;                                                                              \
+      if (ct + 1 < CT) {                                                                                \
+        z_nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(WA[ct + 1], (XB), CINIT[ct + 1], 0, 0, 0);         \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+      }                                                                                                 \
       const int k = ct / TPH;                                                                           \
-      pe[k][0] = fmaf(ATT[ct][0], fabsf(z[0]), pe[k][0]);                                               \
-      pe[k][1] = fmaf(ATT[ct][1], fabsf(z[1]), pe[k][1]);                                               \
-      pe[k][0] = fmaf(ATT[ct][2], fabsf(z[2]), pe[k][0]);                                               \
-      pe[k][1] = fmaf(ATT[ct][3], fabsf(z[3]), pe[k][1]);                                               \
+      pe[k][0] = fmaf(ATT[ct][0], fabsf(z_cur[0]), pe[k][0]);                                           \
+      pe[k][1] = fmaf(ATT[ct][1], fabsf(z_cur[1]), pe[k][1]);                                           \
+      pe[k][0] = fmaf(ATT[ct][2], fabsf(z_cur[2]), pe[k][0]);                                           \
+      pe[k][1] = fmaf(ATT[ct][3], fabsf(z_cur[3]), pe[k][1]);                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+      z_cur = z_nxt;                                                                                    \
     }                                                                                                   \
     E_OUT = reduce_heads(pe[0][0] + pe[0][1], pe[1][0] + pe[1][1], pe[2][0] + pe[2][1], pe[3][0] + pe[3][1]); \
   }

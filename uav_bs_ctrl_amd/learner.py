@@ -30,26 +30,30 @@ from .agents import REGISTRY as agent_REGISTRY
 
 class FlatGradBuffer:
     """All gradients of a module as views into one contiguous fp32 buffer (one collective instead of one per tensor;
-    the reference's unused helper all-reduces per parameter: utils/mpi_pytorch.py:19-26)."""
+    the reference's unused helper all-reduces per parameter: utils/mpi_pytorch.py:19-26).  ``offsets`` / ``numel``: the
+    layout of an ``optim.FlatParams`` (gradient i sits where parameter i sits); default: densely packed."""
 
-    def __init__(self, params: List[th.nn.Parameter]):
+    def __init__(self, params: List[th.nn.Parameter], offsets: Optional[List[int]] = None, numel: Optional[int] = None):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        if offsets is None:
+            offsets, o = [], 0
+            for p in self.params:
+                offsets.append(o)
+                o += p.numel()
+            numel = o
+        assert len(offsets) == len(self.params)
+        self.offsets = list(offsets)
         dev = self.params[0].device
-        self.flat = th.zeros(n, dtype=th.float32, device=dev)
+        self.flat = th.zeros(numel, dtype=th.float32, device=dev)
         self.force_collective = False   # run the collective even at world size 1 (RCCL smoke test / bench --force-dist)
-        o = 0
-        for p in self.params:
+        for p, o in zip(self.params, self.offsets):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
-            o += p.numel()
 
     def zero_(self):
         self.flat.zero_()
-        o = 0
-        for p in self.params:   # re-attach (an optimizer's zero_grad(set_to_none=True) would detach the views)
+        for p, o in zip(self.params, self.offsets):   # re-attach (zero_grad(set_to_none=True) would detach the views)
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
                 p.grad = self.flat[o:o + p.numel()].view_as(p)
-            o += p.numel()
 
     def all_reduce_mean_(self, group=None):
         if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.force_collective):
@@ -106,7 +110,22 @@ class MultiAgentQLearner:
         self.gamma, self.polyak = args.gamma, args.polyak
         self.batch_size = getattr(args, "batch_size", None)
         self.double_q = args.double_q
-        self.optimizer = th.optim.AdamW(self.params, lr=args.lr)
+        self.n_policy = sum(p.numel() for p in self.policy_net.parameters())
+        self.fused_tail = self.device.type == "cuda"
+        if self.fused_tail:
+            # parameters, gradients, Adam moments and the target network as views of flat buffers: the update's tail
+            # (clip + AdamW + polyak) is ONE launch, the DP exchange ONE all-reduce (uav_bs_ctrl_amd/optim.py)
+            from .optim import FlatParams, FusedAdamW
+            mods = [self.policy_net] + ([self.mixer] if self.mixer is not None else [])
+            tmods = [self.target_net] + ([self.target_mixer] if self.mixer is not None else [])
+            self.flat = FlatParams(mods)
+            self.flat_target = self.flat.mirror(tmods)
+            self.grads = FlatGradBuffer(self.flat.params, self.flat.index_of, self.flat.numel)
+            self.optimizer = FusedAdamW(self.flat, self.grads.flat, lr=args.lr, clip=1.0, n_clip=self.flat.span(1),
+                                        target_flat=self.flat_target, polyak=args.polyak)
+        else:       # host-side harness (CPU tests of the data-parallel logic): stock optimizer, same arithmetic
+            self.optimizer = th.optim.AdamW(self.params, lr=args.lr)
+            self.grads = FlatGradBuffer(self.params)
         # lr annealing (learner.py:51-54; `anneal_lr` defaults to True in madrqn/config.py:36): the caller steps
         # ``learner.lr_scheduler`` once per epoch as run.py:107-108 does.  (The reference passes verbose=True, which
         # torch >= 2.7 rejects; the schedule itself is identical.)
@@ -114,8 +133,6 @@ class MultiAgentQLearner:
         if self.anneal_lr:
             self.lr_scheduler = th.optim.lr_scheduler.LambdaLR(self.optimizer,
                                                                lr_lambda=lambda epoch: max(0.4, 1 - epoch / 100))
-        self.grads = FlatGradBuffer(self.params)
-        self.n_policy = sum(p.numel() for p in self.policy_net.parameters())
         self._gen = th.Generator(device=self.device)
         self._gen.manual_seed(int(getattr(args, "seed", 0)) + 7919 * (dist.get_rank() if dist.is_initialized() else 0))
 
@@ -220,6 +237,14 @@ class MultiAgentQLearner:
         finally:
             ops.GRAD_SINK = None
         self.grads.all_reduce_mean_(self.group)           # the only collective of the data path
+        if self.fused_tail:
+            # clip_grad_value_(policy_net.parameters(), 1) (the mixer is NOT clipped, learner.py:159) + AdamW step +
+            # polyak of target net / target mixer (learner.py:157-166): one launch over the flat buffers
+            if not self.flat.intact():
+                raise L.UavGnnError("a parameter was moved out of the learner's flat buffer (module.to() / p.data = ... "
+                                    "after the learner was built): rebuild the learner")
+            self.optimizer.step()
+            return dict(LossQ=loss.detach(), QVals=agent_out.detach())
         # == nn.utils.clip_grad_value_(policy_net.parameters(), 1): the mixer is NOT clipped (learner.py:159)
         self.grads.flat[:self.n_policy].clamp_(-1.0, 1.0)
         self.optimizer.step()
