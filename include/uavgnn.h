@@ -184,6 +184,10 @@ int uavgnn_talk_compact(const float* d_u2u, int n, int B, float r_comm, const in
  */
 int uavgnn_eps_greedy(const float* q, int ld_q, int N, int A, int n_agents, const float* u_team, const float* u_agent,
                       float eps, long long* acts, uavgnn_stream_t stream);
+/* Same with the exploration rate read from DEVICE memory (*eps_dev) at execution time, so that a hipGraph captured around
+ * the rollout step replays with the current epsilon of the schedule (algos/madrqn/run.py:60-61). */
+int uavgnn_eps_greedy_dev(const float* q, int ld_q, int N, int A, int n_agents, const float* u_team, const float* u_agent,
+                          const float* eps_dev, long long* acts, uavgnn_stream_t stream);
 
 /* ---- bias gradients ---------------------------------------------------------------------------------------------
  * acc[s, :] += column sums of the rows [s*R, (s+1)*R) of x[N, C] (row stride ld, unit column stride), R = ceil(N / S).

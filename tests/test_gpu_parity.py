@@ -1165,3 +1165,87 @@ def test_fused_adamw_clip_polyak_kernel_matches_torch_and_checkpoints_interchang
     ropt2.step()
     for p, q in zip(fp.params, rparams):
         assert_close(p, q, 2e-6, "param after checkpoint interchange", floor=1e-7)
+
+
+def _padded_obs(gen, lead, n, M, dev):
+    gt = th.rand(*lead, n, M, 5, device=dev, generator=gen) * 2 - 1
+    gt[..., 0] = (th.rand(*lead, n, M, device=dev, generator=gen) < 0.3).float()
+    ub = th.rand(*lead, n, n - 1, 3, device=dev, generator=gen) * 2 - 1
+    ub[..., 0] = (th.rand(*lead, n, n - 1, device=dev, generator=gen) < 0.6).float()
+    d = th.rand(*lead, n, n, device=dev, generator=gen) * 2
+    d = (d + d.transpose(-1, -2)) / 2 * (1 - th.eye(n, device=dev))
+    return gt, ub, th.rand(*lead, n, 2, device=dev, generator=gen), d
+
+
+def _graph_learner(n, T, seed=0):
+    import types
+    from uav_bs_ctrl_amd.learner import MultiAgentQLearner
+    args = types.SimpleNamespace(device="cuda", hidden_size=256, c="tarmac", n_heads=4, n_layers=1, msg_size=64, key_size=16,
+                                 n_rounds=1, dueling=False, mixer=False, double_q=True, lr=1e-3, gamma=0.99, polyak=0.99,
+                                 max_seq_len=T, seed=0)
+    th.manual_seed(seed)
+    return MultiAgentQLearner(dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=9, n_agents=n, episode_limit=T), args)
+
+
+def test_graphed_act_replays_the_eager_rollout_step():
+    """hipGraph capture of learner.act (device graph builder in static mode + no-grad policy forward + selection with the
+    exploration rate in device memory): replays on NEW observations equal the eager step on the same observations."""
+    from uav_bs_ctrl_amd import from_padded_obs
+    from uav_bs_ctrl_amd.graphs import GraphedAct
+    dev, (B, n, M) = th.device("cuda"), (3, 8, 50)
+    L = _graph_learner(n, 5)
+    ga = GraphedAct(L, B, n, M, r_comm=1.2)
+    gen = th.Generator(device=dev).manual_seed(4)
+    h = 0.1 * th.randn(B * n, 256, device=dev, generator=gen)
+    for it in range(3):
+        gt, ub, ag, d = _padded_obs(gen, (B,), n, M, dev)
+        acts, h2 = ga(gt, ub, ag, d, h, 0.0)
+        g = from_padded_obs(gt, ub, ag, d, 1.2)
+        acts_e, h2_e = L.act(g, h, 0.0)
+        assert th.equal(acts, acts_e), it
+        assert_close(h2, h2_e, 1e-6, f"h' replay {it}")
+        h = h2.clone()
+    acts_r, _ = ga(gt, ub, ag, d, h, 1.0)                       # everyone explores: uniform random actions
+    a1 = acts_r.clone()
+    acts_r, _ = ga(gt, ub, ag, d, h, 1.0)
+    assert int(a1.min()) >= 0 and int(a1.max()) < 9 and not th.equal(a1, acts_r)   # fresh randomness every replay
+
+
+def test_graphed_update_replays_the_eager_update():
+    """hipGraph capture of the WHOLE update (device graph builder for all T+1 steps, time-batched encoder, 2T+1
+    forwards, BPTT backward, clip + AdamW + polyak in one launch): two replays on two sampled batches leave the same
+    loss, policy and target parameters as two eager updates of an identical learner on the same batches."""
+    from uav_bs_ctrl_amd import batch as hb_batch
+    from uav_bs_ctrl_amd.graphs import GraphedUpdate
+    from uav_bs_ctrl_amd.replay import SequenceReplay
+    dev, (E, n, M, T, Bs) = th.device("cuda"), (12, 4, 30, 4, 6)
+    L1, L2 = _graph_learner(n, T, seed=1), _graph_learner(n, T, seed=1)
+    assert th.equal(L1.flat.flat, L2.flat.flat)
+    rb = SequenceReplay(capacity=E, max_seq_len=T, n_agents=n, n_gts=M, hidden_size=256, n_envs=E, state_dim=0,
+                        r_comm=0.9, device=dev)
+    gen = th.Generator(device=dev).manual_seed(7)
+
+    def obs():
+        gt, ub, ag, d = _padded_obs(gen, (E,), n, M, dev)
+        return dict(gt=gt, ubs=ub, agent=ag, d_u2u=d, h=0.1 * th.randn(E, n, 256, device=dev, generator=gen),
+                    state=th.zeros(E, 0, device=dev))
+    cur = obs()
+    for t in range(T):
+        nxt = obs()
+        tr = dict(cur, act=th.randint(9, (E, n), device=dev, generator=gen), rew=th.rand(E, n, device=dev, generator=gen),
+                  done=(th.rand(E, 1, device=dev, generator=gen) < 0.2).float())
+        tr.update({"next_" + k: v for k, v in nxt.items()})
+        rb.push(tr)
+        cur = nxt
+    gu = GraphedUpdate(L2, Bs, T, n, M, r_comm=0.9)
+    assert th.equal(L1.flat.flat, L2.flat.flat) and float(L2.optimizer.hyper[1]) == 0.0   # capture left no trace
+    for it in range(2):
+        idx = rb.sample_indices(Bs, gen)
+        b = rb.gather(idx)
+        b["obs_all"] = hb_batch(b["obs"])
+        out_e = L1.update(b)
+        out_g = gu({k: v.index_select(0, idx) for k, v in rb.mem.items()})
+        assert_close(out_g["LossQ"], out_e["LossQ"], 1e-5, f"loss, replay {it}")
+    assert_close(L2.flat.flat, L1.flat.flat, 1e-5, "policy parameters after two replays", floor=1e-7)
+    assert_close(L2.flat_target, L1.flat_target, 1e-5, "target parameters after two replays", floor=1e-7)
+    assert float(L2.optimizer.hyper[1]) == 2.0

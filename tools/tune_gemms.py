@@ -24,16 +24,29 @@ import torch.cuda.tunable as tun  # noqa: E402
 from bench import exp3_args, make_sequence  # noqa: E402
 from uav_bs_ctrl_amd.learner import MultiAgentQLearner  # noqa: E402
 
-env_info = dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=9, n_agents=8, episode_limit=50)
-L = MultiAgentQLearner(env_info, exp3_args("cuda"))
-batch = make_sequence(4096, 8, 80, 50, "dense", th.device("cuda"), seed=1, distinct=4)
-h = L.init_hidden(4096)
-for t in range(3):
-    _, h = L.act(batch["obs"][t], h, 0.05)
-L.update(batch)
-th.cuda.synchronize()
+import argparse  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--sizes", nargs="*", default=["4096x8x80"], help="BxnxM workloads to tune (update + act at B envs)")
+ap.add_argument("--merge", action="store_true", help="keep the rows of the existing csv for shapes not tuned now")
+a = ap.parse_args()
+for size in a.sizes:
+    B, n, M = (int(v) for v in size.split("x"))
+    env_info = dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=9, n_agents=n, episode_limit=50)
+    L = MultiAgentQLearner(env_info, exp3_args("cuda"))
+    batch = make_sequence(B, n, M, 50, "dense" if B >= 1024 else "env", th.device("cuda"), seed=1, distinct=4)
+    h = L.init_hidden(B)
+    for t in range(3):
+        _, h = L.act(batch["obs"][t], h, 0.05)
+    L.update(batch)
+    th.cuda.synchronize()
 tun.write_file(tmp) if hasattr(tun, "write_file") else None
 src = tmp if os.path.exists(tmp) else tmp.replace(".csv", "0.csv")
 dst = os.path.join(ROOT, "uav_bs_ctrl_amd", "tuned", "gemm_gfx950.csv")
-shutil.copyfile(src, dst)
+new_lines = open(src).read().splitlines()
+if a.merge and os.path.exists(dst):
+    have = {tuple(l.split(",")[:2]) for l in new_lines if not l.startswith("Validator")}
+    new_lines += [l for l in open(dst).read().splitlines()
+                  if l and not l.startswith("Validator") and tuple(l.split(",")[:2]) not in have]
+open(dst, "w").write("\n".join(new_lines) + "\n")
 print(open(dst).read())

@@ -68,6 +68,7 @@ SIGNATURES = {
                                           _c_ip, _c_int, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_int, _c_fp,
                                           _c_int, _c_fp, _c_int, _c_st]),
     "uavgnn_eps_greedy": (_c_int, [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_f32, ctypes.c_void_p, _c_st]),
+    "uavgnn_eps_greedy_dev": (_c_int, [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp, ctypes.c_void_p, _c_st]),
     "uavgnn_colsum_acc": (_c_int, [_c_fp, ctypes.c_longlong, _c_int, _c_int, _c_fp, _c_int, _c_st]),
     "uavgnn_adamw_polyak": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, ctypes.c_longlong, _c_fp, _c_f32,
                                      _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_st]),

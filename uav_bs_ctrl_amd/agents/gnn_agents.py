@@ -143,6 +143,10 @@ class TarMAC(nn.Module):
         autograd history: the fused step (ops.tarmac_step) returns / sinks the gradient of the stack and splits it
         back itself."""
         ws, bs = self._projection_params()
+        # fast path (151 calls per training cycle): the six data pointers are what they were when the views were made
+        ptrs = (ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), bs[0].data_ptr(), bs[1].data_ptr(), bs[2].data_ptr())
+        if getattr(self, "_stacked_ptrs", None) == ptrs:
+            return self._stacked
 
         def adjacent(ts):
             nxt = ts[0].data_ptr()
@@ -161,13 +165,11 @@ class TarMAC(nn.Module):
                     w.data = Wst[r:r + w.shape[0]]
                     b.data = bst[r:r + b.shape[0]]
                     r += w.shape[0]
-        key = (ws[0].data_ptr(), bs[0].data_ptr(), ws[0].dtype)
-        if getattr(self, "_stacked_key", None) != key:
-            rows = sum(w.shape[0] for w in ws)
-            w0, b0 = ws[0].data, bs[0].data
-            self._stacked = (w0.as_strided((rows, w0.shape[1]), (w0.shape[1], 1), w0.storage_offset()),
-                             b0.as_strided((rows,), (1,), b0.storage_offset()))
-            self._stacked_key = key
+        rows = sum(w.shape[0] for w in ws)
+        w0, b0 = ws[0].data, bs[0].data
+        self._stacked = (w0.as_strided((rows, w0.shape[1]), (w0.shape[1], 1), w0.storage_offset()),
+                         b0.as_strided((rows,), (1,), b0.storage_offset()))
+        self._stacked_ptrs = tuple(t.data_ptr() for t in ws + bs)
         return self._stacked
 
     def forward(self, g, x, h):

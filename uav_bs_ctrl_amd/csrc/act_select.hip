@@ -12,7 +12,8 @@ namespace {
 
 __global__ void eps_greedy_kernel(const float* __restrict__ q, int ld_q, int N, int A, int n_agents,
                                   const float* __restrict__ u_team, const float* __restrict__ u_agent, float eps,
-                                  long long* __restrict__ acts) {
+                                  const float* __restrict__ eps_dev, long long* __restrict__ acts) {
+  if (eps_dev != nullptr) eps = *eps_dev;   // exploration rate from device memory: a captured graph replays with the current one
   for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < N; a += gridDim.x * blockDim.x) {
     const float* __restrict__ row = q + static_cast<size_t>(a) * ld_q;
     int best = 0;
@@ -41,6 +42,17 @@ extern "C" int uavgnn_eps_greedy(const float* q, int ld_q, int N, int A, int n_a
   if (N < 0 || A < 1 || n_agents < 1 || ld_q < A || (N > 0 && (!q || !u_team || !u_agent || !acts))) return UAVGNN_EINVAL;
   if (N == 0) return 0;
   hipLaunchKernelGGL(eps_greedy_kernel, dim3(capped_grid(N, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), q,
-                     ld_q, N, A, n_agents, u_team, u_agent, eps, acts);
+                     ld_q, N, A, n_agents, u_team, u_agent, eps, static_cast<const float*>(nullptr), acts);
+  return launch_status();
+}
+
+extern "C" int uavgnn_eps_greedy_dev(const float* q, int ld_q, int N, int A, int n_agents, const float* u_team,
+                                     const float* u_agent, const float* eps_dev, long long* acts,
+                                     uavgnn_stream_t stream) {
+  if (N < 0 || A < 1 || n_agents < 1 || ld_q < A || !eps_dev || (N > 0 && (!q || !u_team || !u_agent || !acts)))
+    return UAVGNN_EINVAL;
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(eps_greedy_kernel, dim3(capped_grid(N, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), q,
+                     ld_q, N, A, n_agents, u_team, u_agent, 0.f, eps_dev, acts);
   return launch_status();
 }

@@ -503,11 +503,15 @@ def from_obs_dicts(obs: Sequence[dict], d_u2u=None, r_comm: float = np.inf, with
 
 
 def from_padded_obs(gt: th.Tensor, ubs: th.Tensor, agent: th.Tensor, d_u2u: Optional[th.Tensor] = None,
-                    r_comm: float = float("inf")) -> HeteroBatch:
+                    r_comm: float = float("inf"), static: bool = False) -> HeteroBatch:
     """Device-side builder for B environments at once: padded observation tensors
     gt [B,n,M,5], ubs [B,n,n-1,3] (column 0 = visibility flag), agent [B,n,2] and d_u2u [B,n,n], all resident on the GPU,
     become a HeteroBatch through two HIP passes (count, compact) and prefix sums; nothing is copied to the host except
-    the three edge totals needed to size the outputs.  Bit-identical to batching ``from_obs_dicts`` per environment."""
+    the three edge totals needed to size the outputs.  Bit-identical to batching ``from_obs_dicts`` per environment.
+
+    static=True: no host round trip at all - the edge arrays are allocated at CAPACITY (B n M / B n (n-1) / B n n rows)
+    and only their first E rows are written; offsets say which.  Shapes then depend on (B, n, M) only, which is what a
+    hipGraph capture of the step needs (uav_bs_ctrl_amd/graphs.py); ``number_of_edges`` still reports the true count."""
     from . import _lib as L
     L.require_gpu(gt, ubs, agent, d_u2u)
     B, n, M, Sg = gt.shape
@@ -531,9 +535,12 @@ def from_padded_obs(gt: th.Tensor, ubs: th.Tensor, agent: th.Tensor, d_u2u: Opti
         talk_off, env_base = th.zeros(N + 1, **i32), th.zeros(B + 1, **i32)
         talk_off[1:] = th.cumsum(deg_t, 0)
         env_base[1:] = th.cumsum(env_e, 0)
-        totals = th.stack((seen_off[-1], near_off[-1], talk_off[-1])).tolist()   # the one host sync: output sizes
-    else:
+        if not static:
+            totals = th.stack((seen_off[-1], near_off[-1], talk_off[-1])).tolist()   # the one host sync: output sizes
+    elif not static:
         totals = th.stack((seen_off[-1], near_off[-1])).tolist() + [0]
+    if static:
+        totals = [N * M, N * U, N * n if with_comm else 0]
     Es, En, Et = totals
     x_gt = th.empty((Es, Sg - 1), dtype=th.float32, device=dev)
     x_ubs = th.empty((En, Su - 1), dtype=th.float32, device=dev)
