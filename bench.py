@@ -215,6 +215,73 @@ def cpu_baseline(n, M, dist_name, T_s=2, budget_s=24.0):
                 sec_per_cycle=sweep[best]["sec_per_cycle_median"])
 
 
+def end_to_end(learner, a, device, cycles=2):
+    """SURVEY 8f rows f1 + f2 + f3 inside the timed region (reported NEXT TO the headline, whose graphs are synthetic as
+    BASELINE.json asks): B environments of the batched device simulator (csrc/env_sim.hip; exp3 'DenseHotSpot' physics,
+    maps.py:82-111, at n x M) are rolled out for T steps with the policy - simulator step, device graph construction,
+    act, replay push per step - then ONE update consumes the B stored sequences (graphs of all T+1 steps rebuilt from the
+    replay's padded tensors).  env-steps/s = B T / cycle time.  Random initial policy: ~95 % of the agents see no GT."""
+    from uav_bs_ctrl_amd import from_padded_obs
+    from uav_bs_ctrl_amd.replay import SequenceReplay
+    from uav_bs_ctrl_amd.sim import BatchedUbsCoverageEnv, MapParams
+    B, n, M, T = a.B, a.n, a.M, a.T
+    mp = MapParams(n_ubs=n, n_gts=M, n_rbs=5, range_pos=6000.0, episode_limit=T, dt=40.0, r_cov=100.0, r_sns=400.0,
+                   vels=(5.0, 10.0), n_dirs=4, reward_scale_rate=10.0)
+    env = BatchedUbsCoverageEnv(mp, B, device)
+    rb = SequenceReplay(capacity=B, max_seq_len=T, n_agents=n, n_gts=M, hidden_size=256, n_envs=B, state_dim=0,
+                        r_comm=mp.r_comm, device=device)
+    gen = th.Generator(device=device)
+    gen.manual_seed(99)
+
+    def positions():   # hotspot of M/5 groups of 5 GTs on a 200 m grid, UBSs on grid points (maps.py:96-111)
+        grid = 200.0
+        spot = th.randint(0, 26, (B, 1, 2), device=device, generator=gen).double() * grid
+        grp = spot + th.randint(0, 4, (B, M // 5, 2), device=device, generator=gen).double() * grid
+        gts = grp.repeat_interleave(5, 1) + 100.0 * (th.rand(B, M, 2, device=device, generator=gen, dtype=th.float64) - 0.5)
+        ubs = th.randint(0, 30, (B, n, 2), device=device, generator=gen).double() * grid
+        return ubs, gts.clamp(0, mp.range_pos).float()
+
+    def cycle():
+        ubs, gts = positions()
+        o = env.reset(ubs, gts, generator=gen)
+        h = learner.init_hidden(B)
+        for t in range(T):
+            g = from_padded_obs(o["gt"], o["ubs"], o["agent"], o["d_u2u"], r_comm=mp.r_comm)
+            cur = {k: o[k].clone() for k in ("gt", "ubs", "agent", "d_u2u")}
+            acts, h2 = learner.act(g, h, 0.05)
+            o, rew, done, _ = env.step(acts)
+            rb.push(dict(cur, h=h.view(B, n, -1), state=th.zeros(B, 0, device=device), act=acts.view(B, n),
+                         rew=rew.float(), done=th.zeros(B, 1, device=device), next_gt=o["gt"], next_ubs=o["ubs"],
+                         next_agent=o["agent"], next_d_u2u=o["d_u2u"], next_h=h2.view(B, n, -1),
+                         next_state=th.zeros(B, 0, device=device)))
+            h = h2
+        m = rb.mem                                              # all B sequences, time-major padded tensors
+        tm = {k: m[k].transpose(0, 1).contiguous() for k in ("gt", "ubs", "agent", "d_u2u")}
+        obs = [from_padded_obs(tm["gt"][t], tm["ubs"][t], tm["agent"][t], tm["d_u2u"][t], r_comm=mp.r_comm)
+               for t in range(T + 1)]
+        flat = lambda x, lo: x[lo:].reshape((-1,) + x.shape[2:])  # noqa: E731
+        batch = dict(obs=obs, obs_all=from_padded_obs(flat(tm["gt"], 0), flat(tm["ubs"], 0), flat(tm["agent"], 0)),
+                     obs_all_next=from_padded_obs(flat(tm["gt"], 1), flat(tm["ubs"], 1), flat(tm["agent"], 1)),
+                     h0=m["h"][:, 0].reshape(B * n, -1), h1=m["h"][:, 1].reshape(B * n, -1),
+                     acts=m["act"].permute(1, 0, 2).reshape(T, B * n, 1), rews=m["rew"].permute(1, 0, 2).contiguous(),
+                     dones=m["done"].permute(1, 0, 2).contiguous())
+        return learner.update(batch)
+
+    cycle()
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(cycles):
+        out = cycle()
+    th.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / cycles
+    served = float((env.out["gt_ubs"] >= 0).float().mean())
+    seen = float(env.out["obs_gt"][..., 0].mean())
+    return dict(value=B * T / dt, unit="env-steps/s", ms_per_cycle=1e3 * dt, cycles=cycles, loss=float(out["LossQ"]),
+                includes="batched device simulator (f3) + device graph construction (f1) + tensor replay (f2) + act + update",
+                physics=f"DenseHotSpot-style map at {n} x {M}: 5 RBs, r_cov 100 m, r_sns 400 m, range 6 km, dt 40 s",
+                mean_gt_visibility=seen, mean_gt_served=served)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +294,7 @@ def main():
     ap.add_argument("--dist", default="dense", choices=["dense", "env"])
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic graphs cycled through the T+1 steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the simulator-inclusive figure (rows f1+f2+f3)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (smoke test)")
     a = ap.parse_args()
 
@@ -367,6 +435,8 @@ def main():
                                         "D-env (94 % of agents see no GT): AI below the machine balance, the launch mix is "
                                         "bound by HBM (output-row writes)")}
         res["kernel_ms_per_launch"] = {n: round(v["avg_ms"], 4) for n, v in ktimes.items()}
+        if world == 1 and not a.no_end_to_end:
+            res["end_to_end"] = end_to_end(learner, a, device)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.n, a.M, a.dist)
         print(json.dumps(res), flush=True)

@@ -251,6 +251,23 @@ int uavgnn_adamw_polyak(float* p, float* g, float* exp_avg, float* exp_avg_sq, f
                         long long n_clip, const float* hyper, float beta1, float beta2, float eps, float weight_decay,
                         float clip, float polyak, uavgnn_stream_t stream);
 
+/* Batched simulator step of the multi-UBS coverage environment, B independent environments per launch (reference:
+ * envs/mubs_cov/mubs_cov.py:104-129 step, :131-210 _transmit_data, :212-242 get_obs, :278-296 get_state, :324-341
+ * _get_reward; envs/common.py:19-25 Jain index, :49-59 air-to-ground channel gain).  actions [B, n] int64 or NULL (the
+ * reset-time transmission: no move, t stays as it is).  In/out per environment: pos_ubs [B,n,2] f64, prior [B,M] (GT
+ * priorities used by this step -> priorities for the next one), avg_rate [B,M], t [B], run_f32 [B,4] = {total throughput,
+ * average global utility, Jain index, global utility}, n_colls [B].  Outputs: d_u2g [B,n,M], d_u2u [B,n,n], gt_ubs /
+ * gt_rb [B,M] (serving UBS / resource block per GT, -1 = unserved), rate_per_gt [B,M], rate_per_ubs [B,n] f64,
+ * mask_collision [B,n], reward [B,n] f64, done [B], padded observations obs_gt [B,n,M,5|4], obs_ubs [B,n,n-1,3],
+ * obs_agent [B,n,2] (column 0 = visibility flag: the input format of uavgnn_obs_degrees / _compact) and the global state
+ * [B, uavgnn_env_state_dim] (may be NULL).  int_consts / f64_consts: HOST arrays, layout in csrc/env_sim.hip. */
+int uavgnn_env_state_dim(int n_ubs, int n_gts, int fair_service);
+int uavgnn_env_step(const int32_t* int_consts, const double* f64_consts, int B, const long long* actions,
+                    const double* avail_moves, double* pos_ubs, const float* pos_gts, int32_t* prior, float* avg_rate,
+                    int32_t* t, float* run_f32, double* n_colls, float* d_u2g, float* d_u2u, int32_t* gt_ubs,
+                    int32_t* gt_rb, float* rate_per_gt, double* rate_per_ubs, int32_t* mask_collision, double* reward,
+                    float* done, float* obs_gt, float* obs_ubs, float* obs_agent, float* state, uavgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
