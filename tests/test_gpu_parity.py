@@ -720,8 +720,15 @@ def test_talk_attention_per_graph_kernels_with_parallel_edges():
     sd, qd, vd = (t.detach().float().cuda().requires_grad_(True) for t in (s, q, v))
     c = ops.talk_attention(sd, qd, vd, g, 1.0 / K)
     assert_close(c, c64, 1e-5, "c")
-    for a, b, nm in zip(th.autograd.grad((c * w.float().cuda()).sum(), [sd, qd, vd]), g64, ["d_s", "d_q", "d_v"]):
+    got = th.autograd.grad((c * w.float().cuda()).sum(), [sd, qd, vd], retain_graph=True)
+    for a, b, nm in zip(got, g64, ["d_s", "d_q", "d_v"]):
         assert_close(a, b, 1e-4, nm, floor=1e-6)
+    # duplicates are summed in CSC order by the lane of the first one (no float atomics): bit-exact run to run
+    for _ in range(5):
+        c2 = ops.talk_attention(sd, qd, vd, g, 1.0 / K)
+        assert th.equal(c2, c)
+        for a, b in zip(th.autograd.grad((c2 * w.float().cuda()).sum(), [sd, qd, vd]), got):
+            assert th.equal(a, b)
 
 
 def test_talk_attention_per_graph_kernel_fails_loudly_on_a_wrong_hint():

@@ -40,10 +40,10 @@ __host__ __device__ inline EnvDims env_dims(int nmax, int M, int K) {
   return d;
 }
 
-// words of LDS per wavefront: P | OFF | SC | AD | SRC | DST        (forward)
-//                             P | DC | OFF | A | DA | AD | DE | SRC | DST   (backward)
-inline int fwd_words(const EnvDims& d) { return d.nmax * d.ldp + (d.nmax + 1) + 4 * d.emax; }
-inline int bwd_words(const EnvDims& d) { return d.nmax * d.ldp + d.nmax * d.ldm + (d.nmax + 1) + 6 * d.emax; }
+// words of LDS per wavefront: P | OFF | SC | AD | SRC | DST | AV        (forward)
+//                             P | DC | OFF | A | DA | AD | DE | SRC | DST | DV   (backward)
+inline int fwd_words(const EnvDims& d) { return d.nmax * d.ldp + (d.nmax + 1) + 5 * d.emax; }
+inline int bwd_words(const EnvDims& d) { return d.nmax * d.ldp + d.nmax * d.ldm + (d.nmax + 1) + 7 * d.emax; }
 inline int waves_for(int words) {
   const int per_block = 64 * 1024 / 4;   // default dynamic-LDS ceiling of a workgroup
   int w = per_block / words;
@@ -112,6 +112,27 @@ __device__ __forceinline__ void poison_rows(float* __restrict__ dst, int ld, int
     for (int ch = lane; ch < W; ch += kWave) dst[static_cast<size_t>(a0 + i) * ld + ch] = NAN;
 }
 
+// Deterministic scatter of per-edge values VAL (LDS) into the dense [NMAX x NMAX] matrix Mx (zero-initialised): parallel
+// (duplicate) edges of one (destination, source) pair are summed IN CSC ORDER by the lane of the first of them - no float
+// atomics, so the result does not depend on which lane got to the LDS first.  Simple graphs: one
+// pass over the <= n earlier / later in-edges of the destination, plain store.
+__device__ __forceinline__ void scatter_edges(float* __restrict__ Mx, int nmax, const float* __restrict__ VAL,
+                                              const int* __restrict__ SRC, const int* __restrict__ DST,
+                                              const int* __restrict__ OFF, int E, int lane) {
+  for (int e = lane; e < E; e += kWave) {
+    const int d = DST[e], sidx = SRC[e];
+    const int j0 = OFF[d], j1 = OFF[d + 1];
+    bool first = true;
+    for (int jx = j0; jx < e; ++jx) first = first && (SRC[jx] != sidx);
+    if (first) {
+      float acc = VAL[e];
+      for (int jx = e + 1; jx < j1; ++jx)
+        if (SRC[jx] == sidx) acc += VAL[jx];
+      Mx[d * nmax + sidx] = acc;
+    }
+  }
+}
+
 // out[r][ch] = sum_{t < NMAX} W[r, t] * X[t][ch] for r < n, one 64-channel block at a time, X rows in registers
 // (rows >= n are clamped copies multiplied by the zero padding of W).  TRANS: W[r, t] = Wm[t * NMAX + r], else
 // Wm[r * NMAX + t].  The Wm reads are wave-uniform (LDS broadcast) and independent of each other.
@@ -153,6 +174,7 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_fwd_kern
   float* __restrict__ AD = SC + dm.emax;
   int* __restrict__ SRC = reinterpret_cast<int*>(AD + dm.emax);
   int* __restrict__ DST = SRC + dm.emax;
+  float* __restrict__ AV = reinterpret_cast<float*>(DST + dm.emax);
 
   // blockIdx.y == 1: copy-only workgroups.  The x half of the [x || c] rows is a pure stream (2/3 of this kernel's
   // bytes); giving it its own wavefronts lets it overlap the LDS phases of the attention wavefronts, which otherwise
@@ -248,8 +270,10 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_fwd_kern
         a = expf(SC[e] - m) / den;
       }
       a_save[g.e_lo + e] = a;
-      atomicAdd(&AD[d * NMAX + SRC[e]], a);   // LDS; parallel edges add up
+      AV[e] = a;
     }
+    wave_sync_lds();
+    scatter_edges(AD, NMAX, AV, SRC, DST, OFF, g.E, lane);   // parallel edges add up, in CSC order
     wave_sync_lds();
     dense_rows<NMAX, false>(AD, P, dm.ldp, g.n, M, lane, c + static_cast<size_t>(g.a0) * ld_c, ld_c);
     wave_sync_lds();   // the next graph restages the same LDS
@@ -279,6 +303,7 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_bwd_kern
   float* __restrict__ DE = AD + dm.emax;
   int* __restrict__ SRC = reinterpret_cast<int*>(DE + dm.emax);
   int* __restrict__ DST = SRC + dm.emax;
+  float* __restrict__ DV = reinterpret_cast<float*>(DST + dm.emax);
 
   for (int b = blockIdx.x * waves + wave; b < B; b += gridDim.x * waves) {
     EnvGraph g;
@@ -331,8 +356,8 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_bwd_kern
       poison_rows(d_v, ld_dv, g.a0, g.n, M, lane);
       continue;
     }
+    scatter_edges(AD, NMAX, A, SRC, DST, OFF, g.E, lane);
     for (int e = lane; e < g.E; e += kWave) {
-      atomicAdd(&AD[DST[e] * NMAX + SRC[e]], A[e]);
       if (!uniform) {   // da_e = <d_c[dst_e], v[src_e]>
         const float* __restrict__ dr = DC + DST[e] * dm.ldm;
         const float* __restrict__ vr = P + SRC[e] * dm.ldp;
@@ -351,8 +376,10 @@ __global__ __launch_bounds__(kEnvMaxWaves* kWave, 4) void talk_attn_env_bwd_kern
         float T = 0.f;
 #pragma unroll 2
         for (int j = OFF[d]; j < j1; ++j) T = fmaf(A[j], DA[j], T);
-        atomicAdd(&DE[d * NMAX + SRC[e]], A[e] * (DA[e] - T) * scale);
+        DV[e] = A[e] * (DA[e] - T) * scale;
       }
+      wave_sync_lds();
+      scatter_edges(DE, NMAX, DV, SRC, DST, OFF, g.E, lane);
       wave_sync_lds();
       // d_q[r][k] = sum_u dE[r][u] s[u][k],  d_s[r][k] = sum_d dE[d][r] q[d][k]:  lane = (row r, key column k)
       const int rpp = kWave / K;                      // rows per pass (K <= 64)
