@@ -138,7 +138,12 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     float* __restrict__ a_save_n, int phases) {
   __shared__ __attribute__((aligned(16))) float sWs[H * FS_S];     // fc_src.weight of `seen`, row-major [H, 4]
   __shared__ __attribute__((aligned(16))) float sWn[H * FS_N];     // fc_src.weight of `near`, row-major [H, 2]
-  __shared__ float sAs[H], sAn[H];                                  // attention vectors
+  __shared__ __attribute__((aligned(16))) float sAs[H], sAn[H];     // attention vectors
+  __shared__ __attribute__((aligned(16))) float sWdn[H * 2];        // fc_dst.weight of `near` (A operand rows of phase N)
+  __shared__ __attribute__((aligned(16))) float sBCn[H];            // b_s + b_d of `near` (the constant C operand)
+  // the remaining small operands, staged once per workgroup instead of fetched by every wavefront:
+  __shared__ __attribute__((aligned(16))) float sWds[H * 2], sWrs[H * 2], sWrn[H * 2];   // seen fc_dst / res_fc, near res_fc
+  __shared__ __attribute__((aligned(16))) float sBss[H], sBds[H], sBrs[H], sBsn[H], sBrn[H];   // biases (b_r: 0 when absent)
   __shared__ float sWa[2][NH * 4];                                  // wa[k][f] = sum_d attn[k,d] W_s[k,d,f] per relation
   __shared__ __attribute__((aligned(16))) float sC[kWavesPerBlock][H];
 
@@ -150,11 +155,22 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
 
   for (int i = tid; i < H * FS_S / 4; i += kThreads)
     reinterpret_cast<float4*>(sWs)[i] = reinterpret_cast<const float4*>(ps.W_s)[i];
-  for (int i = tid; i < H * FS_N / 4; i += kThreads)
+  for (int i = tid; i < H * FS_N / 4; i += kThreads) {
     reinterpret_cast<float4*>(sWn)[i] = reinterpret_cast<const float4*>(pn.W_s)[i];
+    reinterpret_cast<float4*>(sWdn)[i] = reinterpret_cast<const float4*>(pn.W_d)[i];
+    reinterpret_cast<float4*>(sWds)[i] = reinterpret_cast<const float4*>(ps.W_d)[i];
+    reinterpret_cast<float4*>(sWrs)[i] = reinterpret_cast<const float4*>(ps.W_r)[i];
+    reinterpret_cast<float4*>(sWrn)[i] = reinterpret_cast<const float4*>(pn.W_r)[i];
+  }
   for (int i = tid; i < H; i += kThreads) {
     sAs[i] = ps.attn[i];
     sAn[i] = pn.attn[i];
+    sBCn[i] = pn.b_s[i] + pn.b_d[i];
+    sBss[i] = ps.b_s[i];
+    sBds[i] = ps.b_d[i];
+    sBsn[i] = pn.b_s[i];
+    sBrs[i] = ps.b_r != nullptr ? ps.b_r[i] : 0.f;
+    sBrn[i] = pn.b_r != nullptr ? pn.b_r[i] : 0.f;
   }
   __syncthreads();
   {  // wa[rel][k][f]: 2 x 16 outputs, 16 partial sums each; 256 threads = 16 rows of 16 lanes, two rounds
@@ -193,12 +209,11 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     // lane <-> channels 4*lane .. 4*lane+3 (head g)
     float wd[4][2], bc[4], wr[4][2], br[4], bs[4];
     {
-      const float4 bs4 = reinterpret_cast<const float4*>(ps.b_s)[lane];
-      const float4 bd4 = reinterpret_cast<const float4*>(ps.b_d)[lane];
-      const float4 wd_lo = reinterpret_cast<const float4*>(ps.W_d)[2 * lane], wd_hi = reinterpret_cast<const float4*>(ps.W_d)[2 * lane + 1];
-      const float4 wr_lo = reinterpret_cast<const float4*>(ps.W_r)[2 * lane], wr_hi = reinterpret_cast<const float4*>(ps.W_r)[2 * lane + 1];
-      float4 br4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ps.b_r != nullptr) br4 = reinterpret_cast<const float4*>(ps.b_r)[lane];
+      const float4 bs4 = reinterpret_cast<const float4*>(sBss)[lane];
+      const float4 bd4 = reinterpret_cast<const float4*>(sBds)[lane];
+      const float4 wd_lo = reinterpret_cast<const float4*>(sWds)[2 * lane], wd_hi = reinterpret_cast<const float4*>(sWds)[2 * lane + 1];
+      const float4 wr_lo = reinterpret_cast<const float4*>(sWrs)[2 * lane], wr_hi = reinterpret_cast<const float4*>(sWrs)[2 * lane + 1];
+      const float4 br4 = reinterpret_cast<const float4*>(sBrs)[lane];
       bs[0] = bs4.x; bs[1] = bs4.y; bs[2] = bs4.z; bs[3] = bs4.w;
       bc[0] = bs4.x + bd4.x; bc[1] = bs4.y + bd4.y; bc[2] = bs4.z + bd4.z; bc[3] = bs4.w + bd4.w;
       wd[0][0] = wd_lo.x; wd[0][1] = wd_lo.y; wd[1][0] = wd_lo.z; wd[1][1] = wd_lo.w;
@@ -336,12 +351,12 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int row = ct * 16 + j;
-      Wa[ct] = (g < 2) ? sWn[row * FS_N + g] : pn.W_d[row * 2 + (g - 2)];
+      Wa[ct] = (g < 2) ? sWn[row * FS_N + g] : sWdn[row * 2 + (g - 2)];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ch = ct * 16 + 4 * g + r;
         att[ct][r] = c_abs * sAn[ch];
-        cconst[ct][r] = pn.b_s[ch] + pn.b_d[ch];
+        cconst[ct][r] = sBCn[ch];
       }
     }
 #pragma unroll
@@ -349,13 +364,11 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     // epilogue constants, lane <-> channels 4*lane .. 4*lane+3
     float ws[4][2], bsn[4], wrn[4][2], brn[4], wrs[4][2], brs[4];
     {
-      const float4 bs4 = reinterpret_cast<const float4*>(pn.b_s)[lane];
+      const float4 bs4 = reinterpret_cast<const float4*>(sBsn)[lane];
       const float4 ws_lo = reinterpret_cast<const float4*>(sWn)[2 * lane], ws_hi = reinterpret_cast<const float4*>(sWn)[2 * lane + 1];
-      const float4 wn_lo = reinterpret_cast<const float4*>(pn.W_r)[2 * lane], wn_hi = reinterpret_cast<const float4*>(pn.W_r)[2 * lane + 1];
-      const float4 wq_lo = reinterpret_cast<const float4*>(ps.W_r)[2 * lane], wq_hi = reinterpret_cast<const float4*>(ps.W_r)[2 * lane + 1];
-      float4 bn4 = make_float4(0.f, 0.f, 0.f, 0.f), bq4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pn.b_r != nullptr) bn4 = reinterpret_cast<const float4*>(pn.b_r)[lane];
-      if (ps.b_r != nullptr) bq4 = reinterpret_cast<const float4*>(ps.b_r)[lane];
+      const float4 wn_lo = reinterpret_cast<const float4*>(sWrn)[2 * lane], wn_hi = reinterpret_cast<const float4*>(sWrn)[2 * lane + 1];
+      const float4 wq_lo = reinterpret_cast<const float4*>(sWrs)[2 * lane], wq_hi = reinterpret_cast<const float4*>(sWrs)[2 * lane + 1];
+      const float4 bn4 = reinterpret_cast<const float4*>(sBrn)[lane], bq4 = reinterpret_cast<const float4*>(sBrs)[lane];
       bsn[0] = bs4.x; bsn[1] = bs4.y; bsn[2] = bs4.z; bsn[3] = bs4.w;
       ws[0][0] = ws_lo.x; ws[0][1] = ws_lo.y; ws[1][0] = ws_lo.z; ws[1][1] = ws_lo.w;
       ws[2][0] = ws_hi.x; ws[2][1] = ws_hi.y; ws[3][0] = ws_hi.z; ws[3][1] = ws_hi.w;
