@@ -105,6 +105,13 @@ int uavgnn_gatv2_bwd(const float* x_src, int E, int F_src, const float* x_dst, i
                      int nh, int D, float slope, const float* out, const float* d_out, int ld_out,
                      const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d, float* dattn,
                      float* dW_r, float* db_r, void* workspace, size_t workspace_bytes, uavgnn_stream_t stream);
+/* Same contract, generic kernel only (one destination per wavefront).  uavgnn_gatv2_bwd itself picks the
+ * pair-of-destinations kernel for two-feature relations with mean in-degree <= 8 (`near`): in-library A/B reference. */
+int uavgnn_gatv2_bwd_generic(const float* x_src, int E, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
+                     const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
+                     int nh, int D, float slope, const float* out, const float* d_out, int ld_out,
+                     const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d, float* dattn,
+                     float* dW_r, float* db_r, void* workspace, size_t workspace_bytes, uavgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * K3b  Targeted attention over the talk relation, forward.

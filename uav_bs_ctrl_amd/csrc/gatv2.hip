@@ -534,6 +534,282 @@ constexpr int kMaxBwdBlocks = 1024;
 
 inline int bwd_blocks(int N) { return capped_grid(N, kWavesPerBlock, kMaxBwdBlocks); }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1 backward for LOW-DEGREE two-feature relations (`near`: n - 1 <= 8 in-edges of 2 features; nh = 4, D = 64).
+// The generic kernel above owns one destination per wavefront and pays ~1400 cycles of per-destination bookkeeping
+// (LDS round trips for G, four 64-lane reductions for T, edge staging for up to 64 edges) around ~700 cycles of
+// per-(edge, channel) work when the degree is 7.  Here a wavefront owns a PAIR of destinations (2p, 2p+1):
+//   * lane <-> four consecutive channels 4*lane..4*lane+3 of head k = lane>>4 for everything per channel (rows of `out`
+//     / `d_out` are one 16-byte load per lane), and lane = (head k, destination half, edge slot) for everything per edge
+//     - the same 16-lane row serves head k in both roles, so G[k], T[k], P[k], Sb[k] never leave their row: the
+//     reductions are DPP all-reduces over 16 (channels) or 8 (edge slots of one destination) lanes, no LDS, no barrier;
+//   * only the per-edge (x_u, de_uk) values go through a 96-float per-wave LDS buffer to be broadcast to the channel
+//     lanes; degrees above 8 take further passes (any degree is correct);
+//   * same arithmetic, same partial-row layout and the same fixed-order two-stage reduction as the generic kernel
+//     (deterministic).
+constexpr int kRowRorCtl = 0x120, kQuadXor1Ctl = 0xB1, kQuadXor2Ctl = 0x4E, kHalfMirrorCtl = 0x141;
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_allsum(float v) {
+  v += dpp_f<kRowRorCtl + 8>(v);
+  v += dpp_f<kRowRorCtl + 4>(v);
+  v += dpp_f<kRowRorCtl + 2>(v);
+  v += dpp_f<kRowRorCtl + 1>(v);
+  return v;
+}
+__device__ __forceinline__ float half8_allsum(float v) {
+  v += dpp_f<kQuadXor1Ctl>(v);
+  v += dpp_f<kQuadXor2Ctl>(v);
+  v += dpp_f<kHalfMirrorCtl>(v);
+  return v;
+}
+
+__global__ __launch_bounds__(kThreads) void gatv2_bwd_pair_kernel(
+    const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off, int N,
+    const float* __restrict__ W_s, const float* __restrict__ b_s, const float* __restrict__ W_d,
+    const float* __restrict__ b_d, const float* __restrict__ attn, float slope, const float* __restrict__ out,
+    const float* __restrict__ d_out, int ld_out, const float* __restrict__ a_save, float* __restrict__ partial) {
+  constexpr int FS = 2, NH = 4, D = 64, H = NH * D;
+  constexpr int P = partial_len<FS>(H);
+  __shared__ float sRed[P];
+  __shared__ __attribute__((aligned(16))) float sX[kWavesPerBlock][2][8][2];     // x_u of (half, slot)
+  __shared__ __attribute__((aligned(16))) float sDE[kWavesPerBlock][2][8][NH];   // de_uk of (half, slot, head)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = lane >> 4, half = (lane >> 3) & 1, slot = lane & 7;
+  const float c_lin = 0.5f * (1.f + slope), c_abs = 0.5f * (1.f - slope);
+
+  // per-lane constants for channels n = 4*lane + r
+  float Ws[4][2], att[4], wd[4][2], bc[4];
+  {
+    const float4 w_lo = reinterpret_cast<const float4*>(W_s)[2 * lane], w_hi = reinterpret_cast<const float4*>(W_s)[2 * lane + 1];
+    const float4 d_lo = reinterpret_cast<const float4*>(W_d)[2 * lane], d_hi = reinterpret_cast<const float4*>(W_d)[2 * lane + 1];
+    const float4 a4 = reinterpret_cast<const float4*>(attn)[lane];
+    const float4 bs4 = reinterpret_cast<const float4*>(b_s)[lane], bd4 = reinterpret_cast<const float4*>(b_d)[lane];
+    Ws[0][0] = w_lo.x; Ws[0][1] = w_lo.y; Ws[1][0] = w_lo.z; Ws[1][1] = w_lo.w;
+    Ws[2][0] = w_hi.x; Ws[2][1] = w_hi.y; Ws[3][0] = w_hi.z; Ws[3][1] = w_hi.w;
+    wd[0][0] = d_lo.x; wd[0][1] = d_lo.y; wd[1][0] = d_lo.z; wd[1][1] = d_lo.w;
+    wd[2][0] = d_hi.x; wd[2][1] = d_hi.y; wd[3][0] = d_hi.z; wd[3][1] = d_hi.w;
+    att[0] = a4.x; att[1] = a4.y; att[2] = a4.z; att[3] = a4.w;
+    bc[0] = bs4.x + bd4.x; bc[1] = bs4.y + bd4.y; bc[2] = bs4.z + bd4.z; bc[3] = bs4.w + bd4.w;
+  }
+  float aWs[4][2], abs_[4], aWd[4][2], abd[4], aatt[4], aWr[4][2], abr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    aWs[r][0] = aWs[r][1] = aWd[r][0] = aWd[r][1] = aWr[r][0] = aWr[r][1] = 0.f;
+    abs_[r] = abd[r] = aatt[r] = abr[r] = 0.f;
+  }
+  float* __restrict__ xw = &sX[wave][0][0][0];
+  float* __restrict__ dw = &sDE[wave][0][0][0];
+
+  const int stride = gridDim.x * kWavesPerBlock;
+  const int it0 = blockIdx.x * kWavesPerBlock + wave;
+  const int NP = (N + 1) >> 1;
+
+  // per-destination tail (lane <-> channel): fold S1 / S2 / P / Sb of ONE destination into the register accumulators
+  auto finish = [&](const float (&g)[4], const float (&c)[4], const float (&S1)[4], const float (&S2)[4][2], const float P0,
+                    const float P1, const float Sb0, const float Sb1, const float xv0, const float xv1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float wS2 = fmaf(Ws[r][1], S2[r][1], Ws[r][0] * S2[r][0]);
+      const float wP = fmaf(Ws[r][1], P1, Ws[r][0] * P0);
+      aWs[r][0] += att[r] * fmaf(c_abs, S2[r][0], c_lin * P0) + g[r] * Sb0;
+      aWs[r][1] += att[r] * fmaf(c_abs, S2[r][1], c_lin * P1) + g[r] * Sb1;
+      aatt[r] += fmaf(c_abs, fmaf(c[r], S1[r], wS2), c_lin * wP);
+      const float der = att[r] * c_abs * S1[r];
+      abs_[r] += g[r] + der;
+      abd[r] += der;
+      aWd[r][0] = fmaf(der, xv0, aWd[r][0]);
+      aWd[r][1] = fmaf(der, xv1, aWd[r][1]);
+    }
+  };
+
+  for (int kb = 0; it0 + kb * stride < NP; kb += kWave) {
+    const int my_p = it0 + (kb + lane) * stride;
+    const bool mine = my_p < NP;
+    const int vA0 = 2 * my_p;
+    const bool hasB0 = mine && (vA0 + 1 < N);
+    const int m_n0 = mine ? seg_off[vA0] : 0;
+    const int m_n1 = mine ? seg_off[vA0 + 1] : 0;
+    const int m_n2 = hasB0 ? seg_off[vA0 + 2] : m_n1;
+    const float2 m_xa = mine ? *reinterpret_cast<const float2*>(x_dst + 2 * vA0) : make_float2(0.f, 0.f);
+    const float2 m_xb = hasB0 ? *reinterpret_cast<const float2*>(x_dst + 2 * vA0 + 2) : make_float2(0.f, 0.f);
+    const int cnt = min(kWave, (NP - it0 - kb * stride + stride - 1) / stride);
+    // Software pipeline over the pairs of this chunk: rows and first-pass edge data of pair ii+1 are requested (clamped,
+    // never predicated loads: the compiler can count them) before pair ii computes - with two wavefronts per SIMD an
+    // exposed HBM round trip per pair would dominate everything else.
+    float4 q_oA, q_dA, q_oB, q_dB;
+    float2 q_xe;
+    float q_ae;
+    auto request = [&](const int ix) {
+      const int pp = it0 + (kb + ix) * stride;
+      const int va = 2 * pp;
+      const bool hb = va + 1 < N;
+      const int a0 = __builtin_amdgcn_readlane(m_n0, ix), a1 = __builtin_amdgcn_readlane(m_n1, ix);
+      const int a2 = __builtin_amdgcn_readlane(m_n2, ix);
+      const size_t ra = static_cast<size_t>(va) * ld_out, rb = static_cast<size_t>(hb ? va + 1 : va) * ld_out;
+      q_oA = *reinterpret_cast<const float4*>(out + ra + 4 * lane);
+      q_dA = *reinterpret_cast<const float4*>(d_out + ra + 4 * lane);
+      q_oB = *reinterpret_cast<const float4*>(out + rb + 4 * lane);
+      q_dB = *reinterpret_cast<const float4*>(d_out + rb + 4 * lane);
+      const int e0 = half ? a1 : a0, dg = half ? a2 - a1 : a1 - a0;
+      const size_t u = static_cast<size_t>(slot < dg ? e0 + slot : 0);
+      q_xe = *reinterpret_cast<const float2*>(x_src + u * FS);
+      q_ae = a_save[u * NH + k];
+    };
+    request(0);
+    for (int ii = 0; ii < cnt; ++ii) {
+      const int p = it0 + (kb + ii) * stride;
+      const int vA = 2 * p;
+      const bool hasB = vA + 1 < N;
+      const int n0 = __builtin_amdgcn_readlane(m_n0, ii), n1 = __builtin_amdgcn_readlane(m_n1, ii);
+      const int n2 = __builtin_amdgcn_readlane(m_n2, ii);
+      const float xa0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(m_xa.x), ii));
+      const float xa1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(m_xa.y), ii));
+      const float xb0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(m_xb.x), ii));
+      const float xb1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(m_xb.y), ii));
+      const int degA = n1 - n0, degB = n2 - n1;
+      const float4 oA = q_oA, dA = q_dA, oB = q_oB, dB = q_dB;
+      const int my_e0 = half ? n1 : n0, my_deg = half ? degB : degA;
+      const int dmax = max(degA, degB);
+      float2 xe = slot < my_deg ? q_xe : make_float2(0.f, 0.f);
+      float ae = slot < my_deg ? q_ae : 0.f;
+      request(min(ii + 1, cnt - 1));           // the last iteration re-requests itself (harmless, keeps the count static)
+      float gA[4], gB[4], cA[4], cB[4];
+      {
+        const float oa[4] = {oA.x, oA.y, oA.z, oA.w}, da[4] = {dA.x, dA.y, dA.z, dA.w};
+        const float ob[4] = {oB.x, oB.y, oB.z, oB.w}, db[4] = {dB.x, dB.y, dB.z, dB.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gA[r] = oa[r] > 0.f ? da[r] : 0.f;                       // ReLU mask
+          gB[r] = (hasB && ob[r] > 0.f) ? db[r] : 0.f;
+          aWr[r][0] = fmaf(gA[r], xa0, fmaf(gB[r], xb0, aWr[r][0]));
+          aWr[r][1] = fmaf(gA[r], xa1, fmaf(gB[r], xb1, aWr[r][1]));
+          abr[r] += gA[r] + gB[r];
+          cA[r] = fmaf(wd[r][1], xa1, fmaf(wd[r][0], xa0, bc[r]));
+          cB[r] = fmaf(wd[r][1], xb1, fmaf(wd[r][0], xb0, bc[r]));
+        }
+      }
+      if (dmax == 0) continue;
+      // G[k][f] = sum_d g[k,d] W_s[k,d,f] of both destinations: all-reduce over the 16 lanes of row k
+      float GA0 = 0.f, GA1 = 0.f, GB0 = 0.f, GB1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        GA0 = fmaf(gA[r], Ws[r][0], GA0); GA1 = fmaf(gA[r], Ws[r][1], GA1);
+        GB0 = fmaf(gB[r], Ws[r][0], GB0); GB1 = fmaf(gB[r], Ws[r][1], GB1);
+      }
+      GA0 = row16_allsum(GA0); GA1 = row16_allsum(GA1); GB0 = row16_allsum(GB0); GB1 = row16_allsum(GB1);
+      const float G0 = half ? GB0 : GA0, G1 = half ? GB1 : GA1;
+      // T[k] = sum_u a_uk (G[k].x_u) over ALL in-edges of the lane's destination
+      float tsum = ae * fmaf(G1, xe.y, G0 * xe.x);
+      for (int base = 8; base < dmax; base += 8) {
+        if (base + slot < my_deg) {
+          const size_t u = static_cast<size_t>(my_e0 + base + slot);
+          const float2 x2 = *reinterpret_cast<const float2*>(x_src + u * FS);
+          tsum = fmaf(a_save[u * NH + k], fmaf(G1, x2.y, G0 * x2.x), tsum);
+        }
+      }
+      const float T = half8_allsum(tsum);
+
+      float S1A[4], S2A[4][2], S1B[4], S2B[4][2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S1A[r] = S2A[r][0] = S2A[r][1] = S1B[r] = S2B[r][0] = S2B[r][1] = 0.f;
+      float accP0 = 0.f, accP1 = 0.f, accS0 = 0.f, accS1 = 0.f;
+      for (int base = 0; base < dmax; base += 8) {
+        if (base > 0) {
+          const bool valid = base + slot < my_deg;
+          const size_t u = static_cast<size_t>(valid ? my_e0 + base + slot : 0);
+          xe = *reinterpret_cast<const float2*>(x_src + u * FS);
+          ae = a_save[u * NH + k];
+          if (!valid) {
+            xe = make_float2(0.f, 0.f);
+            ae = 0.f;
+          }
+        }
+        const float de = ae * (fmaf(G1, xe.y, G0 * xe.x) - T);      // 0 on empty slots (a = 0)
+        accP0 = fmaf(de, xe.x, accP0); accP1 = fmaf(de, xe.y, accP1);
+        accS0 = fmaf(ae, xe.x, accS0); accS1 = fmaf(ae, xe.y, accS1);
+        dw[(half * 8 + slot) * NH + k] = de;
+        if (k == 0) *reinterpret_cast<float2*>(xw + (half * 8 + slot) * 2) = xe;
+        wave_sync_lds();
+        // lane <-> channel: the sign part, destination A then B (edge data = LDS broadcast within the row)
+        const int cntA = min(8, degA - base), cntB = min(8, degB - base);
+        for (int i = 0; i < cntA; ++i) {
+          const float2 x2 = *reinterpret_cast<const float2*>(xw + i * 2);
+          const float dek = dw[i * NH + k];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = fmaf(Ws[r][1], x2.y, fmaf(Ws[r][0], x2.x, cA[r]));
+            const float sde = z > 0.f ? dek : -dek;
+            S1A[r] += sde;
+            S2A[r][0] = fmaf(sde, x2.x, S2A[r][0]);
+            S2A[r][1] = fmaf(sde, x2.y, S2A[r][1]);
+          }
+        }
+        for (int i = 0; i < cntB; ++i) {
+          const float2 x2 = *reinterpret_cast<const float2*>(xw + (8 + i) * 2);
+          const float dek = dw[(8 + i) * NH + k];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = fmaf(Ws[r][1], x2.y, fmaf(Ws[r][0], x2.x, cB[r]));
+            const float sde = z > 0.f ? dek : -dek;
+            S1B[r] += sde;
+            S2B[r][0] = fmaf(sde, x2.x, S2B[r][0]);
+            S2B[r][1] = fmaf(sde, x2.y, S2B[r][1]);
+          }
+        }
+        wave_sync_lds();
+      }
+      // P[k][f] = sum_u de_uk x_u, Sb[k][f] = sum_u a_uk x_u per destination: all-reduce over its 8 slots, then the other
+      // half's values by a row rotation
+      const float p0 = half8_allsum(accP0), p1 = half8_allsum(accP1), b0 = half8_allsum(accS0), b1 = half8_allsum(accS1);
+      const float q0 = dpp_f<kRowRorCtl + 8>(p0), q1 = dpp_f<kRowRorCtl + 8>(p1);
+      const float r0 = dpp_f<kRowRorCtl + 8>(b0), r1 = dpp_f<kRowRorCtl + 8>(b1);
+      if (degA > 0) finish(gA, cA, S1A, S2A, half ? q0 : p0, half ? q1 : p1, half ? r0 : b0, half ? r1 : b1, xa0, xa1);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { /* isolated destination: only the residual gradient (done above) */ }
+      }
+      if (degB > 0) finish(gB, cB, S1B, S2B, half ? p0 : q0, half ? p1 : q1, half ? b0 : r0, half ? b1 : r1, xb0, xb1);
+    }
+  }
+
+  // fold the 4 waves in fixed order through LDS, then one partial row per workgroup (layout of the generic kernel)
+  for (int w = 0; w < kWavesPerBlock; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 4 * lane + r;
+        auto put = [&](int idx, float val) { sRed[idx] = (w == 0) ? val : sRed[idx] + val; };
+        put(n * FS + 0, aWs[r][0]);
+        put(n * FS + 1, aWs[r][1]);
+        int o = H * FS;
+        put(o + n, abs_[r]);
+        o += H;
+        put(o + 2 * n, aWd[r][0]);
+        put(o + 2 * n + 1, aWd[r][1]);
+        o += 2 * H;
+        put(o + n, abd[r]);
+        o += H;
+        put(o + n, aatt[r]);
+        o += H;
+        put(o + 2 * n, aWr[r][0]);
+        put(o + 2 * n + 1, aWr[r][1]);
+        o += 2 * H;
+        put(o + n, abr[r]);
+      }
+    }
+    __syncthreads();
+  }
+  float* __restrict__ prow = partial + static_cast<size_t>(blockIdx.x) * P;
+  for (int i = tid; i < P; i += kThreads) prow[i] = sRed[i];
+}
+
 template <int FS, int NH, int D>
 int launch_fwd(const float* x_src, const float* x_dst, const int32_t* seg_off, const int32_t* dst_order, int N,
                const float* W_s,
@@ -651,12 +927,14 @@ extern "C" size_t uavgnn_gatv2_bwd_workspace_bytes(int F_src, int H) {
   return static_cast<size_t>(kMaxBwdBlocks) * static_cast<size_t>(H) * (F_src + 8) * sizeof(float);
 }
 
-extern "C" int uavgnn_gatv2_bwd(const float* x_src, int E, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
-                                const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d,
-                                const float* attn, int nh, int D, float slope, const float* out, const float* d_out,
-                                int ld_out, const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d,
-                                float* dattn, float* dW_r, float* db_r, void* workspace, size_t workspace_bytes,
-                                uavgnn_stream_t stream) {
+// variant: 0 = generic kernel only (one destination per wavefront), 1 = automatic (pair kernel for low-degree two-feature
+// relations, else generic)
+static int gatv2_bwd_checked(int variant, const float* x_src, int E, int F_src, const float* x_dst, int F_dst,
+                             const int32_t* seg_off, const int32_t* dst_order, int N, const float* W_s, const float* b_s,
+                             const float* W_d, const float* b_d, const float* attn, int nh, int D, float slope,
+                             const float* out, const float* d_out, int ld_out, const float* attn_save, float* dW_s,
+                             float* db_s, float* dW_d, float* db_d, float* dattn, float* dW_r, float* db_r,
+                             void* workspace, size_t workspace_bytes, uavgnn_stream_t stream) {
   if (N <= 0 || !seg_off || !x_dst || !W_s || !b_s || !W_d || !b_d || !attn || !out || !d_out || !attn_save ||
       !dW_s || !db_s || !dW_d || !db_d || !dattn || !dW_r || !db_r || !workspace)
     return UAVGNN_EINVAL;
@@ -676,7 +954,44 @@ extern "C" int uavgnn_gatv2_bwd(const float* x_src, int E, int F_src, const floa
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
   const bool sparse_hint = static_cast<long long>(E) < 16LL * N;
+  // low-degree two-feature relations (`near`): two destinations per wavefront (any degree is correct; pays for mean <= 8)
+  if (variant == 1 && F_src == 2 && nh == 4 && D == 64 && E > 0 && static_cast<long long>(E) <= 8LL * N && (ld_out % 4) == 0 &&
+      ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(W_s) |
+        reinterpret_cast<uintptr_t>(W_d) | reinterpret_cast<uintptr_t>(b_s) | reinterpret_cast<uintptr_t>(b_d) |
+        reinterpret_cast<uintptr_t>(attn)) & 15) == 0 && (reinterpret_cast<uintptr_t>(x_src) & 7) == 0) {
+    const int grid = bwd_blocks((N + 1) / 2);
+    hipLaunchKernelGGL(gatv2_bwd_pair_kernel, dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, N, W_s, b_s, W_d,
+                       b_d, attn, slope, out, d_out, ld_out, attn_save, ws);
+    int rc = launch_status();
+    if (rc) return rc;
+    constexpr int Pn = partial_len<2>(256);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((Pn + kWave - 1) / kWave), dim3(1024), 0, st, ws, grid, Pn, gp);
+    return launch_status();
+  }
   UAVGNN_DISPATCH_ALL((launch_bwd<FS_, NH_, D_>(x_src, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out,
                                                  ld_out, attn_save, gp, ws, sparse_hint, st)))
   return UAVGNN_EUNSUPPORTED;
+}
+
+extern "C" int uavgnn_gatv2_bwd(const float* x_src, int E, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
+                                const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d,
+                                const float* attn, int nh, int D, float slope, const float* out, const float* d_out,
+                                int ld_out, const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d,
+                                float* dattn, float* dW_r, float* db_r, void* workspace, size_t workspace_bytes,
+                                uavgnn_stream_t stream) {
+  return gatv2_bwd_checked(1, x_src, E, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, nh, D, slope, out,
+                           d_out, ld_out, attn_save, dW_s, db_s, dW_d, db_d, dattn, dW_r, db_r, workspace, workspace_bytes,
+                           stream);
+}
+
+extern "C" int uavgnn_gatv2_bwd_generic(const float* x_src, int E, int F_src, const float* x_dst, int F_dst,
+                                        const int32_t* seg_off, const int32_t* dst_order, int N, const float* W_s,
+                                        const float* b_s, const float* W_d, const float* b_d, const float* attn, int nh,
+                                        int D, float slope, const float* out, const float* d_out, int ld_out,
+                                        const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d,
+                                        float* dattn, float* dW_r, float* db_r, void* workspace, size_t workspace_bytes,
+                                        uavgnn_stream_t stream) {
+  return gatv2_bwd_checked(0, x_src, E, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, nh, D, slope, out,
+                           d_out, ld_out, attn_save, dW_s, db_s, dW_d, db_d, dattn, dW_r, db_r, workspace, workspace_bytes,
+                           stream);
 }
