@@ -255,6 +255,7 @@ def end_to_end(learner, a, device, cycles=2):
                         r_comm=mp.r_comm, device=device)
     gen = th.Generator(device=device)
     gen.manual_seed(99)
+    STATIC = os.environ.get("UAVGNN_E2E_STATIC", "1") == "1"   # per-step graphs without the host round trip for edge totals
 
     def positions():   # hotspot of M/5 groups of 5 GTs on a 200 m grid, UBSs on grid points (maps.py:96-111)
         grid = 200.0
@@ -269,7 +270,7 @@ def end_to_end(learner, a, device, cycles=2):
         o = env.reset(ubs, gts, generator=gen)
         h = learner.init_hidden(B)
         for t in range(T):
-            g = from_padded_obs(o["gt"], o["ubs"], o["agent"], o["d_u2u"], r_comm=mp.r_comm)
+            g = from_padded_obs(o["gt"], o["ubs"], o["agent"], o["d_u2u"], r_comm=mp.r_comm, static=STATIC)
             cur = {k: o[k].clone() for k in ("gt", "ubs", "agent", "d_u2u")}
             acts, h2 = learner.act(g, h, 0.05)
             o, rew, done, _ = env.step(acts)
@@ -280,7 +281,7 @@ def end_to_end(learner, a, device, cycles=2):
             h = h2
         m = rb.mem                                              # all B sequences, time-major padded tensors
         tm = {k: m[k].transpose(0, 1).contiguous() for k in ("gt", "ubs", "agent", "d_u2u")}
-        obs = [from_padded_obs(tm["gt"][t], tm["ubs"][t], tm["agent"][t], tm["d_u2u"][t], r_comm=mp.r_comm)
+        obs = [from_padded_obs(tm["gt"][t], tm["ubs"][t], tm["agent"][t], tm["d_u2u"][t], r_comm=mp.r_comm, static=STATIC)
                for t in range(T + 1)]
         flat = lambda x, lo: x[lo:].reshape((-1,) + x.shape[2:])  # noqa: E731
         batch = dict(obs=obs, obs_all=from_padded_obs(flat(tm["gt"], 0), flat(tm["ubs"], 0), flat(tm["agent"], 0)),

@@ -275,6 +275,16 @@ int uavgnn_env_step(const int32_t* int_consts, const double* f64_consts, int B, 
                     int32_t* gt_rb, float* rate_per_gt, double* rate_per_ubs, int32_t* mask_collision, double* reward,
                     float* done, float* obs_gt, float* obs_ubs, float* obs_agent, float* state, uavgnn_stream_t stream);
 
+/* The four construction passes above + the three prefix sums in ONE launch for small batches (B n <=
+ * uavgnn_build_graph_small_max_agents() = 4096 agents; reference: env_wrappers.py:65-89,:122-154 for B environments): seen_off /
+ * near_off / talk_off [B n + 1], graph_off [B + 1] and the compacted x_gt / x_ubs / talk_src / talk_eid (allocated by the
+ * caller at capacity B n M / B n U / B n n rows; the first E rows are written).  d_u2u NULL: no talk relation (talk_off, when
+ * given, is zero-filled).  Bit-identical to the multi-launch path. */
+int uavgnn_build_graph_small_max_agents(void);
+int uavgnn_build_graph_small(const float* gt, int M, int Fg, const float* ubs, int U, int Fu, const float* d_u2u, int n, int B,
+                             float r_comm, int32_t* seen_off, int32_t* near_off, int32_t* talk_off, float* x_gt, float* x_ubs,
+                             int32_t* talk_src, int32_t* talk_eid, int32_t* graph_off, uavgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

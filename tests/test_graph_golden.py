@@ -80,3 +80,31 @@ def test_device_builder_equals_reference_wrapper_output(case):
     # and the batch of host-built graphs moved to the device is the same object content-wise
     h = batch([from_obs_dicts(obs, raw["d_u2u"][f], r_comm) for f, obs in enumerate(_frames(raw))]).to("cuda")
     _assert_bit_exact(_arrays(h), ref, f"host->device[{case}]")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_static_single_launch_builder_equals_reference_wrapper_output(case):
+    """``from_padded_obs(static=True)`` on a small batch = ONE launch (csrc/build_graph.hip build_graph_small_kernel), edge
+    arrays at capacity: offsets bit-exact, the first E rows of every edge array bit-exact; and identical to the
+    multi-launch path on a batch too large for it."""
+    from uav_bs_ctrl_amd import from_padded_obs
+    raw, r_comm, ref = _load(case)
+    dev = {k: th.as_tensor(v).cuda() for k, v in raw.items()}
+    g = from_padded_obs(dev["gt"], dev["ubs"], dev["agent"], dev["d_u2u"], r_comm=r_comm, static=True)
+    got = _arrays(g)
+    for k in ("x_a", "seen_off", "near_off", "talk_off"):
+        assert np.array_equal(got[k], ref[k].astype(got[k].dtype)), k
+    for k, ko in (("x_gt", "seen_off"), ("x_ubs", "near_off"), ("talk_src", "talk_off"), ("talk_eid", "talk_off")):
+        E = int(ref[ko][-1])
+        assert got[k].shape[0] >= E and np.array_equal(got[k][:E], ref[k].astype(got[k].dtype)), k
+    # a batch above the single-launch limit takes the multi-launch static path: same content
+    reps = 4096 // (raw["agent"].shape[0] * raw["agent"].shape[1]) + 1
+    big = {k: v.repeat((reps,) + (1,) * (v.dim() - 1)) for k, v in dev.items()}
+    gb = from_padded_obs(big["gt"], big["ubs"], big["agent"], big["d_u2u"], r_comm=r_comm, static=True)
+    gs = from_padded_obs(big["gt"], big["ubs"], big["agent"], big["d_u2u"], r_comm=r_comm, static=False)
+    a, b = _arrays(gb), _arrays(gs)
+    for k in ("seen_off", "near_off", "talk_off"):
+        assert np.array_equal(a[k], b[k])
+    for k in ("x_gt", "x_ubs", "talk_src", "talk_eid"):
+        assert np.array_equal(a[k][:b[k].shape[0]], b[k]), k

@@ -57,6 +57,9 @@ SIGNATURES = {
                                     _c_st]),
     "uavgnn_talk_degrees": (_c_int, [_c_fp, _c_int, _c_int, _c_f32, _c_ip, _c_ip, _c_st]),
     "uavgnn_talk_compact": (_c_int, [_c_fp, _c_int, _c_int, _c_f32, _c_ip, _c_ip, _c_ip, _c_ip, _c_st]),
+    "uavgnn_build_graph_small_max_agents": (_c_int, []),
+    "uavgnn_build_graph_small": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_f32, _c_ip, _c_ip,
+                                          _c_ip, _c_fp, _c_fp, _c_ip, _c_ip, _c_ip, _c_st]),
     "uavgnn_degree_order_workspace_bytes": (ctypes.c_size_t, [_c_int]),
     "uavgnn_degree_order": (_c_int, [_c_ip, _c_int, _c_ip, ctypes.c_void_p, ctypes.c_size_t, _c_st]),
     "uavgnn_csc_transpose_workspace_bytes": (ctypes.c_size_t, [_c_int]),

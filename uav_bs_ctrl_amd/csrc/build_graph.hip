@@ -122,6 +122,122 @@ __global__ __launch_bounds__(kThreads) void talk_compact_kernel(const float* __r
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The whole construction in ONE launch for small batches (N <= 4096 agents: a rollout step of a few environments, the
+// per-step graphs of a 32-sequence update): one workgroup counts (wave per agent / per environment), scans the three
+// degree arrays in LDS and compacts.  At these sizes the multi-launch path above is 17 launches of ~3 us each around a
+// few hundred bytes of work (what bounds `act` at the reference's own operating point).  Results are
+// bit-identical to the multi-launch path; edge arrays are written at their true length (the caller allocates capacity).
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallMaxAgents = 4096;
+
+// exclusive scan of v[0..n) in LDS by the whole workgroup (n <= 4 * blockDim), total returned to every thread
+__device__ int block_exclusive_scan(int* __restrict__ v, int n, int* __restrict__ wave_tot) {
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  int x[4], s = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid * 4 + q;
+    x[q] = i < n ? v[i] : 0;
+    s += x[q];
+  }
+  int incl = s;                                 // inclusive scan of the per-thread sums inside the wave
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == kWave - 1) wave_tot[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < (kSmallThreads >> 6); ++w) {
+    const int t = wave_tot[w];
+    if (w < wave) base += t;
+    total += t;
+  }
+  int run = base + incl - s;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid * 4 + q;
+    if (i < n) v[i] = run;
+    run += x[q];
+  }
+  __syncthreads();
+  return total;
+}
+
+__global__ __launch_bounds__(kSmallThreads) void build_graph_small_kernel(
+    const float* __restrict__ gt, int M, const float* __restrict__ ubs, int U, const float* __restrict__ d_u2u, int n, int B,
+    float r, int32_t* __restrict__ seen_off, int32_t* __restrict__ near_off, int32_t* __restrict__ talk_off,
+    float* __restrict__ x_gt, float* __restrict__ x_ubs, int32_t* __restrict__ talk_src, int32_t* __restrict__ talk_eid,
+    int32_t* __restrict__ graph_off) {
+  __shared__ int sS[kSmallMaxAgents], sN[kSmallMaxAgents], sT[kSmallMaxAgents];
+  __shared__ int sWave[kSmallThreads >> 6];
+  const int N = B * n;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int W = kSmallThreads >> 6;
+  for (int a = wave; a < N; a += W) {                      // pass 1: degrees (as obs_degrees_kernel)
+    int cs = 0, cn = 0;
+    for (int m0 = 0; m0 < M; m0 += kWave) {
+      const int m = m0 + lane;
+      cs += __popcll(__ballot(m < M && gt[(static_cast<size_t>(a) * M + m) * 5] == 1.f));
+    }
+    for (int m0 = 0; m0 < U; m0 += kWave) {
+      const int m = m0 + lane;
+      cn += __popcll(__ballot(m < U && ubs[(static_cast<size_t>(a) * U + m) * 3] == 1.f));
+    }
+    if (lane == 0) {
+      sS[a] = cs;
+      sN[a] = cn;
+    }
+  }
+  if (d_u2u != nullptr) {
+    for (int b = wave; b < B; b += W) {                    // as talk_degrees_kernel (n <= 64)
+      const float* d = d_u2u + static_cast<size_t>(b) * n * n;
+      int cnt = 0;
+      for (int i = 0; i < n; ++i) cnt += (lane < n && d[i * n + lane] <= r) ? 1 : 0;
+      if (lane < n) sT[b * n + lane] = cnt;
+    }
+  }
+  __syncthreads();
+  const int Es = block_exclusive_scan(sS, N, sWave);
+  const int En = block_exclusive_scan(sN, N, sWave);
+  const int Et = d_u2u != nullptr ? block_exclusive_scan(sT, N, sWave) : 0;
+  for (int a = tid; a < N; a += kSmallThreads) {
+    seen_off[a] = sS[a];
+    near_off[a] = sN[a];
+    if (talk_off != nullptr) talk_off[a] = d_u2u != nullptr ? sT[a] : 0;
+  }
+  if (tid == 0) {
+    seen_off[N] = Es;
+    near_off[N] = En;
+    if (talk_off != nullptr) talk_off[N] = Et;
+  }
+  for (int b = tid; b <= B; b += kSmallThreads) graph_off[b] = b * n;
+  for (int a = wave; a < N; a += W) {                      // pass 2: compaction (as obs_compact_kernel)
+    compact_rows<4>(gt, M, 5, a, lane, x_gt, sS[a]);
+    compact_rows<2>(ubs, U, 3, a, lane, x_ubs, sN[a]);
+  }
+  if (d_u2u != nullptr) {
+    for (int b = wave; b < B; b += W) {                    // as talk_compact_kernel; env_base[b] = talk_off[b * n]
+      const float* d = d_u2u + static_cast<size_t>(b) * n * n;
+      int pos = lane < n ? sT[b * n + lane] : 0;
+      int eid = sT[b * n];
+      for (int i = 0; i < n; ++i) {
+        const bool e = lane < n && d[i * n + lane] <= r;
+        const unsigned long long mask = __ballot(e);
+        if (e) {
+          talk_src[pos] = b * n + i;
+          talk_eid[pos] = eid + lanes_below(mask, lane);
+          ++pos;
+        }
+        eid += __popcll(mask);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Derived indexes of a batch: the K1 hand-out order and the transpose of the `talk` CSC.  The reference pays the
 // equivalent (DGL materialises CSR/CSC formats lazily inside the first message-passing call of every new graph); here
 // they are integer passes of a few microseconds, deterministic (no float atomics, integer atomics only where the
@@ -485,5 +601,20 @@ extern "C" int uavgnn_csc_transpose_env(const int32_t* talk_off, const int32_t* 
   }
   hipLaunchKernelGGL(csc_transpose_env_kernel, dim3(capped_grid(B, kWavesPerBlock, 4096)), dim3(kThreads), 0, st,
                      talk_off, talk_src, graph_off, B, t_off, t_dst, t_pos);
+  return launch_status();
+}
+
+extern "C" int uavgnn_build_graph_small_max_agents(void) { return kSmallMaxAgents; }
+
+extern "C" int uavgnn_build_graph_small(const float* gt, int M, int Fg, const float* ubs, int U, int Fu, const float* d_u2u,
+                                        int n, int B, float r_comm, int32_t* seen_off, int32_t* near_off, int32_t* talk_off,
+                                        float* x_gt, float* x_ubs, int32_t* talk_src, int32_t* talk_eid, int32_t* graph_off,
+                                        uavgnn_stream_t stream) {
+  if (B < 0 || n < 1 || M < 0 || U < 0 || !seen_off || !near_off || !graph_off || (B > 0 && M > 0 && (!gt || !x_gt)) ||
+      (B > 0 && U > 0 && (!ubs || !x_ubs)) || (d_u2u && (!talk_off || !talk_src || !talk_eid)))
+    return UAVGNN_EINVAL;
+  if (Fg != 4 || Fu != 2 || n > kWave || static_cast<long long>(B) * n > kSmallMaxAgents) return UAVGNN_EUNSUPPORTED;
+  hipLaunchKernelGGL(build_graph_small_kernel, dim3(1), dim3(kSmallThreads), 0, static_cast<hipStream_t>(stream), gt, M, ubs,
+                     U, d_u2u, n, B, r_comm, seen_off, near_off, talk_off, x_gt, x_ubs, talk_src, talk_eid, graph_off);
   return launch_status();
 }

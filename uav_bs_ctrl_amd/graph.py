@@ -502,6 +502,17 @@ def from_obs_dicts(obs: Sequence[dict], d_u2u=None, r_comm: float = np.inf, with
     return HeteroBatch.from_arrays(**kw)
 
 
+_SMALL_MAX = None
+
+
+def _small_max_agents() -> int:
+    global _SMALL_MAX
+    if _SMALL_MAX is None:
+        from . import _lib as L
+        _SMALL_MAX = int(L.lib().uavgnn_build_graph_small_max_agents())
+    return _SMALL_MAX
+
+
 def from_padded_obs(gt: th.Tensor, ubs: th.Tensor, agent: th.Tensor, d_u2u: Optional[th.Tensor] = None,
                     r_comm: float = float("inf"), static: bool = False) -> HeteroBatch:
     """Device-side builder for B environments at once: padded observation tensors
@@ -520,13 +531,33 @@ def from_padded_obs(gt: th.Tensor, ubs: th.Tensor, agent: th.Tensor, d_u2u: Opti
     dev = gt.device
     gt, ubs, agent = L.f32c(gt), L.f32c(ubs), L.f32c(agent)
     i32 = dict(dtype=th.int32, device=dev)
+    with_comm = d_u2u is not None
+    if static and 0 < N <= _small_max_agents() and n <= 64 and Sg == 5 and Su == 3:
+        # small batch without a host round trip: counts, prefix sums and compaction in ONE launch
+        f32 = dict(dtype=th.float32, device=dev)
+        seen_off, near_off = th.empty(N + 1, **i32), th.empty(N + 1, **i32)
+        talk_off = th.empty(N + 1, **i32) if with_comm else None
+        x_gt, x_ubs = th.empty((N * M, 4), **f32), th.empty((N * U, 2), **f32)
+        talk_src = th.empty(N * n, **i32) if with_comm else None
+        talk_eid = th.empty(N * n, **i32) if with_comm else None
+        graph_off = th.empty(B + 1, **i32)
+        if with_comm:
+            d_u2u = L.f32c(d_u2u)
+        L.check(L.lib().uavgnn_build_graph_small(gt.data_ptr(), M, 4, ubs.data_ptr(), U, 2, L.ptr(d_u2u), n, B,
+                                                 float(min(r_comm, 3.0e38)), seen_off.data_ptr(), near_off.data_ptr(),
+                                                 L.ptr(talk_off), x_gt.data_ptr(), x_ubs.data_ptr(), L.ptr(talk_src),
+                                                 L.ptr(talk_eid), graph_off.data_ptr(), L.stream()), "uavgnn_build_graph_small")
+        kw = dict(x_a=agent.view(N, -1), x_gt=x_gt, seen_off=seen_off, x_ubs=x_ubs, near_off=near_off, graph_off=graph_off,
+                  hints={"max_graph_agents": n, "max_deg:seen": M, "max_deg:near": U})
+        if with_comm:
+            kw.update(talk_off=talk_off, talk_src=talk_src, talk_eid=talk_eid)
+        return HeteroBatch.from_arrays(device=dev, **kw)
     deg_s, deg_n = th.empty(N, **i32), th.empty(N, **i32)
     L.check(L.lib().uavgnn_obs_degrees(gt.data_ptr(), M, Sg - 1, ubs.data_ptr(), U, Su - 1, N, deg_s.data_ptr(),
                                        deg_n.data_ptr(), L.stream()), "uavgnn_obs_degrees")
     seen_off, near_off = th.zeros(N + 1, **i32), th.zeros(N + 1, **i32)
     seen_off[1:] = th.cumsum(deg_s, 0)
     near_off[1:] = th.cumsum(deg_n, 0)
-    with_comm = d_u2u is not None
     if with_comm:
         d_u2u = L.f32c(d_u2u)
         deg_t, env_e = th.empty(N, **i32), th.empty(B, **i32)
