@@ -285,6 +285,20 @@ int uavgnn_build_graph_small(const float* gt, int M, int Fg, const float* ubs, i
                              float r_comm, int32_t* seen_off, int32_t* near_off, int32_t* talk_off, float* x_gt, float* x_ubs,
                              int32_t* talk_src, int32_t* talk_eid, int32_t* graph_off, uavgnn_stream_t stream);
 
+/* K4, the whole GRU cell in one launch (reference: nn.GRUCell at algos/madrqn/agents/gnn_agents.py:29,:123,:164,:208,
+ * :246,:282; SURVEY 2.2 "gru_cell_fused"): h_out = GRUCell(inp [N, K_in] (leading dimension ld_inp), h [N, H]) with PyTorch's
+ * parameter layout W_ih [3H, K_in], W_hh [3H, H], b_ih / b_hh [3H] (gate order r, z, n).  Both GEMMs run on fp32 MFMA into
+ * shared r / z accumulators and separate gi_n / gh_n accumulators, gates in the epilogue: the [N, 3H] pre-activations never
+ * reach HBM.  pre_save (may be NULL): [N, 4H] = r_pre | z_pre | gi_n | gh_n (biases included) for
+ * uavgnn_gru_gates_bwd_fused, which produces the same d_gi / d_gh [N, 3H] and d_h [N, H] as uavgnn_gru_gates_bwd.
+ * uavgnn_gru_cell_supported: K_in and H multiples of 32 (else: vendor GEMMs + uavgnn_gru_gates_fwd). */
+int uavgnn_gru_cell_supported(int K_in, int H);
+int uavgnn_gru_cell_fwd(const float* inp, int ld_inp, int K_in, const float* h, int N, int H, const float* W_ih,
+                        const float* b_ih, const float* W_hh, const float* b_hh, float* h_out, float* pre_save,
+                        uavgnn_stream_t stream);
+int uavgnn_gru_gates_bwd_fused(const float* pre, const float* h, const float* d_hout, int N, int H, float* d_gi, float* d_gh,
+                               float* d_h, uavgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

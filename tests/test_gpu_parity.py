@@ -1299,3 +1299,43 @@ def test_low_degree_k1_backward_pair_kernel_agrees_with_generic(N, maxdeg, seed)
     for a, b, c, nm in zip(g_pair, g_gen, g_pair2, ["dW_s", "db_s", "dW_d", "db_d", "dattn", "dW_r", "db_r"]):
         assert th.equal(a, c), f"{nm}: pair kernel not bit-reproducible"
         assert_close(a, b, 2e-5, f"{nm}: pair vs generic", floor=1e-5 * max(1.0, float(N) ** 0.5 * 1e-2))
+
+
+@pytest.mark.parametrize("N,K_in,H", [(1000, 320, 256), (128, 256, 256), (77, 384, 256), (3, 32, 32), (4099, 96, 64)])
+def test_fused_gru_cell_kernel_vs_oracle(N, K_in, H):
+    """K4 as one kernel (csrc/gru_fused.hip: both GEMMs on fp32 MFMA into shared r / z and separate n accumulators, gates
+    in the epilogue) against nn.GRUCell's math in float64, forward and every gradient (backward = gate kernel on the saved
+    pre-activation sets + vendor GEMMs); N not a multiple of the 128-row tile, all supported K / H granularities; and
+    against the unfused path (vendor GEMMs + gate kernel)."""
+    from uav_bs_ctrl_amd import ops
+    gen = th.Generator().manual_seed(N + H)
+    cell = th.nn.GRUCell(K_in, H)
+    with th.no_grad():
+        for p in cell.parameters():
+            p.copy_(0.3 * th.randn(p.shape, generator=gen))
+    inp, h = th.randn(N, K_in, generator=gen), th.randn(N, H, generator=gen)
+    w = th.randn(N, H, generator=gen)
+    c64 = th.nn.GRUCell(K_in, H).double()
+    c64.load_state_dict({k: v.double() for k, v in cell.state_dict().items()})
+    i64, h64 = inp.double().requires_grad_(True), h.double().requires_grad_(True)
+    ref = c64(i64, h64)
+    gref = th.autograd.grad((ref * w.double()).sum(), [i64, h64] + list(c64.parameters()))
+    cell = cell.cuda()
+    res = {}
+    for fused in (True, False):
+        ops.GRU_FUSED = fused
+        try:
+            i_d, h_d = inp.cuda().requires_grad_(True), h.cuda().requires_grad_(True)
+            assert ops.gru_cell_supported(i_d, h_d) == fused
+            out = ops.gru_cell(i_d, h_d, cell)
+            got = th.autograd.grad((out * w.cuda()).sum(), [i_d, h_d] + list(cell.parameters()))
+            with th.no_grad():
+                out_ng = ops.gru_cell(inp.cuda(), h.cuda(), cell)
+            assert th.equal(out_ng, out.detach())
+            res[fused] = (out.detach(), got)
+        finally:
+            ops.GRU_FUSED = True
+    for fused, (out, got) in res.items():
+        assert_close(out, ref, 1e-5, f"h' fused={fused}")
+        for a, b, nm in zip(got, gref, ["d_inp", "d_h", "dW_ih", "dW_hh", "db_ih", "db_hh"]):
+            assert_close(a, b, 1e-4, f"{nm} fused={fused}", floor=1e-5)

@@ -136,6 +136,119 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel2(const float* __restric
         C[static_cast<size_t>(m0 + wm + a * 16 + 4 * g + r) * N + n0 + wn + b * 16 + j] = acc[a][b][r];
 }
 
+// Variant 3: variant 1 with a BK = 32 slice (half the barriers) and conflict-free stride 34; optional 32x32x2 MFMA.
+template <bool MF32>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel3(const float* __restrict__ A, const float* __restrict__ W,
+                                                          float* __restrict__ C, int M, int N, int K) {
+  constexpr int BKK = 32, ST = 34;
+  __shared__ __attribute__((aligned(16))) float sA[BM * ST], sB[BN * ST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // loader: thread -> (row = tid / 2, 16 consecutive k)
+  const int lr = tid >> 1, lk = (tid & 1) * 16;
+  const float* ga = A + static_cast<size_t>(m0 + lr) * K + lk;
+  const float* gb = W + static_cast<size_t>(n0 + lr) * K + lk;
+  float4 ra[4], rb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { ra[q] = reinterpret_cast<const float4*>(ga)[q]; rb[q] = reinterpret_cast<const float4*>(gb)[q]; }
+  if constexpr (!MF32) {
+    const int j = lane & 15, g = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += BKK) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float* pa = sA + lr * ST + lk + 4 * q;
+        float* pb = sB + lr * ST + lk + 4 * q;
+        *reinterpret_cast<float2*>(pa) = make_float2(ra[q].x, ra[q].y); *reinterpret_cast<float2*>(pa + 2) = make_float2(ra[q].z, ra[q].w);
+        *reinterpret_cast<float2*>(pb) = make_float2(rb[q].x, rb[q].y); *reinterpret_cast<float2*>(pb + 2) = make_float2(rb[q].z, rb[q].w);
+      }
+      __syncthreads();
+      if (k0 + BKK < K) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ra[q] = reinterpret_cast<const float4*>(ga + k0 + BKK)[q];
+          rb[q] = reinterpret_cast<const float4*>(gb + k0 + BKK)[q];
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < BKK; ks += 4) {
+        float fa[4], fb[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) fa[a] = sA[(wm + a * 16 + j) * ST + ks + g];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fb[b] = sB[(wn + b * 16 + j) * ST + ks + g];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          C[static_cast<size_t>(m0 + wm + a * 16 + 4 * g + r) * N + n0 + wn + b * 16 + j] = acc[a][b][r];
+  } else {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int j = lane & 31, g = lane >> 5;      // 32x32x2: operand row / column j, k index g
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += BKK) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float* pa = sA + lr * ST + lk + 4 * q;
+        float* pb = sB + lr * ST + lk + 4 * q;
+        *reinterpret_cast<float2*>(pa) = make_float2(ra[q].x, ra[q].y); *reinterpret_cast<float2*>(pa + 2) = make_float2(ra[q].z, ra[q].w);
+        *reinterpret_cast<float2*>(pb) = make_float2(rb[q].x, rb[q].y); *reinterpret_cast<float2*>(pb + 2) = make_float2(rb[q].z, rb[q].w);
+      }
+      __syncthreads();
+      if (k0 + BKK < K) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ra[q] = reinterpret_cast<const float4*>(ga + k0 + BKK)[q];
+          rb[q] = reinterpret_cast<const float4*>(gb + k0 + BKK)[q];
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < BKK; ks += 2) {
+        float fa[2], fb[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa[a] = sA[(wm + a * 32 + j) * ST + ks + g];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fb[b] = sB[(wn + b * 32 + j) * ST + ks + g];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    // D layout 32x32: lane (g, j): column j, rows 8*q + 4*g + r for acc[4*q + r]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            C[static_cast<size_t>(m0 + wm + a * 32 + 8 * q + 4 * g + r) * N + n0 + wn + b * 32 + j] = acc[a][b][4 * q + r];
+  }
+}
+
 int main() {
   const int M = 32768;
   rocblas_handle h;
@@ -152,6 +265,8 @@ int main() {
     auto mine = [&] { hipLaunchKernelGGL(gemm_nt_kernel, dim3(N / BN, M / BM), dim3(256), 0, 0, A, W, C, M, N, K); };
     auto mine2 = [&] { hipLaunchKernelGGL(gemm_nt_kernel2<16>, dim3(N / BN, M / BM), dim3(256), 0, 0, A, W, C, M, N, K); };
     auto mine3 = [&] { hipLaunchKernelGGL(gemm_nt_kernel2<32>, dim3(N / BN, M / BM), dim3(256), 0, 0, A, W, C, M, N, K); };
+    auto mine4 = [&] { hipLaunchKernelGGL(gemm_nt_kernel3<false>, dim3(N / BN, M / BM), dim3(256), 0, 0, A, W, C, M, N, K); };
+    auto mine5 = [&] { hipLaunchKernelGGL(gemm_nt_kernel3<true>, dim3(N / BN, M / BM), dim3(256), 0, 0, A, W, C, M, N, K); };
     const float one = 1.f, zero = 0.f;
     // row-major C[M,N] = A W^T  ==  column-major C^T[N,M] = W(op T: [N,K]) A^T([K,M]):  sgemm(T, N, N, M, K, W ld K, A ld K, C ld N)
     auto vendor = [&] { rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, N, M, K, &one, W, K, A, K, &zero, C2, N); };
@@ -173,6 +288,16 @@ int main() {
     };
     const double fl = 2.0 * M * N * K;
     const float t1 = time_us(mine), t2 = time_us(vendor);
+    for (int v = 0; v < 2; ++v) {
+      if (v == 0) mine4(); else mine5();
+      hipDeviceSynchronize();
+      hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);
+      double e2 = 0;
+      for (size_t i = 0; i < c1.size(); i += 97) e2 = fmax(e2, fabs(double(c1[i]) - c2[i]));
+      const float tv = v == 0 ? time_us(mine4) : time_us(mine5);
+      printf("   variant 3 (BK=32, stride 34, %s): %7.1f us = %6.1f TFLOP/s  (vs rocBLAS %.2f)  max|diff| %.2e\n",
+             v == 0 ? "16x16x4 MFMA" : "32x32x2 MFMA", tv, fl / tv * 1e-6, t2 / tv, e2);
+    }
     for (int v = 0; v < 2; ++v) {
       if (v == 0) mine2(); else mine3();
       hipDeviceSynchronize();

@@ -80,6 +80,9 @@ SIGNATURES = {
     "uavgnn_env_step": (_c_int, [ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double), _c_int] + [_c_fp] * 22 + [_c_st]),
     "uavgnn_adamw_polyak": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, ctypes.c_longlong, _c_fp, _c_f32,
                                      _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_st]),
+    "uavgnn_gru_cell_supported": (_c_int, [_c_int, _c_int]),
+    "uavgnn_gru_cell_fwd": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_st]),
+    "uavgnn_gru_gates_bwd_fused": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_st]),
     "uavgnn_gru_gates_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_st]),
     "uavgnn_gru_gates_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_st]),
 }

@@ -104,9 +104,7 @@ def _gru(cell: nn.GRUCell, i_parts, h):
     fused HIP kernel (K4).  The cat of a [N,H] and a [N,msg] block costs less HBM traffic than summing two [N,3H]
     partial products would."""
     inp = i_parts[0] if len(i_parts) == 1 else th.cat(i_parts, 1)
-    gi = ops.linear(inp, cell.weight_ih, cell.bias_ih)
-    gh = ops.linear(h, cell.weight_hh, cell.bias_hh)
-    return ops.gru_gates(gi, gh, h)
+    return ops.gru_cell(inp, h, cell)     # K4: one fused launch when the shape has an instantiation
 
 
 def _parent(g) -> HeteroBatch:

@@ -1,0 +1,246 @@
+// K4 as SURVEY 2.2 specifies it: the WHOLE GRU cell in one kernel - both GEMMs on fp32 MFMA accumulating into r / z / n gate
+// tiles, sigmoid / tanh / blend epilogue - so that the [N, 3H] pre-activation blocks gi, gh never reach HBM.
+// Replaces nn.GRUCell at /root/reference/algos/madrqn/agents/gnn_agents.py:29,:123,:164,:208,:246,:282 (PyTorch gate order
+// r, z, n):
+//   r = sigma(W_ir i + b_ir + W_hr h + b_hr)   z = sigma(W_iz i + b_iz + W_hz h + b_hz)
+//   n = tanh(W_in i + b_in + r (W_hn h + b_hn))   h' = (1 - z) n + z h
+//
+// One workgroup owns 128 rows (agents) x 32 hidden units.  Its four wavefronts (2 x 2) each hold 64 rows x 16 hidden units
+// of FOUR accumulator sets - r and z (shared by both GEMMs: the sum is all the gates need), gi_n and gh_n - i.e. 4 x 4
+// v_mfma_f32_16x16x4_f32 tiles = 64 accumulator registers, the shape of a plain 64 x 64 GEMM wave tile.  Phase 1 walks K
+// over the input [x || c] with the r / z / n rows of W_ih as B operand, phase 2 walks K over h with the rows of W_hh; per
+// 32-wide K slice the operands are staged in LDS (rows padded to 34 floats: conflict-free dword fragment reads), the next
+// slice is in flight in registers while the current one computes.  The epilogue applies biases and gate math in registers
+// on the MFMA D layout and stores h'; the training variant also stores the four pre-activation sets [N, 4H]
+// (r_pre | z_pre | gi_n | gh_n, biases included) for uavgnn_gru_gates_bwd_fused.
+//
+// GEMM core measured stand-alone (tools/ubench/gemm_f32.hip, profiles/r02_ubench_gemm_f32_vs_rocblas.txt): 104-107 TFLOP/s
+// at the GRU shapes = 0.98-1.00 of rocBLAS, 0.92-0.95 of the recorded hipBLASLt solutions; the fused cell wins by what it
+// does NOT do: the 44 us gate pass and 8 KB per agent of gi / gh traffic.
+#include "common.h"
+
+namespace uavgnn {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int BM = 128, BJ = 32, BK = 32, ST = 34;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <bool SAVE>
+__global__ __launch_bounds__(256, 2) void gru_cell_fwd_kernel(
+    const float* __restrict__ inp, int ld_inp, int K1, const float* __restrict__ h, int N, int H,
+    const float* __restrict__ W_ih, const float* __restrict__ b_ih, const float* __restrict__ W_hh,
+    const float* __restrict__ b_hh, float* __restrict__ h_out, float* __restrict__ pre) {
+  __shared__ __attribute__((aligned(16))) float sA[BM * ST];
+  __shared__ __attribute__((aligned(16))) float sB[3 * BJ * ST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int wm = (wave >> 1) * 64, wc = (wave & 1) * 16;
+  const int m0 = blockIdx.y * BM, j0 = blockIdx.x * BJ;
+
+  f32x4 acc[4][4];     // [row tile][set: r, z, gi_n, gh_n]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[a][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // loaders: A tile 128 rows x 32 k (thread -> row tid/2, 16 k), B tile 96 rows x 32 k (three float4 per thread)
+  const int lr = tid >> 1, lk = (tid & 1) * 16;
+  const int arow = min(m0 + lr, N - 1);                  // rows past N: clamped loads, masked stores
+  float4 ra[4], rb[3];
+  auto gload = [&](const float* __restrict__ Asrc, int lda, const float* __restrict__ Wsrc, int K, int k0) {
+    const float* pa = Asrc + static_cast<size_t>(arow) * lda + k0 + lk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ra[q] = reinterpret_cast<const float4*>(pa)[q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = tid + 256 * q, row = idx >> 3, c4 = idx & 7;   // row = set * 32 + unit
+      const int wrow = (row >> 5) * H + j0 + (row & 31);
+      rb[q] = *reinterpret_cast<const float4*>(Wsrc + static_cast<size_t>(wrow) * K + k0 + 4 * c4);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float* p = sA + lr * ST + lk + 4 * q;
+      *reinterpret_cast<float2*>(p) = make_float2(ra[q].x, ra[q].y);
+      *reinterpret_cast<float2*>(p + 2) = make_float2(ra[q].z, ra[q].w);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = tid + 256 * q, row = idx >> 3, c4 = idx & 7;
+      float* p = sB + row * ST + 4 * c4;
+      *reinterpret_cast<float2*>(p) = make_float2(rb[q].x, rb[q].y);
+      *reinterpret_cast<float2*>(p + 2) = make_float2(rb[q].z, rb[q].w);
+    }
+  };
+
+  // ---- phase 1: input GEMM (sets r, z, gi_n) -------------------------------------------------------------------------
+  gload(inp, ld_inp, W_ih, K1, 0);
+  for (int k0 = 0; k0 < K1; k0 += BK) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (k0 + BK < K1) gload(inp, ld_inp, W_ih, K1, k0 + BK);
+    else gload(h, H, W_hh, H, 0);                         // first slice of phase 2
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      float fa[4], fb[3];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fa[a] = sA[(wm + a * 16 + j) * ST + ks + g];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) fb[s] = sB[(s * BJ + wc + j) * ST + ks + g];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc[a][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[s], acc[a][s], 0, 0, 0);
+    }
+  }
+  // ---- phase 2: hidden GEMM (sets r, z, gh_n) ------------------------------------------------------------------------
+  for (int k0 = 0; k0 < H; k0 += BK) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (k0 + BK < H) gload(h, H, W_hh, H, k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      float fa[4], fb[3];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fa[a] = sA[(wm + a * 16 + j) * ST + ks + g];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) fb[s] = sB[(s * BJ + wc + j) * ST + ks + g];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[0], acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[1], acc[a][1], 0, 0, 0);
+        acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[2], acc[a][3], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue on the D layout: lane (g, j) holds rows 4g..4g+3 of every row tile, hidden unit c ------------------------
+  // The h tile [128 x 32] comes in and the h' tile goes out through LDS with 16-byte row-contiguous accesses (the D layout
+  // alone would touch HBM in 64-byte pieces).
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + 256 * q, row = idx >> 3, c4 = idx & 7;
+    const float4 t = *reinterpret_cast<const float4*>(h + static_cast<size_t>(min(m0 + row, N - 1)) * H + j0 + 4 * c4);
+    float* p = sA + row * ST + 4 * c4;
+    *reinterpret_cast<float2*>(p) = make_float2(t.x, t.y);
+    *reinterpret_cast<float2*>(p + 2) = make_float2(t.z, t.w);
+  }
+  __syncthreads();
+  const int c = j0 + wc + j;
+  const float b_r = b_ih[c] + b_hh[c], b_z = b_ih[H + c] + b_hh[H + c], b_in = b_ih[2 * H + c], b_hn = b_hh[2 * H + c];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lrow = wm + a * 16 + 4 * g + r;
+      const int row = m0 + lrow;
+      const float pr = acc[a][0][r] + b_r, pz = acc[a][1][r] + b_z, gin = acc[a][2][r] + b_in, ghn = acc[a][3][r] + b_hn;
+      const float rr = sigmoidf_(pr), zz = sigmoidf_(pz);
+      const float nn = tanhf(fmaf(rr, ghn, gin));
+      float* hp = sA + lrow * ST + wc + j;
+      *hp = fmaf(zz, *hp - nn, nn);                      // every element of the tile has exactly one owner lane
+      if (SAVE && row < N) {
+        float* p = pre + static_cast<size_t>(row) * 4 * H + c;
+        p[0] = pr;
+        p[H] = pz;
+        p[2 * H] = gin;
+        p[3 * H] = ghn;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + 256 * q, row = idx >> 3, c4 = idx & 7;
+    if (m0 + row < N) {
+      const float* p = sA + row * ST + 4 * c4;
+      *reinterpret_cast<float4*>(h_out + static_cast<size_t>(m0 + row) * H + j0 + 4 * c4) = make_float4(p[0], p[1], p[2], p[3]);
+    }
+  }
+}
+
+// pointwise backward from the saved pre-activation sets: d_gi [N,3H], d_gh [N,3H], d_h [N,H] (layout of gru.hip's kernel)
+__global__ __launch_bounds__(256) void gru_gates_bwd_fused_kernel(const float* __restrict__ pre, const float* __restrict__ h,
+                                                                  const float* __restrict__ d_hout, long long total, int H,
+                                                                  float* __restrict__ d_gi, float* __restrict__ d_gh,
+                                                                  float* __restrict__ d_h) {
+  const int HV = H / 4;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
+    const long long row = i / HV;
+    const int col = static_cast<int>(i - row * HV) * 4;
+    const float* p = pre + row * 4 * H + col;
+    const float4 pr = *reinterpret_cast<const float4*>(p), pz = *reinterpret_cast<const float4*>(p + H);
+    const float4 gin = *reinterpret_cast<const float4*>(p + 2 * H), ghn = *reinterpret_cast<const float4*>(p + 3 * H);
+    const float4 hh = *reinterpret_cast<const float4*>(h + row * H + col);
+    const float4 dho = *reinterpret_cast<const float4*>(d_hout + row * H + col);
+    const float a_pr[4] = {pr.x, pr.y, pr.z, pr.w}, a_pz[4] = {pz.x, pz.y, pz.z, pz.w};
+    const float a_gi[4] = {gin.x, gin.y, gin.z, gin.w}, a_gh[4] = {ghn.x, ghn.y, ghn.z, ghn.w};
+    const float a_h[4] = {hh.x, hh.y, hh.z, hh.w}, a_d[4] = {dho.x, dho.y, dho.z, dho.w};
+    float dr[4], dz[4], dni[4], dnh[4], dh[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float r = sigmoidf_(a_pr[t]), z = sigmoidf_(a_pz[t]);
+      const float n = tanhf(fmaf(r, a_gh[t], a_gi[t]));
+      const float dn_pre = a_d[t] * (1.f - z) * (1.f - n * n);
+      dni[t] = dn_pre;
+      dnh[t] = dn_pre * r;
+      dr[t] = dn_pre * a_gh[t] * r * (1.f - r);
+      dz[t] = a_d[t] * (a_h[t] - n) * z * (1.f - z);
+      dh[t] = a_d[t] * z;
+    }
+    float* gi = d_gi + row * 3 * H + col;
+    float* gh = d_gh + row * 3 * H + col;
+    *reinterpret_cast<float4*>(gi) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+    *reinterpret_cast<float4*>(gi + H) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+    *reinterpret_cast<float4*>(gi + 2 * H) = make_float4(dni[0], dni[1], dni[2], dni[3]);
+    *reinterpret_cast<float4*>(gh) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+    *reinterpret_cast<float4*>(gh + H) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+    *reinterpret_cast<float4*>(gh + 2 * H) = make_float4(dnh[0], dnh[1], dnh[2], dnh[3]);
+    *reinterpret_cast<float4*>(d_h + row * H + col) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+  }
+}
+
+}  // namespace
+}  // namespace uavgnn
+
+using namespace uavgnn;
+
+extern "C" int uavgnn_gru_cell_supported(int K_in, int H) {
+  return (K_in >= BK && K_in % BK == 0 && H >= BK && H % BK == 0) ? 1 : 0;
+}
+
+extern "C" int uavgnn_gru_cell_fwd(const float* inp, int ld_inp, int K_in, const float* h, int N, int H, const float* W_ih,
+                                   const float* b_ih, const float* W_hh, const float* b_hh, float* h_out, float* pre_save,
+                                   uavgnn_stream_t stream) {
+  if (N < 0 || !inp || !h || !W_ih || !b_ih || !W_hh || !b_hh || !h_out || ld_inp < K_in) return UAVGNN_EINVAL;
+  if (!uavgnn_gru_cell_supported(K_in, H) || (ld_inp & 3) ||
+      ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(W_ih) |
+        reinterpret_cast<uintptr_t>(W_hh)) & 15))
+    return UAVGNN_EUNSUPPORTED;
+  if (N == 0) return 0;
+  const dim3 grid(H / BJ, (N + BM - 1) / BM), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (pre_save != nullptr)
+    hipLaunchKernelGGL(gru_cell_fwd_kernel<true>, grid, block, 0, st, inp, ld_inp, K_in, h, N, H, W_ih, b_ih, W_hh, b_hh, h_out,
+                       pre_save);
+  else
+    hipLaunchKernelGGL(gru_cell_fwd_kernel<false>, grid, block, 0, st, inp, ld_inp, K_in, h, N, H, W_ih, b_ih, W_hh, b_hh, h_out,
+                       pre_save);
+  return launch_status();
+}
+
+extern "C" int uavgnn_gru_gates_bwd_fused(const float* pre, const float* h, const float* d_hout, int N, int H, float* d_gi,
+                                          float* d_gh, float* d_h, uavgnn_stream_t stream) {
+  if (N < 0 || H <= 0 || !pre || !h || !d_hout || !d_gi || !d_gh || !d_h) return UAVGNN_EINVAL;
+  if (H % 4) return UAVGNN_EUNSUPPORTED;
+  if (N == 0) return 0;
+  const long long total = static_cast<long long>(N) * (H / 4);
+  hipLaunchKernelGGL(gru_gates_bwd_fused_kernel, dim3(capped_grid(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     pre, h, d_hout, total, H, d_gi, d_gh, d_h);
+  return launch_status();
+}

@@ -293,6 +293,78 @@ def gru_gates(gi, gh, h):
     return _GruGates.apply(gi, gh, h)
 
 
+GRU_FUSED = True   # K4 as one kernel (csrc/gru_fused.hip); False: vendor GEMMs + the gate kernel (A/B, tools/gru_probe.py)
+
+
+def gru_cell_supported(inp, h) -> bool:
+    return bool(GRU_FUSED and inp.is_cuda and inp.dtype == th.float32 and h.dtype == th.float32 and inp.stride(1) == 1
+                and inp.stride(0) % 4 == 0 and inp.data_ptr() % 16 == 0
+                and L.lib().uavgnn_gru_cell_supported(inp.shape[1], h.shape[1]))
+
+
+def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save):
+    """h' (and the [N, 4H] pre-activation sets when `save`) of the fused GRU cell."""
+    N, H = h.shape
+    h2 = th.empty_like(h)
+    pre = th.empty((N, 4 * H), dtype=th.float32, device=h.device) if save else None
+    with KERNEL_TIMER.span("gru_cell_fwd"):
+        rc = L.lib().uavgnn_gru_cell_fwd(inp.data_ptr(), inp.stride(0), inp.shape[1], h.data_ptr(), N, H, W_ih.data_ptr(),
+                                         b_ih.data_ptr(), W_hh.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), L.ptr(pre),
+                                         L.stream())
+    L.check(rc, "uavgnn_gru_cell_fwd")
+    return h2, pre
+
+
+def _gru_gates_bwd_from_pre(pre, h, d_hout):
+    N, H = h.shape
+    d_gi = th.empty((N, 3 * H), dtype=th.float32, device=h.device)
+    d_gh, dh = th.empty_like(d_gi), th.empty_like(h)
+    with KERNEL_TIMER.span("gru_gates_bwd"):
+        rc = L.lib().uavgnn_gru_gates_bwd_fused(pre.data_ptr(), h.data_ptr(), d_hout.data_ptr(), N, H, d_gi.data_ptr(),
+                                                d_gh.data_ptr(), dh.data_ptr(), L.stream())
+    L.check(rc, "uavgnn_gru_gates_bwd_fused")
+    return d_gi, d_gh, dh
+
+
+class _GruCellFused(th.autograd.Function):
+    """nn.GRUCell as ONE forward launch (K4); backward = gate kernel on the saved pre-activations + vendor GEMMs."""
+
+    @staticmethod
+    def forward(ctx, inp, h, W_ih, b_ih, W_hh, b_hh, train):
+        inp, h = L.f32c(inp), L.f32c(h)
+        p = [L.f32c(t.detach()) for t in (W_ih, b_ih, W_hh, b_hh)]
+        h2, pre = _gru_cell_launch(inp, h, *p, save=bool(train))
+        if train:
+            ctx.save_for_backward(inp, h, pre, p[0], p[2])
+        return h2
+
+    @staticmethod
+    def backward(ctx, d_h2):
+        inp, h, pre, W_ih, W_hh = ctx.saved_tensors
+        d_gi, d_gh, dh = _gru_gates_bwd_from_pre(pre, h, L.f32c(d_h2))
+        d_inp = th.mm(d_gi, W_ih) if ctx.needs_input_grad[0] else None
+        if ctx.needs_input_grad[1]:
+            dh.addmm_(d_gh, W_hh)
+        else:
+            dh = None
+        gWih = _wgrad(d_gi, inp) if ctx.needs_input_grad[2] else None
+        gbih = _colsum(d_gi) if ctx.needs_input_grad[3] else None
+        gWhh = _wgrad(d_gh, h) if ctx.needs_input_grad[4] else None
+        gbhh = _colsum(d_gh) if ctx.needs_input_grad[5] else None
+        return d_inp, dh, gWih, gbih, gWhh, gbhh, None
+
+
+def gru_cell(inp, h, cell):
+    """nn.GRUCell(inp, h) with `cell`'s parameters: fused kernel when the shape has an instantiation, else vendor GEMMs +
+    the gate kernel."""
+    if gru_cell_supported(inp, h):
+        train = th.is_grad_enabled() and (inp.requires_grad or h.requires_grad or cell.weight_ih.requires_grad)
+        return _GruCellFused.apply(inp, h, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, train)
+    gi = linear(inp, cell.weight_ih, cell.bias_ih)
+    gh = linear(h, cell.weight_hh, cell.bias_hh)
+    return gru_gates(gi, gh, h)
+
+
 def _row_blocks(n, cap=256, min_rows=32):
     """Largest power-of-two block count <= cap that divides n with >= min_rows rows per block."""
     S = 1
@@ -503,7 +575,7 @@ class _TarmacStep(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, h, Wp, bp, W_ih, b_ih, W_hh, b_hh, W_out, b_out, M, K, talk_off, talk_src, t_off, t_dst, t_pos,
-                split, env=None, dx_out=None):
+                split, env=None, dx_out=None, train=True):
         L.require_gpu(x, h, Wp, W_ih, talk_off)
         N, H = x.shape
         x, h = L.f32c(x), L.f32c(h)
@@ -516,15 +588,20 @@ class _TarmacStep(th.autograd.Function):
         _launch_talk_fwd(env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld, K, M,
                          talk_off, talk_src, N, 1.0 / K, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(), x.data_ptr(),
                          x.stride(0), H)
-        gi = th.addmm(b_ih, inp, W_ih.t())
-        gh = th.addmm(b_hh, h, W_hh.t())
-        h2 = th.empty_like(h)
-        with KERNEL_TIMER.span("gru_gates_fwd"):
-            rc = L.lib().uavgnn_gru_gates_fwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), N, H, h2.data_ptr(), L.stream())
-        L.check(rc, "uavgnn_gru_gates_fwd")
+        fused = gru_cell_supported(inp, h) and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (W_ih, W_hh))
+        if fused:      # K4 in one launch: gi / gh never reach HBM; training forwards keep the [N, 4H] pre-activation sets
+            h2, pre = _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save=bool(train))
+            gi = gh = pre if pre is not None else h2           # placeholders keep save_for_backward's arity
+        else:
+            gi = th.addmm(b_ih, inp, W_ih.t())
+            gh = th.addmm(b_hh, h, W_hh.t())
+            h2 = th.empty_like(h)
+            with KERNEL_TIMER.span("gru_gates_fwd"):
+                rc = L.lib().uavgnn_gru_gates_fwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), N, H, h2.data_ptr(), L.stream())
+            L.check(rc, "uavgnn_gru_gates_fwd")
         q = th.addmm(b_out, h2, W_out.t())
         ctx.dims = (M, K)
-        ctx.split, ctx.env, ctx.dx_out = split, env, dx_out
+        ctx.split, ctx.env, ctx.dx_out, ctx.fused_gru = split, env, dx_out, fused
         ctx.save_for_backward(x, h, proj, inp, gi, gh, h2, a_save, Wp, W_ih, W_hh, W_out, talk_off, talk_src, t_off,
                               t_dst, t_pos)
         return q, h2
@@ -548,11 +625,14 @@ class _TarmacStep(th.autograd.Function):
             dh2_tot = dh2.addmm_(dq, W_out)
         else:
             dh2_tot = th.addmm(dh2, dq, W_out)
-        d_gi, d_gh, dh = th.empty_like(gi), th.empty_like(gh), th.empty_like(h)
-        with KERNEL_TIMER.span("gru_gates_bwd"):
-            rc = L.lib().uavgnn_gru_gates_bwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), dh2_tot.data_ptr(), N, H,
-                                              d_gi.data_ptr(), d_gh.data_ptr(), dh.data_ptr(), L.stream())
-        L.check(rc, "uavgnn_gru_gates_bwd")
+        if ctx.fused_gru:
+            d_gi, d_gh, dh = _gru_gates_bwd_from_pre(gi, h, dh2_tot)      # gi holds the saved pre-activation sets
+        else:
+            d_gi, d_gh, dh = th.empty_like(gi), th.empty_like(gh), th.empty_like(h)
+            with KERNEL_TIMER.span("gru_gates_bwd"):
+                rc = L.lib().uavgnn_gru_gates_bwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), dh2_tot.data_ptr(), N, H,
+                                                  d_gi.data_ptr(), d_gh.data_ptr(), dh.data_ptr(), L.stream())
+            L.check(rc, "uavgnn_gru_gates_bwd")
         d_inp = th.mm(d_gi, W_ih)                                          # [N, H + M]: d x | d c
         dh.addmm_(d_gh, W_hh)
         if sink is not None:
@@ -587,7 +667,7 @@ class _TarmacStep(th.autograd.Function):
             gWih, gbih = _wgrad(d_gi, inp), _colsum(d_gi)
             gWhh, gbhh = _wgrad(d_gh, h), th.cat((gbih[:2 * H], _colsum(d_gh[:, 2 * H:])))
             gWo, gbo = _wgrad(dq, h2), _colsum(dq)
-        return (dx, dh, gWp, gbp, gWih, gbih, gWhh, gbhh, gWo, gbo) + (None,) * 10
+        return (dx, dh, gWp, gbp, gWih, gbih, gWhh, gbhh, gWo, gbo) + (None,) * 11
 
 
 def tarmac_step(x, h, g, comm, f_out, stacked=None, dx_out=None):
@@ -628,8 +708,9 @@ def tarmac_step(x, h, g, comm, f_out, stacked=None, dx_out=None):
         else:
             _add_grad(params[name], grad)
 
+    train = th.is_grad_enabled() and (x.requires_grad or h.requires_grad or cell.weight_ih.requires_grad)
     return _TarmacStep.apply(x, h, Wp, bp, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, f_out.weight,
-                             f_out.bias, M, K, off, src, t_off, t_dst, t_pos, split, env, dx_out)
+                             f_out.bias, M, K, off, src, t_off, t_dst, t_pos, split, env, dx_out, train)
 
 
 class _DiscComm(th.autograd.Function):
