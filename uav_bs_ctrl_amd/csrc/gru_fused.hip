@@ -84,17 +84,22 @@ __global__ __launch_bounds__(256, 2) void gru_cell_fwd_kernel(
     __syncthreads();
     if (k0 + BK < K1) gload(inp, ld_inp, W_ih, K1, k0 + BK);
     else gload(h, H, W_hh, H, 0);                         // first slice of phase 2
+    // fragment reads: lane group g owns k = 8 p + 2 g + {0, 1} of every 8-wide sub-slice p (the contraction order is free as
+    // long as both operands use the same mapping), so ONE ds_read_b64 serves two k-steps
 #pragma unroll
-    for (int ks = 0; ks < BK; ks += 4) {
-      float fa[4], fb[3];
+    for (int ks = 0; ks < BK; ks += 8) {
+      float2 fa[4], fb[3];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) fa[a] = sA[(wm + a * 16 + j) * ST + ks + g];
+      for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const float2*>(sA + (wm + a * 16 + j) * ST + ks + 2 * g);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) fb[s] = sB[(s * BJ + wc + j) * ST + ks + g];
+      for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const float2*>(sB + (s * BJ + wc + j) * ST + ks + 2 * g);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) acc[a][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[s], acc[a][s], 0, 0, 0);
+        for (int s = 0; s < 3; ++s) {
+          acc[a][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].x, fb[s].x, acc[a][s], 0, 0, 0);
+          acc[a][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].y, fb[s].y, acc[a][s], 0, 0, 0);
+        }
     }
   }
   // ---- phase 2: hidden GEMM (sets r, z, gh_n) ------------------------------------------------------------------------
@@ -104,17 +109,20 @@ __global__ __launch_bounds__(256, 2) void gru_cell_fwd_kernel(
     __syncthreads();
     if (k0 + BK < H) gload(h, H, W_hh, H, k0 + BK);
 #pragma unroll
-    for (int ks = 0; ks < BK; ks += 4) {
-      float fa[4], fb[3];
+    for (int ks = 0; ks < BK; ks += 8) {
+      float2 fa[4], fb[3];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) fa[a] = sA[(wm + a * 16 + j) * ST + ks + g];
+      for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const float2*>(sA + (wm + a * 16 + j) * ST + ks + 2 * g);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) fb[s] = sB[(s * BJ + wc + j) * ST + ks + g];
+      for (int s = 0; s < 3; ++s) fb[s] = *reinterpret_cast<const float2*>(sB + (s * BJ + wc + j) * ST + ks + 2 * g);
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[0], acc[a][0], 0, 0, 0);
-        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[1], acc[a][1], 0, 0, 0);
-        acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[2], acc[a][3], 0, 0, 0);
+        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].x, fb[0].x, acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].x, fb[1].x, acc[a][1], 0, 0, 0);
+        acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].x, fb[2].x, acc[a][3], 0, 0, 0);
+        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].y, fb[0].y, acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].y, fb[1].y, acc[a][1], 0, 0, 0);
+        acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].y, fb[2].y, acc[a][3], 0, 0, 0);
       }
     }
   }
