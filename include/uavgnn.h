@@ -296,6 +296,16 @@ int uavgnn_gru_cell_supported(int K_in, int H);
 int uavgnn_gru_cell_fwd(const float* inp, int ld_inp, int K_in, const float* h, int N, int H, const float* W_ih,
                         const float* b_ih, const float* W_hh, const float* b_hh, float* h_out, float* pre_save,
                         uavgnn_stream_t stream);
+/* The same cell on the bf16 matrix cores (csrc/gru_x3.hip, csrc/bf16x3.h): every fp32 operand is split exactly into three
+ * bf16 terms and each fp32 product is accumulated as six bf16 x bf16 MFMA products in fp32 (error below an fp32 GEMM's,
+ * profiles/r02_ubench_gemm_bf16x3.txt; fp32 MFMA issues at 1/16 of the bf16 MFMA rate on gfx950).
+ * uavgnn_gru_split_weights writes the bf16 planes of W_ih then W_hh ([3][3H][K_in] | [3][3H][H], ..._workspace_bytes bytes,
+ * 16-byte aligned) - call it whenever the weights may have changed; uavgnn_gru_cell_fwd_x3 has the contract of
+ * uavgnn_gru_cell_fwd with `planes` in place of the two weight matrices. */
+long long uavgnn_gru_cell_x3_workspace_bytes(int K_in, int H);
+int uavgnn_gru_split_weights(const float* W_ih, int K_in, const float* W_hh, int H, void* planes, uavgnn_stream_t stream);
+int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, const float* h, int N, int H, const void* planes,
+                           const float* b_ih, const float* b_hh, float* h_out, float* pre_save, uavgnn_stream_t stream);
 int uavgnn_gru_gates_bwd_fused(const float* pre, const float* h, const float* d_hout, int N, int H, float* d_gi, float* d_gh,
                                float* d_h, uavgnn_stream_t stream);
 

@@ -5,6 +5,7 @@ ctypes.  No op has a CPU or eager-PyTorch fallback: CPU tensors raise ``UavGnnEr
 """
 from __future__ import annotations
 
+import os
 import torch as th
 
 from . import _lib as L
@@ -302,11 +303,25 @@ def gru_cell_supported(inp, h) -> bool:
                 and L.lib().uavgnn_gru_cell_supported(inp.shape[1], h.shape[1]))
 
 
+GRU_X3 = os.environ.get("UAVGNN_GRU_X3", "1") != "0"   # the cell's GEMMs as bf16x3 splits on the bf16 matrix cores (csrc/gru_x3.hip)
+
+
 def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save):
     """h' (and the [N, 4H] pre-activation sets when `save`) of the fused GRU cell."""
     N, H = h.shape
     h2 = th.empty_like(h)
     pre = th.empty((N, 4 * H), dtype=th.float32, device=h.device) if save else None
+    if GRU_X3:
+        lib, K_in = L.lib(), inp.shape[1]
+        planes = th.empty(lib.uavgnn_gru_cell_x3_workspace_bytes(K_in, H), dtype=th.uint8, device=h.device)
+        with KERNEL_TIMER.span("gru_cell_fwd"):
+            # the planes are rebuilt on every call: nothing observable tells when a drop-in module's weights changed
+            rc = lib.uavgnn_gru_split_weights(W_ih.data_ptr(), K_in, W_hh.data_ptr(), H, planes.data_ptr(), L.stream())
+            L.check(rc, "uavgnn_gru_split_weights")
+            rc = lib.uavgnn_gru_cell_fwd_x3(inp.data_ptr(), inp.stride(0), K_in, h.data_ptr(), N, H, planes.data_ptr(),
+                                            b_ih.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), L.ptr(pre), L.stream())
+        L.check(rc, "uavgnn_gru_cell_fwd_x3")
+        return h2, pre
     with KERNEL_TIMER.span("gru_cell_fwd"):
         rc = L.lib().uavgnn_gru_cell_fwd(inp.data_ptr(), inp.stride(0), inp.shape[1], h.data_ptr(), N, H, W_ih.data_ptr(),
                                          b_ih.data_ptr(), W_hh.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), L.ptr(pre),
