@@ -302,6 +302,7 @@ int uavgnn_gru_cell_fwd(const float* inp, int ld_inp, int K_in, const float* h, 
  * uavgnn_gru_split_weights writes the bf16 planes of W_ih then W_hh ([3][3H][K_in] | [3][3H][H], ..._workspace_bytes bytes,
  * 16-byte aligned) - call it whenever the weights may have changed; uavgnn_gru_cell_fwd_x3 has the contract of
  * uavgnn_gru_cell_fwd with `planes` in place of the two weight matrices. */
+int uavgnn_gru_cell_x3_supported(int K_in, int H);   /* K_in % 32 == 0 and H % 64 == 0 */
 long long uavgnn_gru_cell_x3_workspace_bytes(int K_in, int H);
 int uavgnn_gru_split_weights(const float* W_ih, int K_in, const float* W_hh, int H, void* planes, uavgnn_stream_t stream);
 int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, const float* h, int N, int H, const void* planes,

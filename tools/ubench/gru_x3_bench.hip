@@ -1,7 +1,6 @@
 // Stand-alone timing of the bf16x3 GRU cell (csrc/gru_x3.hip) at C3 size with parts of the kernel compiled out
 // (-DUAVGNN_X3_DBG=1: no LDS fragment reads / MFMA, 2: no global loads inside the slice loop, 3: no split / LDS writes).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iuav_bs_ctrl_amd/csrc [-DUAVGNN_X3_DBG=n] tools/ubench/gru_x3_bench.hip -o ...
-extern "C" int uavgnn_gru_cell_supported(int K_in, int H) { return K_in % 32 == 0 && H % 32 == 0; }
 #include "../../uav_bs_ctrl_amd/csrc/gru_x3.hip"
 #include <cstdio>
 #include <vector>

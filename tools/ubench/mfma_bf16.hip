@@ -1,0 +1,135 @@
+// Sustained bf16 MFMA rates on gfx950 as a function of instruction shape and of the number of independent accumulators
+// between two dependent MFMAs (the pattern of the bf16x3 GEMM kernels: six products accumulate into the same tile).
+// Every SIMD runs WPS waves; each wave issues `iters` x CH MFMAs, accumulator c = iteration-independent index.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_bf16.hip -o tools/ubench/bin/mfma_bf16
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int CH>
+__global__ __launch_bounds__(256) void k16(float* out, int iters) {
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(threadIdx.x + i); b[i] = (__bf16)(float)(threadIdx.x * 3 + i); }
+  f32x4 acc[CH];
+  for (int c = 0; c < CH; ++c) acc[c] = f32x4{0, 0, 0, 0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[c], 0, 0, 0);
+  }
+  float s = 0;
+  for (int c = 0; c < CH; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int CH>
+__global__ __launch_bounds__(256) void k32(float* out, int iters) {
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(threadIdx.x + i); b[i] = (__bf16)(float)(threadIdx.x * 3 + i); }
+  f32x16 acc[CH];
+  for (int c = 0; c < CH; ++c) for (int i = 0; i < 16; ++i) acc[c][i] = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
+  }
+  float s = 0;
+  for (int c = 0; c < CH; ++c) for (int i = 0; i < 16; ++i) s += acc[c][i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// same pattern with RANDOM operand bits (full switching activity: the sustained clock under power management, not the issue rate)
+__global__ __launch_bounds__(256) void k32_rand(float* out, int iters) {
+  bf16x8 a[3], b[3][3];
+  unsigned st = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (__bf16)(((int)(st >> 9) & 0xffff) * (1.f / 32768.f) - 1.f); };
+  for (int p = 0; p < 3; ++p) for (int i = 0; i < 8; ++i) a[p][i] = rnd();
+  for (int g = 0; g < 3; ++g) for (int p = 0; p < 3; ++p) for (int i = 0; i < 8; ++i) b[g][p][i] = rnd();
+  f32x16 acc[3];
+  for (int c = 0; c < 3; ++c) for (int i = 0; i < 16; ++i) acc[c][i] = 0;
+  for (int it = 0; it < iters; ++it) {
+#define T(ia, ib) _Pragma("unroll") for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ia], b[g][ib], acc[g], 0, 0, 0);
+    T(0, 2) T(2, 0) T(1, 1) T(0, 1) T(1, 0) T(0, 0)
+#undef T
+  }
+  float s = 0;
+  for (int c = 0; c < 3; ++c) for (int i = 0; i < 16; ++i) s += acc[c][i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// the operand pattern of the bf16x3 kernels: 3 accumulators, 3 A fragments x 9 B fragments in distinct registers, 18 MFMAs per group
+__global__ __launch_bounds__(256) void k32_real(float* out, int iters) {
+  bf16x8 a[3], b[3][3];
+  for (int p = 0; p < 3; ++p) for (int i = 0; i < 8; ++i) a[p][i] = (__bf16)(float)(threadIdx.x + i + p);
+  for (int g = 0; g < 3; ++g) for (int p = 0; p < 3; ++p) for (int i = 0; i < 8; ++i) b[g][p][i] = (__bf16)(float)(threadIdx.x * 3 + i + p + 5 * g);
+  f32x16 acc[3];
+  for (int c = 0; c < 3; ++c) for (int i = 0; i < 16; ++i) acc[c][i] = 0;
+  for (int it = 0; it < iters; ++it) {
+#define T(ia, ib) _Pragma("unroll") for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ia], b[g][ib], acc[g], 0, 0, 0);
+    T(0, 2) T(2, 0) T(1, 1) T(0, 1) T(1, 0) T(0, 0)
+#undef T
+    a[0][0] += (__bf16)1.0f;   // keep the loop body from being hoisted
+  }
+  float s = 0;
+  for (int c = 0; c < 3; ++c) for (int i = 0; i < 16; ++i) s += acc[c][i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// the inner loop of the bf16x3 kernels, element by element: 36 MFMAs per iteration (two groups of 18) on fragments that are
+// (MODE & 1) re-read from LDS every iteration (24 ds_read_b128, conflict-free), with (MODE & 2) one s_barrier per iteration;
+// NW wavefronts per workgroup, one workgroup per CU (LDS sized to force it when MODE & 4)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int NW, int MODE>
+__global__ __launch_bounds__(NW * 64) void kloop(float* out, int iters) {
+  __shared__ u32x4 lds[(MODE & 4) ? 5120 : 2048];   // 80 KB: one workgroup per CU
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 2048; i += NW * 64) lds[i] = u32x4{0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  __syncthreads();
+  bf16x8 a[2][3], b[3][2][3];
+  const int l32 = lane & 31, lh = lane >> 5, sw = (l32 >> 2) & 3;
+  auto rd = [&](int row0, int kh) { return __builtin_bit_cast(bf16x8, lds[(row0 + l32) * 4 + ((2 * kh + lh) ^ sw)]); };
+#define READ_ALL(kh) { for (int p = 0; p < 3; ++p) a[kh][p] = rd(32 * p, kh); for (int g = 0; g < 3; ++g) for (int p = 0; p < 3; ++p) b[g][kh][p] = rd(96 + 32 * (3 * g + p), kh); }
+  READ_ALL(0) READ_ALL(1)
+  f32x16 acc[3];
+  for (int c = 0; c < 3; ++c) for (int i = 0; i < 16; ++i) acc[c][i] = 0;
+  for (int it = 0; it < iters; ++it) {
+#define T(kh, ia, ib) _Pragma("unroll") for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kh][ia], b[g][kh][ib], acc[g], 0, 0, 0);
+    if (MODE & 1) READ_ALL(1)
+    __builtin_amdgcn_sched_barrier(0);
+    T(0, 0, 2) T(0, 2, 0) T(0, 1, 1) T(0, 0, 1) T(0, 1, 0) T(0, 0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE & 2) __syncthreads();
+    if (MODE & 1) READ_ALL(0)
+    __builtin_amdgcn_sched_barrier(0);
+    T(1, 0, 2) T(1, 2, 0) T(1, 1, 1) T(1, 0, 1) T(1, 1, 0) T(1, 0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+#undef T
+  }
+  float s = 0;
+  for (int c = 0; c < 3; ++c) for (int i = 0; i < 16; ++i) s += acc[c][i];
+  out[blockIdx.x * NW * 64 + tid] = s;
+}
+template <typename F>
+float time_ms(F f) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  f(); hipEventRecord(e0); for (int i = 0; i < 5; ++i) f(); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); return ms / 5;
+}
+int main() {
+  float* out; hipMalloc(&out, 4 * 256 * 4096);
+  const int iters = 4096;
+  for (int wps = 1; wps <= 2; ++wps) {
+    const int blocks = 256 * wps;   // 4 waves per block: one per SIMD; wps blocks per CU
+#define RUN16(CH) { float ms = time_ms([&] { hipLaunchKernelGGL(k16<CH>, dim3(blocks), dim3(256), 0, 0, out, iters); }); \
+    double n = double(blocks) * 4 * iters * CH; printf("16x16x32 bf16, %d wave(s)/SIMD, %2d independent accumulators: %7.1f TFLOP/s  (%.1f ns per MFMA per SIMD)\n", wps, CH, n * 16384 / ms * 1e-9, ms * 1e6 / (double(iters) * CH * wps)); }
+#define RUN32(CH) { float ms = time_ms([&] { hipLaunchKernelGGL(k32<CH>, dim3(blocks), dim3(256), 0, 0, out, iters); }); \
+    double n = double(blocks) * 4 * iters * CH; printf("32x32x16 bf16, %d wave(s)/SIMD, %2d independent accumulators: %7.1f TFLOP/s  (%.1f ns per MFMA per SIMD)\n", wps, CH, n * 32768 / ms * 1e-9, ms * 1e6 / (double(iters) * CH * wps)); }
+    RUN16(1) RUN16(2) RUN16(3) RUN16(4) RUN16(8) RUN16(16)
+    RUN32(1) RUN32(2) RUN32(3) RUN32(4)
+    for (int it2 : {4096, 65536}) { float ms = time_ms([&] { hipLaunchKernelGGL(k32_rand, dim3(blocks), dim3(256), 0, 0, out, it2); });
+      double n = double(blocks) * 4 * it2 * 18; printf("32x32x16 bf16, %d wave(s)/SIMD, RANDOM operands, %6.1f ms kernel: %7.1f TFLOP/s  (%.1f ns per MFMA per SIMD)\n", wps, ms, n * 32768 / ms * 1e-9, ms * 1e6 / (double(it2) * 18 * wps)); }
+    { float ms = time_ms([&] { hipLaunchKernelGGL(k32_real, dim3(blocks), dim3(256), 0, 0, out, iters); });
+      double n = double(blocks) * 4 * iters * 18; printf("32x32x16 bf16, %d wave(s)/SIMD, bf16x3 operand pattern (12 distinct fragments, 3 accumulators): %7.1f TFLOP/s  (%.1f ns per MFMA per SIMD)\n", wps, n * 32768 / ms * 1e-9, ms * 1e6 / (double(iters) * 18 * wps)); }
+  }
+#define RUNL(NW, MODE, BLK) { float ms = time_ms([&] { hipLaunchKernelGGL((kloop<NW, MODE>), dim3(BLK), dim3(NW * 64), 0, 0, out, 2048); }); \
+    printf("loop of 36 MFMAs, %d waves / workgroup, %d workgroups%s%s%s: %.1f ns per MFMA per SIMD\n", NW, BLK, (MODE & 1) ? ", 24 LDS fragment reads" : "", (MODE & 2) ? ", 1 barrier" : "", (MODE & 4) ? ", 1 workgroup / CU" : "", ms * 1e6 / (2048.0 * 36 * ((MODE & 4) ? NW / 4.0 : (double(BLK) * NW / 4 / 256)))); }
+  RUNL(8, 4, 256) RUNL(8, 5, 256) RUNL(8, 6, 256) RUNL(8, 7, 256)
+  RUNL(4, 0, 512) RUNL(4, 1, 512) RUNL(4, 2, 512) RUNL(4, 3, 512)
+  return 0;
+}

@@ -17,6 +17,7 @@ namespace uavgnn {
 namespace x3 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -61,6 +62,14 @@ __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(b
 
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// 32x32x16 fragments (lane -> row lane % 32, chunk 2 kh + lane / 32 of the 32-wide slice): the swizzle that keeps the four
+// 16-lane groups of a ds_read_b128 on distinct 16-byte bank groups is the row's 4-row block index
+__device__ __forceinline__ int swz32(int row) { return (row >> 2) & 3; }
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 }  // namespace x3

@@ -7,14 +7,24 @@
 //
 // Data flow.  uavgnn_gru_split_weights turns W_ih [3H, K_in] and W_hh [3H, H] into bf16 planes [3][3H][K] (one launch per
 // forward: the weights of a drop-in module may change behind any cache - `.data` writes do not bump a version counter - and
-// the launch costs 3 us).  gru_cell_fwd_x3_kernel: one workgroup owns 128 agents x 32 hidden units and four accumulator
-// sets r, z, gi_n, gh_n (r and z take both contractions); per 32-wide K slice the activation tile is loaded as fp32, split
-// in registers (v_cvt_pk_bf16_f32 + two subtractions per term) and written to LDS as three bf16 planes, the weight planes
-// are copied; LDS rows are 64 B with an XOR swizzle (conflict-free ds_read_b128 fragments, no padding); every wavefront
-// (64 agents x 16 units) issues 72 v_mfma_f32_16x16x32_bf16 per slice.  The eight column blocks of a row block run on the
-// same XCD (blockIdx -> XCD round robin), so the activation tile is fetched from HBM once and re-read from that XCD's L2.
-// Epilogue as gru_fused.hip: biases, gates, h' through an LDS tile (full-row HBM accesses), optional pre-activations
-// [N, 4H] for uavgnn_gru_gates_bwd_fused.
+// the launch costs 3 us).  The cell kernel walks K in 32-wide slices over [x || c] (W_ih rows) and then h (W_hh rows) with
+// four accumulator sets r, z, gi_n, gh_n (r and z take both contractions); per slice the activation tile is loaded as fp32,
+// split in registers (v_cvt_pk_bf16_f32 + two subtractions per term) and written to LDS as three bf16 planes, the weight
+// planes are copied; LDS rows are 64 B with an XOR swizzle (conflict-free ds_read_b128 fragments, no padding).  The column
+// blocks of a row block run on the same XCD (blockIdx -> XCD round robin), so the activation tile is fetched from HBM once
+// and re-read from that XCD's L2.  Epilogue as gru_fused.hip: biases, gates, h' through an LDS tile (full-row HBM
+// accesses), optional pre-activations [N, 4H] for uavgnn_gru_gates_bwd_fused.
+//
+// gru_cell_fwd_x3w8_kernel (H % 64 == 0; other shapes take the fp32-MFMA cell of gru_fused.hip): 512 threads own 128 agents
+// x 64 hidden units; eight wavefronts of 32 agents x 32 units x 4 sets (64 accumulator registers) on
+// v_mfma_f32_32x32x16_bf16.  The LDS tiles are double-buffered with ONE barrier per slice, the fragment reads are software-
+// pipelined over the two 16-wide halves of a slice, the loads of slice t+2 are in flight while slice t computes.
+// Measured (tools/ubench/gru_x3_bench.hip, C3 size): 194 us; without any staging (fragment reads + MFMAs + barriers) 161 us;
+// prologue + epilogue alone 36 us (one workgroup per CU: nothing overlaps them); the MFMAs alone would take 94 us
+// (tools/ubench/mfma_bf16.hip: 18.2 ns per 32x32x16 MFMA per SIMD with random operands).  Variants measured and dropped:
+// 128 x 32 tiles with four waves and 16x16x32 MFMAs (200 us: three independent accumulators between dependent 16x16x32
+// MFMAs issue at half rate, profiles/r02_ubench_mfma_bf16.txt), the same with 32x32x16 MFMAs (215 us), loads two slices
+// ahead through a fully unrolled slice loop (-4 us), a start skew between co-resident workgroups (0).
 #include "bf16x3.h"
 #include "common.h"
 
@@ -22,13 +32,12 @@ namespace uavgnn {
 namespace {
 
 using namespace x3;
-constexpr int BM = 128, BJ = 32, BK = 32, ST = 34;
-constexpr int PA = BM * 4, PB = 3 * BJ * 4;
-#ifndef SKEW
-#define SKEW 32   // x 64 cycles
-#endif   // 16-byte chunks per split plane of the A / B tile
+constexpr int BM = 128, BK = 32;
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// gate non-linearities on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each): absolute error <= 2e-7, far inside
+// the 1e-5 parity tolerance; tanh as 1 - 2 / (1 + e^{2x}) saturates correctly at both ends (e^{2x} -> inf / 0)
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 
 // two weight matrices -> bf16 planes, one launch: pair index p over (n0 + n1) / 2
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ w0, unsigned short* __restrict__ p0,
@@ -52,200 +61,197 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   *reinterpret_cast<unsigned*>(p + 2 * n + i) = s.h3;
 }
 
-// NK1 / NK2 > 0: the slice counts K_in / 32 and H / 32 are compile-time, the slice loop is fully unrolled and the loads run
-// TWO slices ahead (with a rolled loop the compiler's s_waitcnt placement drains every load at the loop header, i.e. a
-// prefetch distance of one compute phase - shorter than the loaded L2 / HBM latency: 45 % of the wave cycles were s_waitcnt).
-template <bool SAVE, int NK1, int NK2>
-__global__ __launch_bounds__(256, 2) void gru_cell_fwd_x3_kernel(
+// products of one fp32 product, smallest first: (a1 b3) (a3 b1) (a2 b2) (a1 b2) (a2 b1) (a1 b1)
+#define UAVGNN_X3_FOR_TERMS(M) M(0, 2) M(2, 0) M(1, 1) M(0, 1) M(1, 0) M(0, 0)
+
+// ---- eight wavefronts, 128 agents x 64 hidden units, double-buffered LDS, one barrier per slice ----------------------------
+namespace w8 {
+constexpr int BJ = 64, NT = 512, ST = 68;
+constexpr int PA = BM * 4, PB = 3 * BJ * 4;            // 16-byte chunks per split plane of the A / B tile
+constexpr int BUF = 3 * PA + 3 * PB;                   // chunks per buffer (60 KB)
+}  // namespace w8
+
+template <bool SAVE>
+__global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
     const float* __restrict__ inp, int ld_inp, int K1, const float* __restrict__ h, int N, int H,
     const unsigned short* __restrict__ Wih_p, const float* __restrict__ b_ih, const unsigned short* __restrict__ Whh_p,
     const float* __restrict__ b_hh, float* __restrict__ h_out, float* __restrict__ pre, int row_blocks) {
-  __shared__ u32x4 sA[3 * PA];   // [plane][128 rows][4 chunks]          24 KB (reused as the fp32 h / h' tile)
-  __shared__ u32x4 sB[3 * PB];   // [plane][96 rows = gate * 32 + unit][4] 18 KB
+  using namespace w8;
+  __shared__ u32x4 smem[2 * BUF];   // buffer b: A planes [3][128][4] then B planes [3][192 = gate * 64 + unit][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 15, g = lane >> 4;
-  const int wm = (wave >> 1) * 64, wc = (wave & 1) * 16;
+  const int wm = (wave >> 1) * 32, wc = (wave & 1) * 32;
   const int CB = H / BJ;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int rb = (slot / CB) * 8 + xcd, cb = slot - (slot / CB) * CB;
   if (rb >= row_blocks) return;
   const int m0 = rb * BM, j0 = cb * BJ;
-  // Two workgroups share a CU and alternate a VALU phase (split + LDS writes) with an MFMA phase per slice; started together
-  // they stay in lockstep and the matrix pipe idles through both VALU phases.  The second workgroup of every CU in the first
-  // round starts half a slice late, later rounds inherit the skew (a CU's slots now free up at different times).
-  if (blockIdx.x >= 256 && blockIdx.x < 512) __builtin_amdgcn_s_sleep(SKEW);
 
-  f32x4 acc[4][4];     // [row tile][set: r, z, gi_n, gh_n]
+  f32x16 acc[4];     // 32 x 32 tile per set: r, z, gi_n, gh_n
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc[a][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 16; ++i) acc[s][i] = 0.f;
+  const int l32 = lane & 31, lh = lane >> 5, sw = swz32(l32);
 
-  // A loader: float4 q = tid + 256 i -> row tid / 8 + 32 i, k = 4 (tid % 8); rows past N are clamped (stores are masked)
+  // A loader: float4 q = tid + 512 i -> row tid / 8 + 64 i, k = 4 (tid % 8); rows past N are clamped (stores are masked)
   const int lr = tid >> 3, c4 = tid & 7;
-  int ar[4];
+  int ar[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ar[i] = min(m0 + lr + 32 * i, N - 1);
-  unsigned short* sa_w = reinterpret_cast<unsigned short*>(sA) + lr * 32 + (((c4 >> 1) ^ swz(lr)) * 8) + (c4 & 1) * 4;
-  // B loader: chunk q = tid + 256 i (i < 5, 1152 chunks): plane q / 384, row (q % 384) / 4 = gate * 32 + unit, chunk q % 4
+  for (int i = 0; i < 2; ++i) ar[i] = min(m0 + lr + 64 * i, N - 1);
+  const int sa_w = lr * 32 + (((c4 >> 1) ^ swz32(lr)) * 8) + (c4 & 1) * 4;   // in bf16 units inside an A plane
+  // B loader: chunk q = tid + 512 i (i < 5, 2304 chunks): plane q / 768, row (q % 768) / 4 = gate * 64 + unit, chunk q % 4
   int wr[5], wk[5], sbw[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
-    const int q = min(tid + 256 * i, 3 * PB - 1), pl = q / PB, rem = q - pl * PB, row = rem >> 2, c = rem & 3;
-    wr[i] = pl * 3 * H + (row >> 5) * H + j0 + (row & 31);
+    const int q = min(tid + NT * i, 3 * PB - 1), pl = q / PB, rem = q - pl * PB, row = rem >> 2, c = rem & 3;
+    wr[i] = pl * 3 * H + (row >> 6) * H + j0 + (row & 63);
     wk[i] = 8 * c;
-    sbw[i] = pl * PB + row * 4 + (c ^ swz(row));
+    sbw[i] = 3 * PA + pl * PB + row * 4 + (c ^ swz32(row));
   }
-  float4 ra[2][4];
-  u32x4 rw[2][5];
-#define UAVGNN_X3_GLOAD(SET, Asrc, lda, Wp, K, k0)                                                                  \
-  {                                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) ra[SET][i] =                                                     \
-        *reinterpret_cast<const float4*>((Asrc) + static_cast<size_t>(ar[i]) * (lda) + (k0) + 4 * c4);              \
-    _Pragma("unroll") for (int i = 0; i < 5; ++i) rw[SET][i] =                                                     \
-        *reinterpret_cast<const u32x4*>((Wp) + static_cast<size_t>(wr[i]) * (K) + wk[i] + (k0));                    \
-  }
-#if defined(UAVGNN_X3_DBG) && UAVGNN_X3_DBG == 3   /* timing experiment: raw copies, no split */
-#define UAVGNN_X3_LSTORE(SET)                                                                                      \
-  {                                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) sA[tid + 256 * i] = __builtin_bit_cast(u32x4, ra[SET][i]);        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) sB[sbw[i]] = rw[SET][i];                                         \
-    if (tid < 3 * PB - 1024) sB[sbw[4]] = rw[SET][4];                                                              \
-  }
-#elif defined(UAVGNN_X3_DBG) && UAVGNN_X3_DBG == 4   /* timing experiment: nothing staged at all */
-#define UAVGNN_X3_LSTORE(SET) {}
-#else
-#define UAVGNN_X3_LSTORE(SET)                                                                                      \
-  {                                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) stage4(sa_w + 32 * i * 32, PA * 8, ra[SET][i]);                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) sB[sbw[i]] = rw[SET][i];                                         \
-    if (tid < 3 * PB - 1024) sB[sbw[4]] = rw[SET][4];                                                              \
-  }
-#endif
-  // one K slice: 4 row tiles x 3 gates x 6 products; smallest products first, three independent accumulators per product
-#define UAVGNN_X3_TERM(ia, ib, NS)                \
-  acc[a][0] = mfma(fa[ia], fb[0][ib], acc[a][0]); \
-  acc[a][1] = mfma(fa[ia], fb[1][ib], acc[a][1]); \
-  acc[a][NS] = mfma(fa[ia], fb[2][ib], acc[a][NS]);
-#if defined(UAVGNN_X3_DBG) && UAVGNN_X3_DBG == 1
-#define UAVGNN_X3_SLICE(NS) {}
-#else
-#define UAVGNN_X3_SLICE(NS)                                                                                        \
-  {                                                                                                                \
-    bf16x8 fb[3][3];                                                                                               \
-    _Pragma("unroll") for (int s = 0; s < 3; ++s) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) fb[s][pl] =     \
-        as_frag(sB[pl * PB + (s * BJ + wc + j) * 4 + (g ^ swz(j))]);                                               \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                                \
-      bf16x8 fa[3];                                                                                                \
-      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) fa[pl] = as_frag(sA[pl * PA + (wm + a * 16 + j) * 4 + (g ^ swz(j))]); \
-      UAVGNN_X3_TERM(0, 2, NS) UAVGNN_X3_TERM(2, 0, NS) UAVGNN_X3_TERM(1, 1, NS)                                  \
-      UAVGNN_X3_TERM(0, 1, NS) UAVGNN_X3_TERM(1, 0, NS) UAVGNN_X3_TERM(0, 0, NS)                                  \
-    }                                                                                                              \
-  }
-#endif
-
-  if constexpr (NK1 > 0) {
-    // slice t < NK1: input GEMM (sets r, z, gi_n); t >= NK1: hidden GEMM (sets r, z, gh_n); loads two slices ahead
-    constexpr int NS = NK1 + NK2;
-#if defined(UAVGNN_X3_DBG) && UAVGNN_X3_DBG == 2   /* timing experiment: only the first two slices are ever loaded */
-#define UAVGNN_X3_LOAD_SLICE(SET, t) \
-  if ((t) < 2) UAVGNN_X3_GLOAD(SET, inp, ld_inp, Wih_p, K1, (t) * BK)
-#else
-#define UAVGNN_X3_LOAD_SLICE(SET, t)                                          \
-  if ((t) < NK1) UAVGNN_X3_GLOAD(SET, inp, ld_inp, Wih_p, K1, (t) * BK)       \
-  else UAVGNN_X3_GLOAD(SET, h, H, Whh_p, H, ((t) - NK1) * BK)
-#endif
-    UAVGNN_X3_LOAD_SLICE(0, 0)
-    UAVGNN_X3_LOAD_SLICE(1, 1)
+  const int n1 = K1 / BK, ns = n1 + H / BK;
+  float4 ra[2];
+  u32x4 rw[5];
+  auto gload = [&](int t) {   // slice t (clamped by the caller): t < n1 reads [x || c] and W_ih, else h and W_hh
+    const bool p1 = t < n1;
+    const float* __restrict__ Asrc = p1 ? inp : h;
+    const unsigned short* __restrict__ Wp = p1 ? Wih_p : Whh_p;
+    const int lda = p1 ? ld_inp : H, K = p1 ? K1 : H, k0 = (p1 ? t : t - n1) * BK;
 #pragma unroll
-    for (int t = 0; t < NS; t += 2) {
-      __syncthreads();
-      UAVGNN_X3_LSTORE(0)
-      __syncthreads();
-      if (t + 2 < NS) UAVGNN_X3_LOAD_SLICE(0, t + 2)
-      if (t < NK1) UAVGNN_X3_SLICE(2) else UAVGNN_X3_SLICE(3)
-      if (t + 1 < NS) {
-        __syncthreads();
-        UAVGNN_X3_LSTORE(1)
-        __syncthreads();
-        if (t + 3 < NS) UAVGNN_X3_LOAD_SLICE(1, t + 3)
-        if (t + 1 < NK1) UAVGNN_X3_SLICE(2) else UAVGNN_X3_SLICE(3)
-      }
-    }
-#undef UAVGNN_X3_LOAD_SLICE
-  } else {
-    // ---- phase 1: input GEMM (sets r, z, gi_n) -----------------------------------------------------------------------
-    UAVGNN_X3_GLOAD(0, inp, ld_inp, Wih_p, K1, 0)
-    for (int k0 = 0; k0 < K1; k0 += BK) {
-      __syncthreads();
-      UAVGNN_X3_LSTORE(0)
-      __syncthreads();
-      if (k0 + BK < K1) UAVGNN_X3_GLOAD(0, inp, ld_inp, Wih_p, K1, k0 + BK)
-      else UAVGNN_X3_GLOAD(0, h, H, Whh_p, H, 0)            // first slice of phase 2
-      UAVGNN_X3_SLICE(2)
-    }
-    // ---- phase 2: hidden GEMM (sets r, z, gh_n) ----------------------------------------------------------------------
-    for (int k0 = 0; k0 < H; k0 += BK) {
-      __syncthreads();
-      UAVGNN_X3_LSTORE(0)
-      __syncthreads();
-      UAVGNN_X3_GLOAD(0, h, H, Whh_p, H, min(k0 + BK, H - BK))   // unconditional (the tail re-reads the last slice)
-      UAVGNN_X3_SLICE(3)
-    }
+    for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(Asrc + static_cast<unsigned>(ar[i] * lda + k0 + 4 * c4));
+#pragma unroll
+    for (int i = 0; i < 5; ++i) rw[i] = *reinterpret_cast<const u32x4*>(Wp + static_cast<unsigned>(wr[i] * K + wk[i] + k0));
+  };
+  auto lstore = [&](int buf) {
+    u32x4* sb = smem + buf * BUF;
+    unsigned short* sa = reinterpret_cast<unsigned short*>(sb) + sa_w;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) stage4(sa + 64 * i * 32, PA * 8, ra[i]);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) sb[sbw[i]] = rw[i];   // i = 4, tid >= 256: the clamped chunk again - same data, same address
+  };
+  // One K slice = two 16-wide halves of v_mfma_f32_32x32x16_bf16 (lane -> row lane % 32, 8 consecutive k at 8 (lane / 32) of
+  // the half): per half and gate one 32 x 32 tile and six products; the three gates interleave so that dependent MFMAs are
+  // three apart.  The 32x32 shape is chosen for its issue behaviour: 16x16x32 bf16 MFMAs with 3-8 independent accumulators
+  // between dependent ones run at HALF rate or worse (profiles/r02_ubench_mfma_bf16.txt: 457-1075 TFLOP/s vs 2140 for
+  // 32x32x16 at any distance).
+  struct Half {
+    bf16x8 a[3], b[3][3];   // [plane], [gate][plane]
+  };
+#define UAVGNN_X3_W8_READ(F, buf, kh)                                                                              \
+  {                                                                                                                \
+    const u32x4* sb = smem + (buf) * BUF;                                                                          \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) F.a[pl] = as_frag(sb[pl * PA + (wm + l32) * 4 + ((2 * (kh) + lh) ^ sw)]); \
+    _Pragma("unroll") for (int gate = 0; gate < 3; ++gate) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)        \
+        F.b[gate][pl] = as_frag(sb[3 * PA + pl * PB + (gate * BJ + wc + l32) * 4 + ((2 * (kh) + lh) ^ sw)]);       \
   }
-#undef UAVGNN_X3_GLOAD
-#undef UAVGNN_X3_LSTORE
-#undef UAVGNN_X3_SLICE
-#undef UAVGNN_X3_TERM
-  // ---- epilogue on the D layout: lane (g, j) holds rows 4g..4g+3 of every row tile, hidden unit c ------------------------
-  float* sH = reinterpret_cast<float*>(sA);               // [128][ST] fp32 tile: h in, h' out, 16-byte row-contiguous HBM accesses
+#define UAVGNN_X3_W8_TERM(ia, ib)                  \
+  acc[0] = mfma32(F.a[ia], F.b[0][ib], acc[0]);    \
+  acc[1] = mfma32(F.a[ia], F.b[1][ib], acc[1]);    \
+  acc[NSET] = mfma32(F.a[ia], F.b[2][ib], acc[NSET]);
+#define UAVGNN_X3_W8_MFMA(F_, NSET_)               \
+  {                                                \
+    constexpr int NSET = NSET_;                    \
+    const Half& F = F_;                            \
+    UAVGNN_X3_FOR_TERMS(UAVGNN_X3_W8_TERM)         \
+  }
+
+  gload(0);
+  lstore(0);
+  gload(min(1, ns - 1));
   __syncthreads();
+  // Software pipeline over the halves: the fragment reads of a half are issued one MFMA group (18 MFMAs = 576 cycles) before
+  // their use - f1 = (slice t, second half) under the MFMAs of f0, f0 = (slice t + 1, first half) right after the barrier
+  // under the MFMAs of f1.  Iteration t also stages slice t + 1 into the other buffer (its readers passed the barrier of
+  // iteration t - 1) and starts the loads of slice t + 2; the tail re-stages / re-loads the last slice (unconditional).
+  // Waves w and w + 4 share a SIMD: the first four stage BEFORE their first MFMA group, the last four AFTER it.
+  // sched_barrier pins the order (left alone, the compiler sinks the global loads below the MFMAs - prefetch distance zero -
+  // and issues the LDS reads right before their MFMAs).
+  const bool early = wave < 4;
+  Half f0, f1;
+  UAVGNN_X3_W8_READ(f0, 0, 0)
+  int t = 0;
+#ifndef UAVGNN_X3_DBG
+#define UAVGNN_X3_DBG 0   /* timing experiments of tools/ubench/gru_x3_bench.hip: 1 = no global loads in the loop, 2 = no staging */
+#endif
+#define lstore(b) if (UAVGNN_X3_DBG < 2) lstore(b)
+#define gload(tt) if (UAVGNN_X3_DBG < 1) gload(tt)
+#define UAVGNN_X3_W8_STEP(NSET)                            \
+  UAVGNN_X3_W8_READ(f1, t & 1, 1)                          \
+  if (early) {                                             \
+    lstore((t + 1) & 1);                                   \
+    gload(min(t + 2, ns - 1));                             \
+  }                                                        \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  UAVGNN_X3_W8_MFMA(f0, NSET)                              \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  if (!early) {                                            \
+    lstore((t + 1) & 1);                                   \
+    gload(min(t + 2, ns - 1));                             \
+  }                                                        \
+  __syncthreads();                                         \
+  UAVGNN_X3_W8_READ(f0, (t + 1) & 1, 0)                    \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  UAVGNN_X3_W8_MFMA(f1, NSET)                              \
+  __builtin_amdgcn_sched_barrier(0);
+  if (UAVGNN_X3_DBG == 3) t = ns;   /* timing experiment: prologue + epilogue only */
+  for (; t < n1; ++t) { UAVGNN_X3_W8_STEP(2) }
+  for (; t < ns; ++t) { UAVGNN_X3_W8_STEP(3) }
+#undef UAVGNN_X3_W8_STEP
+#undef lstore
+#undef gload
+#undef UAVGNN_X3_W8_MFMA
+#undef UAVGNN_X3_W8_READ
+  __syncthreads();   // the last iteration's read of the stale buffer must not race the epilogue's tile
+#undef UAVGNN_X3_W8_TERM
+  // ---- epilogue on the D layout: lane (g, j) holds rows 4g..4g+3 of a tile, one hidden unit ------------------------------
+  // (the last barrier of the loop has passed: nobody reads the buffers any more)
+  float* sH = reinterpret_cast<float*>(smem);             // [128][ST] fp32 tile: h in, h' out, 16-byte row-contiguous HBM accesses
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int row = lr + 32 * q;
-    const float4 t = *reinterpret_cast<const float4*>(h + static_cast<size_t>(ar[q]) * H + j0 + 4 * c4);
-    float* p = sH + row * ST + 4 * c4;
-    *reinterpret_cast<float2*>(p) = make_float2(t.x, t.y);
-    *reinterpret_cast<float2*>(p + 2) = make_float2(t.z, t.w);
+    const int idx = tid + NT * q, row = idx >> 4, cc = idx & 15;
+    *reinterpret_cast<float4*>(sH + row * ST + 4 * cc) =
+        *reinterpret_cast<const float4*>(h + static_cast<size_t>(min(m0 + row, N - 1)) * H + j0 + 4 * cc);
   }
   __syncthreads();
-  const int c = j0 + wc + j;
+  // D layout of the 32 x 32 tile: lane l holds column l % 32, register i holds row 8 (i / 4) + 4 (l / 32) + i % 4
+  const int c = j0 + wc + l32;
   const float b_r = b_ih[c] + b_hh[c], b_z = b_ih[H + c] + b_hh[H + c], b_in = b_ih[2 * H + c], b_hn = b_hh[2 * H + c];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int lrow = wm + a * 16 + 4 * g + r;
-      const int row = m0 + lrow;
-      const float pr = acc[a][0][r] + b_r, pz = acc[a][1][r] + b_z, gin = acc[a][2][r] + b_in, ghn = acc[a][3][r] + b_hn;
-      const float rr = sigmoidf_(pr), zz = sigmoidf_(pz);
-      const float nn = tanhf(fmaf(rr, ghn, gin));
-      float* hp = sH + lrow * ST + wc + j;
-      *hp = fmaf(zz, *hp - nn, nn);                      // every element of the tile has exactly one owner lane
-      if (SAVE && row < N) {
-        float* p = pre + static_cast<size_t>(row) * 4 * H + c;
-        p[0] = pr;
-        p[H] = pz;
-        p[2 * H] = gin;
-        p[3 * H] = ghn;
-      }
+  for (int i = 0; i < 16; ++i) {
+    const int lrow = wm + 8 * (i >> 2) + 4 * lh + (i & 3);
+    const int row = m0 + lrow;
+    const float pr = acc[0][i] + b_r, pz = acc[1][i] + b_z, gin = acc[2][i] + b_in, ghn = acc[3][i] + b_hn;
+    const float rr = sigmoidf_(pr), zz = sigmoidf_(pz);
+    const float nn = tanhf_(fmaf(rr, ghn, gin));
+    float* hp = sH + lrow * ST + wc + l32;
+    *hp = fmaf(zz, *hp - nn, nn);                          // every element of the tile has exactly one owner lane
+    if (SAVE && row < N) {
+      float* p = pre + static_cast<size_t>(row) * 4 * H + c;
+      p[0] = pr;
+      p[H] = pz;
+      p[2 * H] = gin;
+      p[3 * H] = ghn;
     }
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int row = lr + 32 * q;
-    if (m0 + row < N) {
-      const float* p = sH + row * ST + 4 * c4;
-      *reinterpret_cast<float4*>(h_out + static_cast<size_t>(m0 + row) * H + j0 + 4 * c4) = make_float4(p[0], p[1], p[2], p[3]);
-    }
+    const int idx = tid + NT * q, row = idx >> 4, cc = idx & 15;
+    if (m0 + row < N)
+      *reinterpret_cast<float4*>(h_out + static_cast<size_t>(m0 + row) * H + j0 + 4 * cc) =
+          *reinterpret_cast<const float4*>(sH + row * ST + 4 * cc);
   }
 }
+
 
 }  // namespace
 }  // namespace uavgnn
 
 using namespace uavgnn;
+
+extern "C" int uavgnn_gru_cell_x3_supported(int K_in, int H) {
+  return (K_in >= BK && K_in % BK == 0 && H >= w8::BJ && H % w8::BJ == 0) ? 1 : 0;
+}
 
 extern "C" long long uavgnn_gru_cell_x3_workspace_bytes(int K_in, int H) {
   if (K_in <= 0 || H <= 0) return 0;
@@ -271,26 +277,20 @@ extern "C" int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, co
                                       const void* planes, const float* b_ih, const float* b_hh, float* h_out,
                                       float* pre_save, uavgnn_stream_t stream) {
   if (N < 0 || !inp || !h || !planes || !b_ih || !b_hh || !h_out || ld_inp < K_in) return UAVGNN_EINVAL;
-  if (!uavgnn_gru_cell_supported(K_in, H) || (ld_inp & 3) ||
+  if (!uavgnn_gru_cell_x3_supported(K_in, H) || (ld_inp & 3) ||
       ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(planes) |
         reinterpret_cast<uintptr_t>(h_out)) & 15))
     return UAVGNN_EUNSUPPORTED;
   if (N == 0) return 0;
   const unsigned short* p0 = static_cast<const unsigned short*>(planes);
   const unsigned short* p1 = p0 + 9LL * H * K_in;
-  const int row_blocks = (N + BM - 1) / BM;
-  const dim3 grid(((row_blocks + 7) / 8) * 8 * (H / BJ)), block(256);
+  const int row_blocks = (N + BM - 1) / BM, rb8 = ((row_blocks + 7) / 8) * 8;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define UAVGNN_X3_LAUNCH(SAVE, NK1, NK2)                                                                                  \
-  hipLaunchKernelGGL((gru_cell_fwd_x3_kernel<SAVE, NK1, NK2>), grid, block, 0, st, inp, ld_inp, K_in, h, N, H, p0, b_ih, p1, \
-                     b_hh, h_out, pre_save, row_blocks)
-  if (K_in == 320 && H == 256) {        // exp3 / C3 shape (msg 64 + obs 256 -> 256): unrolled, loads two slices ahead
-    if (pre_save != nullptr) UAVGNN_X3_LAUNCH(true, 10, 8);
-    else UAVGNN_X3_LAUNCH(false, 10, 8);
-  } else {
-    if (pre_save != nullptr) UAVGNN_X3_LAUNCH(true, 0, 0);
-    else UAVGNN_X3_LAUNCH(false, 0, 0);
-  }
+#define UAVGNN_X3_LAUNCH(KERNEL, BJ_, NT_)                                                                              \
+  hipLaunchKernelGGL(KERNEL, dim3(rb8 * (H / (BJ_))), dim3(NT_), 0, st, inp, ld_inp, K_in, h, N, H, p0, b_ih, p1, b_hh, \
+                     h_out, pre_save, row_blocks)
+  if (pre_save != nullptr) UAVGNN_X3_LAUNCH(gru_cell_fwd_x3w8_kernel<true>, w8::BJ, w8::NT);
+  else UAVGNN_X3_LAUNCH(gru_cell_fwd_x3w8_kernel<false>, w8::BJ, w8::NT);
 #undef UAVGNN_X3_LAUNCH
   return launch_status();
 }

@@ -311,7 +311,7 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save):
     N, H = h.shape
     h2 = th.empty_like(h)
     pre = th.empty((N, 4 * H), dtype=th.float32, device=h.device) if save else None
-    if GRU_X3:
+    if GRU_X3 and L.lib().uavgnn_gru_cell_x3_supported(inp.shape[1], H):
         lib, K_in = L.lib(), inp.shape[1]
         planes = th.empty(lib.uavgnn_gru_cell_x3_workspace_bytes(K_in, H), dtype=th.uint8, device=h.device)
         with KERNEL_TIMER.span("gru_cell_fwd"):
