@@ -307,6 +307,18 @@ long long uavgnn_gru_cell_x3_workspace_bytes(int K_in, int H);
 int uavgnn_gru_split_weights(const float* W_ih, int K_in, const float* W_hh, int H, void* planes, uavgnn_stream_t stream);
 int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, const float* h, int N, int H, const void* planes,
                            const float* b_ih, const float* b_hh, float* h_out, float* pre_save, uavgnn_stream_t stream);
+/* Dense layers on the bf16 matrix cores (csrc/gemm_x3.hip; reference: the nn.Linear layers of
+ * algos/madrqn/agents/gnn_agents.py - f_aggr :101-102, :106, TarMAC projections :227-236 - and the input-gradient GEMMs of
+ * loss.backward(), learner.py:157): Y[M, N] = X[M, K] B[N, K]^T (+ bias[N]) (+ Y) (then ReLU), fp32 in / out, each fp32 product
+ * as six exact bf16 products (bf16x3.h).  uavgnn_split_bf16x3 turns a weight matrix W [R, C] (row stride ld) into the bf16
+ * planes the GEMM reads: [3][R][C] (transpose = 0: forward, B = W) or [3][C][R] (transpose = 1: input gradient, B = W^T);
+ * 6 R C bytes, 16-byte aligned.  K % 32 == 0, ldx % 4 == 0, X 16-byte aligned; M, N arbitrary. */
+#define UAVGNN_GEMM_ACCUMULATE 1
+#define UAVGNN_GEMM_RELU 2
+int uavgnn_gemm_x3_supported(int M, int N, int K);
+int uavgnn_split_bf16x3(const float* W, int ld, int R, int C, int transpose, void* planes, uavgnn_stream_t stream);
+int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const void* planes, int N, const float* bias, float* Y, int ldy,
+                      int epilogue, uavgnn_stream_t stream);
 int uavgnn_gru_gates_bwd_fused(const float* pre, const float* h, const float* d_hout, int N, int H, float* d_gi, float* d_gh,
                                float* d_h, uavgnn_stream_t stream);
 

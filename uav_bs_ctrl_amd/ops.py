@@ -357,9 +357,9 @@ class _GruCellFused(th.autograd.Function):
     def backward(ctx, d_h2):
         inp, h, pre, W_ih, W_hh = ctx.saved_tensors
         d_gi, d_gh, dh = _gru_gates_bwd_from_pre(pre, h, L.f32c(d_h2))
-        d_inp = th.mm(d_gi, W_ih) if ctx.needs_input_grad[0] else None
+        d_inp = _mm_nn(d_gi, W_ih) if ctx.needs_input_grad[0] else None
         if ctx.needs_input_grad[1]:
-            dh.addmm_(d_gh, W_hh)
+            _mm_nn(d_gh, W_hh, out=dh, accumulate=True)
         else:
             dh = None
         gWih = _wgrad(d_gi, inp) if ctx.needs_input_grad[2] else None
@@ -401,6 +401,60 @@ def _colsum(dy):
     return _colsum_partial(dy).sum(0)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Dense layers on the bf16 matrix cores (csrc/gemm_x3.hip): fp32 in / out, six exact bf16 products per fp32 product
+# ---------------------------------------------------------------------------------------------------------------------
+GEMM_X3 = os.environ.get("UAVGNN_GEMM_X3", "1") != "0"   # False: vendor fp32 GEMMs (A/B, tools/gemm_x3_probe.py)
+# Measured against the recorded vendor solutions at C3 (tools/gemm_x3_probe.py, profiles/r02_gemm_x3_probe.txt): 1.10-1.30x on
+# outputs that tile by 128 columns (256, 512), 1.01x on 320 (2.5 tiles), 0.84x on 96: only the first group takes the kernel.
+
+
+def gemm_x3_supported(a, n_out, k) -> bool:
+    return bool(GEMM_X3 and a.is_cuda and a.dtype == th.float32 and a.dim() == 2 and a.stride(1) == 1
+                and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and n_out % 128 == 0 and a.shape[0] >= 4096
+                and a.shape[0] * a.stride(0) < 2 ** 31 and L.lib().uavgnn_gemm_x3_supported(a.shape[0], n_out, k))
+
+
+def gemm_x3(a, W, transpose_w=False, bias=None, out=None, accumulate=False, relu=False):
+    """out = a @ W.T (transpose_w=False, W [n_out, k]) or a @ W (transpose_w=True, W [k, n_out]) (+ bias) (+ out) (relu).
+    `W` may be a strided view with unit inner stride; its bf16 planes are rebuilt on every call (3-5 us: nothing observable
+    tells when a drop-in module's weights changed).  Caller checks gemm_x3_supported()."""
+    lib = L.lib()
+    M, K = a.shape
+    R, C = W.shape
+    n_out = C if transpose_w else R
+    assert (R if transpose_w else C) == K and W.stride(1) == 1
+    planes = th.empty(6 * R * C, dtype=th.uint8, device=a.device)
+    if out is None:
+        out = th.empty((M, n_out), dtype=th.float32, device=a.device)
+    with KERNEL_TIMER.span("gemm_x3"):
+        rc = lib.uavgnn_split_bf16x3(W.data_ptr(), W.stride(0), R, C, int(transpose_w), planes.data_ptr(), L.stream())
+        L.check(rc, "uavgnn_split_bf16x3")
+        rc = lib.uavgnn_gemm_nt_x3(a.data_ptr(), a.stride(0), M, K, planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(),
+                                   out.stride(0), (1 if accumulate else 0) | (2 if relu else 0), L.stream())
+    L.check(rc, "uavgnn_gemm_nt_x3")
+    return out
+
+
+def _mm_nt(x, W, b=None, relu=False):
+    """x @ W.T (+ b) (relu): bf16x3 kernel when the shape has one, else the vendor GEMM."""
+    if gemm_x3_supported(x, W.shape[0], W.shape[1]) and W.stride(1) == 1 and (b is None or b.is_contiguous()):
+        return gemm_x3(x, W, False, bias=b, relu=relu)
+    if relu:
+        return th._addmm_activation(b, x, W.t())
+    return th.addmm(b, x, W.t()) if b is not None else th.mm(x, W.t())
+
+
+def _mm_nn(dy, W, out=None, accumulate=False):
+    """dy @ W (+ out when accumulate)."""
+    if gemm_x3_supported(dy, W.shape[1], W.shape[0]) and W.stride(1) == 1 and \
+            (out is None or (out.stride(1) == 1 and out.dtype == th.float32)):
+        return gemm_x3(dy, W, True, out=out, accumulate=accumulate)
+    if out is None:
+        return th.mm(dy, W)
+    return out.addmm_(dy, W) if accumulate else th.mm(dy, W, out=out)
+
+
 class _LinearSplitK(th.autograd.Function):
     """y = x W^T (+ b) on the vendor GEMM (hipBLASLt/rocBLAS fp32), with a weight-gradient path shaped for this
     workload: N_a is 10^4..10^5 rows while W is at most 768 x 512, so dW = dY^T X has a tiny output and a huge
@@ -412,7 +466,7 @@ class _LinearSplitK(th.autograd.Function):
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
-        return th.addmm(b, x, W.t()) if b is not None else th.mm(x, W.t())
+        return _mm_nt(x, W, b)
 
     @staticmethod
     def backward(ctx, dy):
@@ -424,7 +478,7 @@ class _LinearSplitK(th.autograd.Function):
         dy = dy.contiguous()
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = th.mm(dy, W)
+            dx = _mm_nn(dy, W)
         if ctx.needs_input_grad[1]:
             n = x.shape[0]
             S = 1   # row chunks of >= 2048: S = 16 at N_a = 32768 (measured best or within 10 % on every layer shape)
@@ -452,7 +506,7 @@ class _LinearReLU(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b):
-        y = th._addmm_activation(b, x, W.t())
+        y = _mm_nt(x, W, b, relu=True)
         ctx.save_for_backward(x, W, y)
         return y
 
@@ -594,8 +648,12 @@ class _TarmacStep(th.autograd.Function):
         L.require_gpu(x, h, Wp, W_ih, talk_off)
         N, H = x.shape
         x, h = L.f32c(x), L.f32c(h)
-        proj = th.addmm(bp, x, Wp[:, :H].t())
-        proj.addmm_(h, Wp[:, H:].t())                                     # [N, M + 2K]: value | signature | query
+        if gemm_x3_supported(x, Wp.shape[0], H) and gemm_x3_supported(h, Wp.shape[0], H) and bp.is_contiguous():
+            proj = gemm_x3(x, Wp[:, :H], bias=bp)
+            gemm_x3(h, Wp[:, H:], out=proj, accumulate=True)
+        else:
+            proj = th.addmm(bp, x, Wp[:, :H].t())
+            proj.addmm_(h, Wp[:, H:].t())                                 # [N, M + 2K]: value | signature | query
         inp = th.empty((N, H + M), dtype=th.float32, device=x.device)     # [x || c], both halves filled by K3b
         E = talk_src.shape[0]
         a_save = th.empty(max(E, 1), dtype=th.float32, device=x.device)
@@ -648,8 +706,8 @@ class _TarmacStep(th.autograd.Function):
                 rc = L.lib().uavgnn_gru_gates_bwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), dh2_tot.data_ptr(), N, H,
                                                   d_gi.data_ptr(), d_gh.data_ptr(), dh.data_ptr(), L.stream())
             L.check(rc, "uavgnn_gru_gates_bwd")
-        d_inp = th.mm(d_gi, W_ih)                                          # [N, H + M]: d x | d c
-        dh.addmm_(d_gh, W_hh)
+        d_inp = _mm_nn(d_gi, W_ih)                                         # [N, H + M]: d x | d c
+        _mm_nn(d_gh, W_hh, out=dh, accumulate=True)
         if sink is not None:
             sink.owned.add(dh.data_ptr())
         ld = M + 2 * K
