@@ -1322,8 +1322,9 @@ def test_fused_gru_cell_kernel_vs_oracle(N, K_in, H):
     gref = th.autograd.grad((ref * w.double()).sum(), [i64, h64] + list(c64.parameters()))
     cell = cell.cuda()
     res = {}
-    for fused in (True, False):
-        ops.GRU_FUSED = fused
+    # (fused cell, bf16x3 arithmetic): the bf16-matrix-core cell (csrc/gru_x3.hip), the fp32-MFMA cell, vendor GEMMs + gates
+    for fused, x3 in ((True, True), (True, False), (False, False)):
+        ops.GRU_FUSED, ops.GRU_X3 = fused, x3
         try:
             i_d, h_d = inp.cuda().requires_grad_(True), h.cuda().requires_grad_(True)
             assert ops.gru_cell_supported(i_d, h_d) == fused
@@ -1332,10 +1333,69 @@ def test_fused_gru_cell_kernel_vs_oracle(N, K_in, H):
             with th.no_grad():
                 out_ng = ops.gru_cell(inp.cuda(), h.cuda(), cell)
             assert th.equal(out_ng, out.detach())
-            res[fused] = (out.detach(), got)
+            res[(fused, x3)] = (out.detach(), got)
         finally:
-            ops.GRU_FUSED = True
-    for fused, (out, got) in res.items():
-        assert_close(out, ref, 1e-5, f"h' fused={fused}")
+            ops.GRU_FUSED, ops.GRU_X3 = True, True
+    from uav_bs_ctrl_amd import _lib as L
+    if L.lib().uavgnn_gru_cell_x3_supported(K_in, H):
+        assert not th.equal(res[(True, True)][0], res[(True, False)][0]), "the bf16x3 cell did not run"
+    for key, (out, got) in res.items():
+        assert_close(out, ref, 1e-5, f"h' (fused, x3)={key}")
         for a, b, nm in zip(got, gref, ["d_inp", "d_h", "dW_ih", "dW_hh", "db_ih", "db_hh"]):
-            assert_close(a, b, 1e-4, f"{nm} fused={fused}", floor=1e-5)
+            assert_close(a, b, 1e-4, f"{nm} (fused, x3)={key}", floor=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K,transpose", [(4096, 256, 512, False), (5000, 512, 256, True), (4097, 128, 96, False),
+                                             (8192, 384, 768, True), (4200, 256, 32, False)])
+def test_gemm_bf16x3_vs_float64(M, N, K, transpose):
+    """csrc/gemm_x3.hip (fp32 GEMM as six exact bf16 x bf16 MFMA products per fp32 product) against the float64 product of the
+    same operands: forward layout (B = W [N, K]) and input-gradient layout (B = W^T from W [K, N]), strided operands, rows /
+    columns that do not fill the 128 x 128 tile, bias, accumulate and ReLU epilogues.  The error bound is the one an fp32
+    GEMM is held to (relative to sum_k |a_k b_k|), and the vendor GEMM on the same data is measured next to it."""
+    from uav_bs_ctrl_amd import ops
+    gen = th.Generator().manual_seed(M + N + K)
+    a_full = th.randn(M, K + 8, generator=gen).cuda()
+    a = a_full[:, :K]                                             # row stride K + 8
+    W_full = th.randn((K, N + 4) if transpose else (N, K + 4), generator=gen).cuda() * 0.1
+    W = W_full[:, :N] if transpose else W_full[:, :K]             # strided weight view (as Wp[:, :H] in the TarMAC step)
+    bias = th.randn(N, generator=gen).cuda()
+    assert ops.gemm_x3_supported(a, N, K)
+    B64 = W.double() if transpose else W.double().t()
+    ref = a.double() @ B64
+    scale = a.double().abs() @ B64.abs()
+    out = ops.gemm_x3(a, W, transpose)
+    err = ((out.double() - ref).abs() / scale).max().item()
+    err_vendor = (((a @ (W if transpose else W.t())).double() - ref).abs() / scale).max().item()
+    assert err < 6e-7, (err, err_vendor)                          # 10 x 2^-24: an fp32 accumulation of K <= 768 terms
+    assert err < 2.0 * err_vendor + 1e-7, (err, err_vendor)
+    out_b = ops.gemm_x3(a, W, transpose, bias=bias, relu=True)
+    assert_close(out_b, th.relu(ref + bias.double()), 1e-5, "bias + relu epilogue", floor=1e-6)
+    acc0 = th.randn(M, N + 8, generator=gen).cuda()
+    acc = acc0.clone()
+    ops.gemm_x3(a, W, transpose, out=acc[:, :N], accumulate=True)
+    assert_close(acc[:, :N], ref + acc0[:, :N].double(), 1e-5, "accumulate epilogue", floor=1e-6)
+    assert th.equal(acc[:, N:], acc0[:, N:]), "columns past N were written"
+    assert th.equal(ops.gemm_x3(a, W, transpose), out), "not bit-reproducible"
+
+
+def test_linear_layers_take_the_bf16x3_kernel_and_match_vendor_path():
+    """ops.linear / linear_relu forward and input gradient at an encoder-layer shape go through csrc/gemm_x3.hip (the span
+    counter moves) and agree with the vendor-GEMM path within the fp32 tolerance, weight / bias gradients included."""
+    from uav_bs_ctrl_amd import ops
+    gen = th.Generator().manual_seed(5)
+    x = th.randn(8192, 512, generator=gen).cuda().requires_grad_(True)
+    W = (th.randn(256, 512, generator=gen) * 0.05).cuda().requires_grad_(True)
+    b = th.randn(256, generator=gen).cuda().requires_grad_(True)
+    w = th.randn(8192, 256, generator=gen).cuda()
+    res = {}
+    for x3 in (True, False):
+        ops.GEMM_X3 = x3
+        try:
+            assert ops.gemm_x3_supported(x, 256, 512) == x3
+            y = ops.linear(x, W, b)          # (the ReLU variant's backward masks with y > 0: a 1e-7 difference in y flips
+            res[x3] = (y.detach(),) + th.autograd.grad((y * w).sum(), [x, W, b]) + (ops.linear_relu(x, W, b).detach(),)
+        finally:                             #  the mask of entries at the kink, so gradients are compared on the plain layer)
+            ops.GEMM_X3 = True
+    assert not th.equal(res[True][0], res[False][0]), "the bf16x3 GEMM did not run"
+    for a, c, nm in zip(res[True], res[False], ["y", "dx", "dW", "db", "relu(y)"]):
+        assert_close(a, c, 2e-5, nm, floor=1e-5)
