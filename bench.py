@@ -320,6 +320,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the simulator-inclusive figure (rows f1+f2+f3)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (smoke test)")
+    ap.add_argument("--no-fp32-leg", action="store_true",
+                    help="skip the second timing with the bf16x3 kernels off (fp32-MFMA GRU cell, vendor fp32 GEMMs)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -459,6 +461,32 @@ def main():
                                         "D-env (94 % of agents see no GT): AI below the machine balance, the launch mix is "
                                         "bound by HBM (output-row writes)")}
         res["kernel_ms_per_launch"] = {n: round(v["avg_ms"], 4) for n, v in ktimes.items()}
+        res["arithmetic"] = ("fp32 in / out / accumulate everywhere.  K1, K3b, K5 and all pointwise kernels: fp32 FMA / fp32 MFMA.  "
+                             "GRU cell (csrc/gru_x3.hip) and the dense layers whose output tiles by 128 columns (csrc/gemm_x3.hip): "
+                             "each fp32 operand is split EXACTLY into 3 bf16 terms and each fp32 product is the fp32-accumulated "
+                             "sum of 6 exact bf16 x bf16 MFMA products (dropped terms <= 2^-23 |a b|); measured error vs fp64 is "
+                             "BELOW the vendor fp32 GEMM's on the same data (profiles/r02_gemm_x3_probe.txt, "
+                             "profiles/r02_gru_probe_fused_vs_vendor.txt).  `fp32_mfma_leg` is the same cycle with those two "
+                             "kernels switched to fp32 MFMA / vendor fp32 GEMMs (UAVGNN_GRU_X3=0 UAVGNN_GEMM_X3=0).")
+        if world == 1 and not a.no_fp32_leg:
+            ops.GRU_X3 = ops.GEMM_X3 = False
+            try:
+                step()
+                th.cuda.synchronize()
+                gc.collect()
+                gc.disable()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    step()
+                th.cuda.synchronize()
+                e1 = time.perf_counter() - t1
+                gc.enable()
+                res["fp32_mfma_leg"] = {"value": world * a.B * a.T * 2 / e1, "unit": "env-steps/s", "steps": 2,
+                                        "ms_per_step": 1e3 * e1 / 2,
+                                        "config": "UAVGNN_GRU_X3=0 UAVGNN_GEMM_X3=0: GRU cell on fp32 MFMA (csrc/gru_fused.hip), "
+                                                  "every dense layer on the vendor fp32 GEMM"}
+            finally:
+                ops.GRU_X3 = ops.GEMM_X3 = True
         if world == 1 and not a.no_end_to_end:
             res["end_to_end"] = end_to_end(learner, a, device)
         if world == 1 and not a.no_cpu_baseline:

@@ -1323,8 +1323,9 @@ def test_fused_gru_cell_kernel_vs_oracle(N, K_in, H):
     cell = cell.cuda()
     res = {}
     # (fused cell, bf16x3 arithmetic): the bf16-matrix-core cell (csrc/gru_x3.hip), the fp32-MFMA cell, vendor GEMMs + gates
+    min_rows = ops.GRU_FUSED_MIN_ROWS
     for fused, x3 in ((True, True), (True, False), (False, False)):
-        ops.GRU_FUSED, ops.GRU_X3 = fused, x3
+        ops.GRU_FUSED, ops.GRU_X3, ops.GRU_FUSED_MIN_ROWS = fused, x3, 0   # the fused cells at every size, ragged tiles included
         try:
             i_d, h_d = inp.cuda().requires_grad_(True), h.cuda().requires_grad_(True)
             assert ops.gru_cell_supported(i_d, h_d) == fused
@@ -1335,7 +1336,7 @@ def test_fused_gru_cell_kernel_vs_oracle(N, K_in, H):
             assert th.equal(out_ng, out.detach())
             res[(fused, x3)] = (out.detach(), got)
         finally:
-            ops.GRU_FUSED, ops.GRU_X3 = True, True
+            ops.GRU_FUSED, ops.GRU_X3, ops.GRU_FUSED_MIN_ROWS = True, True, min_rows
     from uav_bs_ctrl_amd import _lib as L
     if L.lib().uavgnn_gru_cell_x3_supported(K_in, H):
         assert not th.equal(res[(True, True)][0], res[(True, False)][0]), "the bf16x3 cell did not run"

@@ -107,6 +107,114 @@ void run(const float* w, float* out, int wps, const char* name) {
          wps, us, ns_per_tile_simd, ns_per_tile_simd * 2.0);
 }
 
+// ---- the same tile with the score GEMM on v_mfma_f32_16x16x32_bf16: the K = 4 contraction of fp32 operands becomes 24 of
+// the 32 K slots - the six exact bf16 x bf16 products (w1 x1, w1 x2, w1 x3, w2 x1, w2 x2, w3 x1) of every feature laid side
+// by side - so ONE bf16 MFMA (16 cycles) replaces the fp32 MFMA (32 cycles) at fp32 accuracy.  Per tile every lane splits
+// the four features of its edge (two packed splits) and picks the two 4-slot groups of its K range; the weight operand is
+// pre-arranged per column tile: in registers (WLDS = false, 64 VGPRs) or read from LDS per tile (WLDS = true).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Split3 { unsigned h1, h2, h3; };
+__device__ __forceinline__ Split3 split_pair(float x, float y) {
+  Split3 s;
+  bf16x2 p = __builtin_convertvector(f32x2{x, y}, bf16x2);
+  s.h1 = __builtin_bit_cast(unsigned, p);
+  x -= __uint_as_float(s.h1 << 16); y -= __uint_as_float(s.h1 & 0xffff0000u);
+  p = __builtin_convertvector(f32x2{x, y}, bf16x2);
+  s.h2 = __builtin_bit_cast(unsigned, p);
+  x -= __uint_as_float(s.h2 << 16); y -= __uint_as_float(s.h2 & 0xffff0000u);
+  p = __builtin_convertvector(f32x2{x, y}, bf16x2);
+  s.h3 = __builtin_bit_cast(unsigned, p);
+  return s;
+}
+
+template <int DEPTH, bool WLDS>
+__global__ __launch_bounds__(256, 2) void k_tile_bf16(const float* __restrict__ w, float* __restrict__ out, int tiles) {
+  __shared__ u32x4 sW[CT * 64];
+  const int lane = threadIdx.x & 63, g = lane >> 4;
+  float att[CT][4];
+  f32x4 cinit[CT];
+  u32x4 Wa[WLDS ? 1 : CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const u32x4 v = u32x4{__float_as_uint(w[(ct * 64 + lane) & 1023]) & 0xffff0000u, 0x3f803f80u, 0x3e803e80u, 0x3d803d80u};
+    if (WLDS) { if (threadIdx.x < 64) sW[ct * 64 + lane] = v; } else Wa[ct] = v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      att[ct][r] = w[(ct * 4 + r + lane) & 1023] * 0.01f;
+      cinit[ct][r] = w[(ct * 4 + r + 2 * lane) & 1023];
+    }
+  }
+  __syncthreads();
+  float m = -INFINITY, den = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float4 xe = make_float4(w[lane], w[lane + 1], w[lane + 2], w[lane + 3]);
+  for (int t = 0; t < tiles; ++t) {
+    // B operand: k slots 8g..8g+7 of edge j = two of the groups x1 | x2 | x3 (each = the 4 features as 2 packed words)
+    const Split3 p01 = split_pair(xe.x, xe.y), p23 = split_pair(xe.z, xe.w);
+    u32x4 xb;
+    xb[0] = g == 0 ? p01.h1 : g == 1 ? p01.h3 : g == 2 ? p01.h2 : 0u;
+    xb[1] = g == 0 ? p23.h1 : g == 1 ? p23.h3 : g == 2 ? p23.h2 : 0u;
+    xb[2] = g == 0 ? p01.h2 : g == 3 ? 0u : p01.h1;
+    xb[3] = g == 0 ? p23.h2 : g == 3 ? 0u : p23.h1;
+    const bf16x8 xB = __builtin_bit_cast(bf16x8, xb);
+    float pe[4][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { pe[k][0] = att[k][0] * xe.x; pe[k][1] = 0.f; }
+    f32x4 z[CT];
+#define WOP(ct) __builtin_bit_cast(bf16x8, WLDS ? sW[(ct) * 64 + lane] : Wa[WLDS ? 0 : (ct)])
+#pragma unroll
+    for (int ct = 0; ct < DEPTH && ct < CT; ++ct) z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WOP(ct), xB, cinit[ct], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int k = ct / 4;
+      pe[k][0] = fmaf(att[ct][0], fabsf(z[ct][0]), pe[k][0]);
+      pe[k][1] = fmaf(att[ct][1], fabsf(z[ct][1]), pe[k][1]);
+      pe[k][0] = fmaf(att[ct][2], fabsf(z[ct][2]), pe[k][0]);
+      pe[k][1] = fmaf(att[ct][3], fabsf(z[ct][3]), pe[k][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ct + DEPTH < CT) {
+        z[ct + DEPTH] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WOP(ct + DEPTH), xB, cinit[ct + DEPTH], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#undef WOP
+    float e = reduce_heads(pe[0][0] + pe[0][1], pe[1][0] + pe[1][1], pe[2][0] + pe[2][1], pe[3][0] + pe[3][1]);
+    const float mn = fmaxf(m, e);
+    const float sc = __builtin_amdgcn_exp2f(m - mn);
+    const float p = __builtin_amdgcn_exp2f(e - mn);
+    den = fmaf(den, sc, p);
+    s0 = fmaf(s0, sc, p * xe.x);
+    s1 = fmaf(s1, sc, p * xe.y);
+    s2 = fmaf(s2, sc, p * xe.z);
+    s3 = fmaf(s3, sc, p * xe.w);
+    m = mn;
+    xe.x = xe.x * 0.999f + 0.001f * p; xe.y += 0.001f; xe.z -= 0.001f; xe.w = xe.w * 0.999f;
+  }
+  if (den + s0 + s1 + s2 + s3 == 12345.f) out[0] = m;
+}
+
+template <int DEPTH, bool WLDS>
+void run_bf16(const float* w, float* out, int wps, const char* name) {
+  const int tiles = 4000;
+  const int blocks = 256 * wps;
+  auto launch = [&] { hipLaunchKernelGGL((k_tile_bf16<DEPTH, WLDS>), dim3(blocks), dim3(256), 0, 0, w, out, tiles); };
+  launch();
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0);
+  for (int i = 0; i < 3; ++i) launch();
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1000.0 / 3;
+  const double ns = us * 1e3 / (double(tiles) * wps);
+  printf("%-48s waves/SIMD=%d  %8.1f us  %7.1f ns per tile per SIMD  (= %6.0f cyc @2.0GHz)  bf16 MFMA-only floor 256 cyc\n", name, wps, us, ns, ns * 2.0);
+}
+
 int main() {
   float *w, *out;
   hipMalloc(&w, 4096);
@@ -128,6 +236,11 @@ int main() {
     run<16, false, 0, 1>(w, out, wps, "compiler order, FMAs independent of z");
     run<16, false, 0, 3>(w, out, wps, "16 MFMA + sum(z) only (no |z| FMAs)");
     run<16, true, 0, 3>(w, out, wps, "16 MFMA + sum(z) only, pinned");
+    run_bf16<1, false>(w, out, wps, "bf16x3-in-K score MFMA, depth 1, W in registers");
+    run_bf16<2, false>(w, out, wps, "bf16x3-in-K score MFMA, depth 2, W in registers");
+    run_bf16<4, false>(w, out, wps, "bf16x3-in-K score MFMA, depth 4, W in registers");
+    run_bf16<2, true>(w, out, wps, "bf16x3-in-K score MFMA, depth 2, W from LDS");
+    run_bf16<4, true>(w, out, wps, "bf16x3-in-K score MFMA, depth 4, W from LDS");
   }
   return 0;
 }

@@ -297,8 +297,11 @@ def gru_gates(gi, gh, h):
 GRU_FUSED = True   # K4 as one kernel (csrc/gru_fused.hip); False: vendor GEMMs + the gate kernel (A/B, tools/gru_probe.py)
 
 
+GRU_FUSED_MIN_ROWS = 1024   # below: a handful of workgroups walk 18 K slices serially (25 us at 8 rows; vendor GEMMs + gates: 15 us)
+
+
 def gru_cell_supported(inp, h) -> bool:
-    return bool(GRU_FUSED and inp.is_cuda and inp.dtype == th.float32 and h.dtype == th.float32 and inp.stride(1) == 1
+    return bool(GRU_FUSED and inp.shape[0] >= GRU_FUSED_MIN_ROWS and inp.is_cuda and inp.dtype == th.float32 and h.dtype == th.float32 and inp.stride(1) == 1
                 and inp.stride(0) % 4 == 0 and inp.data_ptr() % 16 == 0
                 and L.lib().uavgnn_gru_cell_supported(inp.shape[1], h.shape[1]))
 
