@@ -24,7 +24,8 @@
 // (tools/ubench/mfma_bf16.hip: 18.2 ns per 32x32x16 MFMA per SIMD with random operands).  Variants measured and dropped:
 // 128 x 32 tiles with four waves and 16x16x32 MFMAs (200 us: three independent accumulators between dependent 16x16x32
 // MFMAs issue at half rate, profiles/r02_ubench_mfma_bf16.txt), the same with 32x32x16 MFMAs (215 us), loads two slices
-// ahead through a fully unrolled slice loop (-4 us), a start skew between co-resident workgroups (0).
+// ahead through a fully unrolled slice loop (-4 us), a start skew between co-resident workgroups (0), persistent workgroups
+// that load the next tile's first slice during the epilogue (207 us).
 #include "bf16x3.h"
 #include "common.h"
 
