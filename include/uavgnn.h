@@ -316,6 +316,7 @@ int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, const float* 
 #define UAVGNN_GEMM_ACCUMULATE 1
 #define UAVGNN_GEMM_RELU 2
 int uavgnn_gemm_x3_supported(int M, int N, int K);
+void uavgnn_gemm_x3_set_variant(int variant);   /* A/B of tools/gemm_x3_probe.py: 8 (default) = 256 x 128 tiles, eight waves, double-buffered LDS; 4 = 128 x 128 tiles, four waves */
 int uavgnn_split_bf16x3(const float* W, int ld, int R, int C, int transpose, void* planes, uavgnn_stream_t stream);
 int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const void* planes, int N, const float* bias, float* Y, int ldy,
                       int epilogue, uavgnn_stream_t stream);

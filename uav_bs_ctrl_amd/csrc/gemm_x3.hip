@@ -140,10 +140,150 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(const float* __restr
   }
 }
 
+// ---- eight wavefronts: 256 x 128 output tile, LDS double-buffered, ONE barrier per slice (the structure of gru_x3.hip) ---------
+// Waves of 64 x 64 (2 x 2 tiles of 32 x 32, 64 accumulator registers); slice t + 1 is split and written to the other buffer
+// in the same straight-line code as the MFMAs of slice t, the loads of slice t + 2 are in flight, the fragment reads are
+// software-pipelined over the two 16-wide halves of a slice; waves w / w + 4 (same SIMD) stage before / after their first
+// MFMA group.  148 KB of LDS: one workgroup per CU.
+namespace w8 {
+constexpr int BM8 = 256, NT = 512;
+constexpr int PA = BM8 * 4, PB = BN * 4;               // 16-byte chunks per split plane of the X / B tile
+constexpr int BUF = 3 * PA + 3 * PB;                   // chunks per buffer (72 KB)
+}  // namespace w8
+
+template <bool ACC, bool RELU>
+__global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __restrict__ X, int ldx, int M, int K,
+                                                              const unsigned short* __restrict__ Bp, int N,
+                                                              const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                              int row_blocks, int col_blocks) {
+  using namespace w8;
+  __shared__ u32x4 smem[2 * BUF];   // buffer b: X planes [3][256][4] then B planes [3][128][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l32 = lane & 31, lh = lane >> 5, sw = swz32(l32);
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int rb = (slot / col_blocks) * 8 + xcd, cb = slot - (slot / col_blocks) * col_blocks;
+  if (rb >= row_blocks) return;
+  const int m0 = rb * BM8, n0 = cb * BN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  // X loader: float4 q = tid + 512 i (i < 4) -> row tid / 8 + 64 i, k = 4 (tid % 8)
+  const int lr = tid >> 3, c4 = tid & 7;
+  unsigned xo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xo[i] = static_cast<unsigned>(min(m0 + lr + 64 * i, M - 1)) * ldx + 4 * c4;
+  const int sa_w = lr * 32 + (((c4 >> 1) ^ swz32(lr)) * 8) + (c4 & 1) * 4;   // bf16 units inside an X plane
+  // B loader: chunk q = tid + 512 i (i < 3): plane i, row tid / 4, chunk tid % 4
+  unsigned bo[3];
+  int sbw[3];
+  const unsigned plane = static_cast<unsigned>(N) * K;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int row = tid >> 2, c = tid & 3;
+    bo[i] = i * plane + static_cast<unsigned>(min(n0 + row, N - 1)) * K + 8 * c;
+    sbw[i] = 3 * PA + i * PB + row * 4 + (c ^ swz32(row));
+  }
+  const int ns = K / BK;
+  float4 ra[4];
+  u32x4 rw[3];
+  auto gload = [&](int t) {
+    const unsigned k0 = static_cast<unsigned>(t) * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(X + (xo[i] + k0));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rw[i] = *reinterpret_cast<const u32x4*>(Bp + (bo[i] + k0));
+  };
+  auto lstore = [&](int buf) {
+    u32x4* sb = smem + buf * BUF;
+    unsigned short* sa = reinterpret_cast<unsigned short*>(sb) + sa_w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage4(sa + 64 * i * 32, PA * 8, ra[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sb[sbw[i]] = rw[i];
+  };
+  struct Half {
+    bf16x8 a[2][3], b[2][3];   // [tile][plane]
+  };
+#define UAVGNN_X3_READ(F, buf, kh)                                                                                 \
+  {                                                                                                                \
+    const u32x4* sb = smem + (buf) * BUF;                                                                          \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {               \
+      F.a[a][pl] = as_frag(sb[pl * PA + (wm + a * 32 + l32) * 4 + ((2 * (kh) + lh) ^ sw)]);                        \
+      F.b[a][pl] = as_frag(sb[3 * PA + pl * PB + (wn + a * 32 + l32) * 4 + ((2 * (kh) + lh) ^ sw)]);               \
+    }                                                                                                              \
+  }
+#define UAVGNN_X3_TERM(ia, ib)                                                                      \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)      \
+      acc[a][b] = mfma32(F.a[a][ia], F.b[b][ib], acc[a][b]);
+#define UAVGNN_X3_MFMA(F_)                                                                           \
+  {                                                                                                  \
+    const Half& F = F_;                                                                              \
+    UAVGNN_X3_TERM(0, 2) UAVGNN_X3_TERM(2, 0) UAVGNN_X3_TERM(1, 1) UAVGNN_X3_TERM(0, 1) UAVGNN_X3_TERM(1, 0) UAVGNN_X3_TERM(0, 0) \
+  }
+  gload(0);
+  lstore(0);
+  gload(min(1, ns - 1));
+  __syncthreads();
+  const bool early = wave < 4;
+  Half f0, f1;
+  UAVGNN_X3_READ(f0, 0, 0)
+  for (int t = 0; t < ns; ++t) {
+    UAVGNN_X3_READ(f1, t & 1, 1)
+    if (early) {
+      lstore((t + 1) & 1);                 // slice t + 1 (the tail re-stages the last slice: unconditional, straight-line)
+      gload(min(t + 2, ns - 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    UAVGNN_X3_MFMA(f0)
+    __builtin_amdgcn_sched_barrier(0);
+    if (!early) {
+      lstore((t + 1) & 1);
+      gload(min(t + 2, ns - 1));
+    }
+    __syncthreads();
+    UAVGNN_X3_READ(f0, (t + 1) & 1, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    UAVGNN_X3_MFMA(f1)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef UAVGNN_X3_MFMA
+#undef UAVGNN_X3_TERM
+#undef UAVGNN_X3_READ
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int col = n0 + wn + b * 32 + l32;
+    if (col >= N) continue;
+    const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m0 + wm + a * 32 + 8 * (i >> 2) + 4 * lh + (i & 3);
+        if (row < M) {
+          float* p = Y + static_cast<size_t>(row) * ldy + col;
+          float v = acc[a][b][i] + bv;
+          if (ACC) v += *p;
+          if (RELU) v = fmaxf(v, 0.f);
+          *p = v;
+        }
+      }
+  }
+}
+
 }  // namespace
 }  // namespace uavgnn
 
 using namespace uavgnn;
+
+static int g_gemm_x3_variant = 8;   // A/B switch of tools/gemm_x3_probe.py (uavgnn_gemm_x3_set_variant): 4 = 128 x 128 tiles, four waves
+extern "C" void uavgnn_gemm_x3_set_variant(int v) { g_gemm_x3_variant = v; }
 
 extern "C" int uavgnn_gemm_x3_supported(int M, int N, int K) {
   // 32-bit element offsets inside the kernel: every operand below 2^31 elements
@@ -169,14 +309,28 @@ extern "C" int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const vo
   if (!uavgnn_gemm_x3_supported(M, N, K) || (ldx & 3) || static_cast<long long>(M) * ldx >= (1LL << 31) ||
       ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(planes)) & 15))
     return UAVGNN_EUNSUPPORTED;
-  const int row_blocks = (M + BM - 1) / BM, col_blocks = (N + BN - 1) / BN;
-  const dim3 grid(((row_blocks + 7) / 8) * 8 * col_blocks), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned short* bp = static_cast<const unsigned short*>(planes);
+  const bool acc = (epilogue & UAVGNN_GEMM_ACCUMULATE) != 0, relu = (epilogue & UAVGNN_GEMM_RELU) != 0;
+  const int col_blocks = (N + BN - 1) / BN;
+  if (g_gemm_x3_variant == 8) {
+    const int row_blocks = (M + w8::BM8 - 1) / w8::BM8;
+    const dim3 grid(((row_blocks + 7) / 8) * 8 * col_blocks), block(w8::NT);
+#define UAVGNN_X3_GEMM(ACC, RELU)                                                                                        \
+  hipLaunchKernelGGL((gemm_nt_x3w8_kernel<ACC, RELU>), grid, block, 0, st, X, ldx, M, K, bp, N, bias, Y, ldy, row_blocks, \
+                     col_blocks)
+    if (acc && relu) UAVGNN_X3_GEMM(true, true);
+    else if (acc) UAVGNN_X3_GEMM(true, false);
+    else if (relu) UAVGNN_X3_GEMM(false, true);
+    else UAVGNN_X3_GEMM(false, false);
+#undef UAVGNN_X3_GEMM
+    return launch_status();
+  }
+  const int row_blocks = (M + BM - 1) / BM;
+  const dim3 grid(((row_blocks + 7) / 8) * 8 * col_blocks), block(256);
 #define UAVGNN_X3_GEMM(ACC, RELU)                                                                                      \
   hipLaunchKernelGGL((gemm_nt_x3_kernel<ACC, RELU>), grid, block, 0, st, X, ldx, M, K, bp, N, bias, Y, ldy, row_blocks, \
                      col_blocks)
-  const bool acc = (epilogue & UAVGNN_GEMM_ACCUMULATE) != 0, relu = (epilogue & UAVGNN_GEMM_RELU) != 0;
   if (acc && relu) UAVGNN_X3_GEMM(true, true);
   else if (acc) UAVGNN_X3_GEMM(true, false);
   else if (relu) UAVGNN_X3_GEMM(false, true);

@@ -412,7 +412,14 @@ GEMM_X3 = os.environ.get("UAVGNN_GEMM_X3", "1") != "0"   # False: vendor fp32 GE
 # outputs that tile by 128 columns (256, 512), 1.01x on 320 (2.5 tiles), 0.84x on 96: only the first group takes the kernel.
 
 
+_gemm_x3_variant_set = False
+
+
 def gemm_x3_supported(a, n_out, k) -> bool:
+    global _gemm_x3_variant_set
+    if not _gemm_x3_variant_set and "UAVGNN_GEMM_X3_VARIANT" in os.environ:   # A/B: 4 = 128 x 128 tiles, four waves
+        L.lib().uavgnn_gemm_x3_set_variant(int(os.environ["UAVGNN_GEMM_X3_VARIANT"]))
+    _gemm_x3_variant_set = True
     return bool(GEMM_X3 and a.is_cuda and a.dtype == th.float32 and a.dim() == 2 and a.stride(1) == 1
                 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and n_out % 128 == 0 and a.shape[0] >= 4096
                 and a.shape[0] * a.stride(0) < 2 ** 31 and L.lib().uavgnn_gemm_x3_supported(a.shape[0], n_out, k))
