@@ -1400,3 +1400,27 @@ def test_linear_layers_take_the_bf16x3_kernel_and_match_vendor_path():
     assert not th.equal(res[True][0], res[False][0]), "the bf16x3 GEMM did not run"
     for a, c, nm in zip(res[True], res[False], ["y", "dx", "dW", "db", "relu(y)"]):
         assert_close(a, c, 2e-5, nm, floor=1e-5)
+
+
+@pytest.mark.parametrize("transpose", [False, True])
+def test_bf16x3_split_is_exact(transpose):
+    """uavgnn_split_bf16x3: the three bf16 planes of a weight matrix sum back to the fp32 input EXACTLY (bit for bit) over
+    46 binades of magnitude, both layouts, strided input - the property the "six exact products" argument of
+    csrc/bf16x3.h rests on - and the terms shrink by >= 2^-8 per plane."""
+    from uav_bs_ctrl_amd import _lib as L
+    gen = th.Generator().manual_seed(11)
+    R, C = 96, 130
+    mag = th.exp2(th.randint(-23, 23, (R, C + 6), generator=gen).float())
+    W_full = (th.randn(R, C + 6, generator=gen) * mag).cuda()
+    W_full[0, :4] = th.tensor([0.0, -0.0, 1.0, -3.0e38])
+    W = W_full[:, :C]                                              # row stride C + 6
+    planes = th.empty(6 * R * C, dtype=th.uint8, device="cuda")
+    L.check(L.lib().uavgnn_split_bf16x3(W.data_ptr(), W.stride(0), R, C, int(transpose), planes.data_ptr(), L.stream()), "split")
+    th.cuda.synchronize()
+    p = planes.view(th.bfloat16).view(3, C, R) if transpose else planes.view(th.bfloat16).view(3, R, C)
+    ref = W.t() if transpose else W
+    total = p[0].double() + p[1].double() + p[2].double()
+    assert th.equal(total, ref.double()), "a1 + a2 + a3 != a"
+    assert th.equal(total.float(), ref)
+    a = ref.abs().double()
+    assert bool((p[1].double().abs() <= a * 2.0 ** -8).all()) and bool((p[2].double().abs() <= a * 2.0 ** -16).all())
