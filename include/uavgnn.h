@@ -112,6 +112,14 @@ int uavgnn_gatv2_bwd_generic(const float* x_src, int E, int F_src, const float* 
                      int nh, int D, float slope, const float* out, const float* d_out, int ld_out,
                      const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d, float* dattn,
                      float* dW_r, float* db_r, void* workspace, size_t workspace_bytes, uavgnn_stream_t stream);
+/* A/B: the same contract for F_src = 4, nh = 4, D = 64 with the per-(edge, channel) part of the backward on the matrix cores
+ * (z^T tiles on fp32 MFMA, sign sums as a bf16 MFMA of +-1 signs against exactly split de x terms; csrc/gatv2.hip). Other
+ * head layouts: UAVGNN_EUNSUPPORTED.  Measured slower than the VALU kernel at C3 (264 vs 230 us): not used by the library. */
+int uavgnn_gatv2_bwd_mfma(const float* x_src, int E, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
+                     const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
+                     int nh, int D, float slope, const float* out, const float* d_out, int ld_out,
+                     const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d, float* dattn,
+                     float* dW_r, float* db_r, void* workspace, size_t workspace_bytes, uavgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * K3b  Targeted attention over the talk relation, forward.

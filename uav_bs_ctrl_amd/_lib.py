@@ -43,6 +43,9 @@ SIGNATURES = {
     "uavgnn_gatv2_bwd_generic": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                   _c_int, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                   _c_fp, _c_fp, _c_fp, ctypes.c_void_p, ctypes.c_size_t, _c_st]),
+    "uavgnn_gatv2_bwd_mfma": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
+                                  _c_int, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
+                                  _c_fp, _c_fp, _c_fp, ctypes.c_void_p, ctypes.c_size_t, _c_st]),
     "uavgnn_talk_attn_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip,
                                       _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_int, _c_st]),
     "uavgnn_talk_attn_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip,
