@@ -1218,6 +1218,28 @@ def test_graphed_act_replays_the_eager_rollout_step():
     assert int(a1.min()) >= 0 and int(a1.max()) < 9 and not th.equal(a1, acts_r)   # fresh randomness every replay
 
 
+def test_graphed_act_at_4096_agents_captures_the_matrix_core_kernels():
+    """The same capture at a batch where the bf16x3 GRU cell and GEMM are in use (512 envs x 8 agents: weight-split launches,
+    512-thread workgroups with 120-148 KB of LDS, per-call plane buffers from the graph's pool): the replay equals the eager
+    step and repeats bit for bit."""
+    from uav_bs_ctrl_amd import from_padded_obs, ops
+    from uav_bs_ctrl_amd.graphs import GraphedAct
+    dev, (B, n, M) = th.device("cuda"), (512, 8, 50)
+    L = _graph_learner(n, 6)
+    ga = GraphedAct(L, B, n, M, r_comm=1.2)
+    gen = th.Generator(device=dev).manual_seed(5)
+    h = 0.1 * th.randn(B * n, 256, device=dev, generator=gen)
+    gt, ub, ag, d = _padded_obs(gen, (B,), n, M, dev)
+    assert ops.gru_cell_supported(th.empty(B * n, 320, device=dev), h) and ops.gemm_x3_supported(th.empty(B * n, 512, device=dev), 256, 512)
+    acts, h2 = ga(gt, ub, ag, d, h, 0.0)
+    acts, h2 = acts.clone(), h2.clone()
+    acts_e, h2_e = L.act(from_padded_obs(gt, ub, ag, d, 1.2), h, 0.0)
+    assert_close(h2, h2_e, 1e-6, "h' replay vs eager")
+    assert float((acts != acts_e).float().mean()) < 1e-3          # argmax ties at the 1e-7 level aside
+    acts_r, h2_r = ga(gt, ub, ag, d, h, 0.0)
+    assert th.equal(acts_r, acts) and th.equal(h2_r, h2)
+
+
 def test_graphed_update_replays_the_eager_update():
     """hipGraph capture of the WHOLE update (device graph builder for all T+1 steps, time-batched encoder, 2T+1
     forwards, BPTT backward, clip + AdamW + polyak in one launch): two replays on two sampled batches leave the same
