@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3   # fp32 vector = fp32 MFMA peak
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; an MFMA-only loop sustains 2080-2140, 1840 on random operands)
 
 
 def exp3_args(device, c="tarmac"):
@@ -460,6 +461,32 @@ def main():
                                         if bound == "mfma" else
                                         "D-env (94 % of agents see no GT): AI below the machine balance, the launch mix is "
                                         "bound by HBM (output-row writes)")}
+        # ---- the GEMM-shaped kernels by time share (the GRU cell is the largest kernel of a dense cycle): MFMA roofs ----------
+        sec = []
+        kc = ktimes.get("gru_cell_fwd")
+        if kc and kc["work"]:
+            fl = sum(2.0 * N * 3 * H * (K_in + H) for (N, K_in, H, _) in kc["work"])       # fp32-equivalent FLOP
+            x3 = all(w[3] == "bf16x3" for w in kc["work"])
+            tf = fl / (kc["total_ms"] * 1e-3) / 1e12
+            sec.append({"kernel": "gru_cell_fwd_x3w8_kernel + split_planes_kernel (K4, whole GRU cell)" if x3 else
+                                  "gru_cell_fwd_kernel (K4, whole GRU cell, fp32 MFMA)",
+                        "bound": "mfma", "launches": kc["count"], "avg_launch_ms": kc["avg_ms"],
+                        "fp32_equivalent_tflops": tf,
+                        "achieved": 6.0 * tf if x3 else tf, "peak": BF16_PEAK_TFLOPS if x3 else FP32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s (bf16 MFMA: six products per fp32 product)" if x3 else "TFLOP/s",
+                        "frac": (6.0 * tf / BF16_PEAK_TFLOPS) if x3 else tf / FP32_PEAK_TFLOPS,
+                        "share_of_step": kc["total_ms"] / (1e3 * elapsed)})
+        kg = ktimes.get("gemm_x3")
+        if kg and kg["work"]:
+            fl = sum(2.0 * M * N * K for (M, N, K) in kg["work"])
+            tf = fl / (kg["total_ms"] * 1e-3) / 1e12
+            sec.append({"kernel": "gemm_nt_x3w8_kernel + split_matrix_kernel (dense layers: forward / input gradient)",
+                        "bound": "mfma", "launches": kg["count"], "avg_launch_ms": kg["avg_ms"],
+                        "fp32_equivalent_tflops": tf, "achieved": 6.0 * tf, "peak": BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s (bf16 MFMA: six products per fp32 product)", "frac": 6.0 * tf / BF16_PEAK_TFLOPS,
+                        "share_of_step": kg["total_ms"] / (1e3 * elapsed)})
+        if sec:
+            res["roofline_secondary"] = sec
         res["kernel_ms_per_launch"] = {n: round(v["avg_ms"], 4) for n, v in ktimes.items()}
         res["arithmetic"] = ("fp32 in / out / accumulate everywhere.  K1, K3b, K5 and all pointwise kernels: fp32 FMA / fp32 MFMA.  "
                              "GRU cell (csrc/gru_x3.hip) and the dense layers whose output tiles by 128 columns (csrc/gemm_x3.hip): "

@@ -317,7 +317,7 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save):
     if GRU_X3 and L.lib().uavgnn_gru_cell_x3_supported(inp.shape[1], H):
         lib, K_in = L.lib(), inp.shape[1]
         planes = th.empty(lib.uavgnn_gru_cell_x3_workspace_bytes(K_in, H), dtype=th.uint8, device=h.device)
-        with KERNEL_TIMER.span("gru_cell_fwd"):
+        with KERNEL_TIMER.span("gru_cell_fwd", (N, K_in, H, "bf16x3")):
             # the planes are rebuilt on every call: nothing observable tells when a drop-in module's weights changed
             rc = lib.uavgnn_gru_split_weights(W_ih.data_ptr(), K_in, W_hh.data_ptr(), H, planes.data_ptr(), L.stream())
             L.check(rc, "uavgnn_gru_split_weights")
@@ -325,7 +325,7 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save):
                                             b_ih.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), L.ptr(pre), L.stream())
         L.check(rc, "uavgnn_gru_cell_fwd_x3")
         return h2, pre
-    with KERNEL_TIMER.span("gru_cell_fwd"):
+    with KERNEL_TIMER.span("gru_cell_fwd", (N, inp.shape[1], H, "f32")):
         rc = L.lib().uavgnn_gru_cell_fwd(inp.data_ptr(), inp.stride(0), inp.shape[1], h.data_ptr(), N, H, W_ih.data_ptr(),
                                          b_ih.data_ptr(), W_hh.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), L.ptr(pre),
                                          L.stream())
@@ -437,7 +437,7 @@ def gemm_x3(a, W, transpose_w=False, bias=None, out=None, accumulate=False, relu
     planes = th.empty(6 * R * C, dtype=th.uint8, device=a.device)
     if out is None:
         out = th.empty((M, n_out), dtype=th.float32, device=a.device)
-    with KERNEL_TIMER.span("gemm_x3"):
+    with KERNEL_TIMER.span("gemm_x3", (M, n_out, K)):
         rc = lib.uavgnn_split_bf16x3(W.data_ptr(), W.stride(0), R, C, int(transpose_w), planes.data_ptr(), L.stream())
         L.check(rc, "uavgnn_split_bf16x3")
         rc = lib.uavgnn_gemm_nt_x3(a.data_ptr(), a.stride(0), M, K, planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(),
