@@ -266,19 +266,19 @@ def end_to_end(learner, a, device, cycles=2):
         ubs = th.randint(0, 30, (B, n, 2), device=device, generator=gen).double() * grid
         return ubs, gts.clamp(0, mp.range_pos).float()
 
+    zero_done = th.zeros(B, 1, device=device)
+
     def cycle():
         ubs, gts = positions()
         o = env.reset(ubs, gts, generator=gen)
         h = learner.init_hidden(B)
         for t in range(T):
             g = from_padded_obs(o["gt"], o["ubs"], o["agent"], o["d_u2u"], r_comm=mp.r_comm, static=STATIC)
-            cur = {k: o[k].clone() for k in ("gt", "ubs", "agent", "d_u2u")}
+            rb.stage_obs(dict(gt=o["gt"], ubs=o["ubs"], agent=o["agent"], d_u2u=o["d_u2u"], h=h.view(B, n, -1)))
             acts, h2 = learner.act(g, h, 0.05)
-            o, rew, done, _ = env.step(acts)
-            rb.push(dict(cur, h=h.view(B, n, -1), state=th.zeros(B, 0, device=device), act=acts.view(B, n),
-                         rew=rew.float(), done=th.zeros(B, 1, device=device), next_gt=o["gt"], next_ubs=o["ubs"],
-                         next_agent=o["agent"], next_d_u2u=o["d_u2u"], next_h=h2.view(B, n, -1),
-                         next_state=th.zeros(B, 0, device=device)))
+            o, rew, done, _ = env.step(acts)      # overwrites the observation buffers in place: they are in the replay already
+            rb.push(dict(act=acts.view(B, n), rew=rew.float(), done=zero_done, next_gt=o["gt"], next_ubs=o["ubs"],
+                         next_agent=o["agent"], next_d_u2u=o["d_u2u"], next_h=h2.view(B, n, -1)))
             h = h2
         m = rb.mem                                              # all B sequences, time-major padded tensors
         tm = {k: m[k].transpose(0, 1).contiguous() for k in ("gt", "ubs", "agent", "d_u2u")}

@@ -191,6 +191,10 @@ int uavgnn_talk_degrees(const float* d_u2u, int n, int B, float r_comm, int32_t*
                         uavgnn_stream_t stream);
 int uavgnn_talk_compact(const float* d_u2u, int n, int B, float r_comm, const int32_t* talk_off,
                         const int32_t* env_base, int32_t* talk_src, int32_t* talk_eid, uavgnn_stream_t stream);
+/* The prefix sums between the two passes, up to four arrays in one launch: o_k[0] = 0, o_k[i + 1] = d_k[0] + ... + d_k[i]
+ * (o_k has n_k + 1 entries; o_k == NULL skips the array).  Replaces torch.cumsum + fills in the device builder. */
+int uavgnn_offsets_scan4(const int32_t* d0, int n0, int32_t* o0, const int32_t* d1, int n1, int32_t* o1, const int32_t* d2,
+                         int n2, int32_t* o2, const int32_t* d3, int n3, int32_t* o3, uavgnn_stream_t stream);
 
 /* ---- rollout: epsilon-greedy selection --------------------------------------------------------------------------
  * acts[a] = u_team[a / n_agents] <= eps ? min(floor(u_agent[a] * A), A - 1) : argmax_j q[a, j]   (first maximum).

@@ -173,3 +173,26 @@ def test_qmix_learner_fixture_is_consistent_with_the_oracle_on_cpu():
         assert_close(loss, th.as_tensor(z["loss"]).double(), 1e-5, "QMIX LossQ (oracle agent)")
     finally:
         LM.agent_REGISTRY = saved
+
+
+def test_stage_obs_then_push_equals_one_push():
+    """stage_obs (observation half, before the simulator is stepped in place) + push (act / rew / done / next_*) leave the
+    same memory as one push of the whole transition."""
+    rng = np.random.default_rng(1)
+    E, n, M, H, T = 2, 3, 5, 4, 3
+    mk = lambda: SequenceReplay(capacity=4, max_seq_len=T, n_agents=n, n_gts=M, hidden_size=H, n_envs=E, state_dim=3,  # noqa: E731
+                                r_comm=0.5, device="cpu")
+    a, b = mk(), mk()
+    trs = [_transition(rng, E, n, M, H, t) for t in range(2 * T + 1)]
+    obs_keys = ("gt", "ubs", "agent", "d_u2u", "h", "state")
+    for t in range(2 * T):
+        nxt = {"next_" + k: trs[t + 1][k] for k in obs_keys}
+        a.push(dict(trs[t], **nxt))
+        buf = {k: trs[t][k].clone() for k in obs_keys}              # the simulator's own buffers ...
+        b.stage_obs(buf)
+        for k in obs_keys:
+            buf[k].fill_(-7.0)                                       # ... overwritten by the step before push() is called
+        b.push(dict({k: trs[t][k] for k in ("act", "rew", "done")}, **nxt))
+    assert len(a) == len(b) == 4 and a.head == b.head
+    for k in a.mem:
+        assert th.equal(a.mem[k], b.mem[k]), k

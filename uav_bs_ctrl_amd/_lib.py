@@ -59,6 +59,7 @@ SIGNATURES = {
     "uavgnn_obs_compact": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip, _c_fp, _c_fp,
                                     _c_st]),
     "uavgnn_talk_degrees": (_c_int, [_c_fp, _c_int, _c_int, _c_f32, _c_ip, _c_ip, _c_st]),
+    "uavgnn_offsets_scan4": (_c_int, [_c_ip, _c_int, _c_ip, _c_ip, _c_int, _c_ip, _c_ip, _c_int, _c_ip, _c_ip, _c_int, _c_ip, _c_st]),
     "uavgnn_talk_compact": (_c_int, [_c_fp, _c_int, _c_int, _c_f32, _c_ip, _c_ip, _c_ip, _c_ip, _c_st]),
     "uavgnn_build_graph_small_max_agents": (_c_int, []),
     "uavgnn_build_graph_small": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_f32, _c_ip, _c_ip,

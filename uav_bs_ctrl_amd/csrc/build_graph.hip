@@ -494,6 +494,62 @@ inline int order_blocks(int N) {
   return b < 1 ? 1 : (b > kOrderMaxBlocks ? kOrderMaxBlocks : b);
 }
 
+
+// ---- the "prefix sum (caller)" of the builder: up to four exclusive scans in ONE launch ------------------------------------
+// out_k[0] = 0, out_k[i + 1] = in_k[0] + ... + in_k[i]: seen / near / talk offsets over the N agents and the per-environment
+// edge bases over the B environments.  One 1024-thread workgroup per array walks it in rounds of 8192 elements (thread ->
+// 8 consecutive elements, wave shuffles + a 16-entry LDS scan, running carry): 32 768 agents take four rounds.  Replaces four
+// torch.cumsum calls + zero fills + slice copies (14 launches) per graph: the device builder of a large batch is launch-bound.
+struct ScanArgs {
+  const int32_t* in[4];
+  int32_t* out[4];
+  int n[4];
+};
+
+__global__ __launch_bounds__(1024) void offsets_scan4_kernel(ScanArgs a) {
+  constexpr int IT = 8;
+  const int32_t* __restrict__ in = a.in[blockIdx.x];
+  int32_t* __restrict__ out = a.out[blockIdx.x];
+  const int n = a.n[blockIdx.x];
+  if (out == nullptr) return;
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) out[0] = 0;
+  int carry = 0;
+  for (int base = 0; base < n; base += 1024 * IT) {
+    const int i0 = base + tid * IT;
+    int v[IT], s = 0;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      v[k] = (i0 + k < n) ? in[i0 + k] : 0;
+      s += v[k];
+    }
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wprefix = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int t = wsum[w];
+      if (w < wave) wprefix += t;
+      total += t;
+    }
+    int run = carry + wprefix + incl - s;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      run += v[k];
+      if (i0 + k < n) out[i0 + k + 1] = run;
+    }
+    carry += total;
+    __syncthreads();
+  }
+}
+
 }  // namespace
 }  // namespace uavgnn
 
@@ -616,5 +672,25 @@ extern "C" int uavgnn_build_graph_small(const float* gt, int M, int Fg, const fl
   if (Fg != 4 || Fu != 2 || n > kWave || static_cast<long long>(B) * n > kSmallMaxAgents) return UAVGNN_EUNSUPPORTED;
   hipLaunchKernelGGL(build_graph_small_kernel, dim3(1), dim3(kSmallThreads), 0, static_cast<hipStream_t>(stream), gt, M, ubs,
                      U, d_u2u, n, B, r_comm, seen_off, near_off, talk_off, x_gt, x_ubs, talk_src, talk_eid, graph_off);
+  return launch_status();
+}
+
+extern "C" int uavgnn_offsets_scan4(const int32_t* d0, int n0, int32_t* o0, const int32_t* d1, int n1, int32_t* o1,
+                                    const int32_t* d2, int n2, int32_t* o2, const int32_t* d3, int n3, int32_t* o3,
+                                    uavgnn_stream_t stream) {
+  ScanArgs a;
+  const int32_t* in[4] = {d0, d1, d2, d3};
+  int32_t* out[4] = {o0, o1, o2, o3};
+  const int n[4] = {n0, n1, n2, n3};
+  int used = 0;
+  for (int k = 0; k < 4; ++k) {
+    if (n[k] < 0 || (out[k] != nullptr && n[k] > 0 && in[k] == nullptr)) return UAVGNN_EINVAL;
+    a.in[k] = in[k];
+    a.out[k] = out[k];
+    a.n[k] = n[k];
+    if (out[k] != nullptr) used = k + 1;
+  }
+  if (used == 0) return 0;
+  hipLaunchKernelGGL(offsets_scan4_kernel, dim3(used), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
   return launch_status();
 }

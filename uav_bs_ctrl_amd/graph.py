@@ -513,6 +513,23 @@ def _small_max_agents() -> int:
     return _SMALL_MAX
 
 
+_GRAPH_OFF_CACHE = {}
+_SCAN4_MAX_ROWS = 1 << 17   # one-launch scans (uavgnn_offsets_scan4) up to here: 16 rounds of 8192 per array
+
+
+def _uniform_graph_off(N, n, dev):
+    """[0, n, 2n, ..., N] for a batch of equal-size graphs; read-only, shared between batches of the same shape."""
+    if th.cuda.is_current_stream_capturing():     # a tensor born inside a capture belongs to the graph's pool: never cached
+        return th.arange(0, N + 1, n, dtype=th.int32, device=dev)
+    key = (N, n, str(dev))
+    t = _GRAPH_OFF_CACHE.get(key)
+    if t is None:
+        if len(_GRAPH_OFF_CACHE) > 64:
+            _GRAPH_OFF_CACHE.clear()
+        t = _GRAPH_OFF_CACHE[key] = th.arange(0, N + 1, n, dtype=th.int32, device=dev)
+    return t
+
+
 def from_padded_obs(gt: th.Tensor, ubs: th.Tensor, agent: th.Tensor, d_u2u: Optional[th.Tensor] = None,
                     r_comm: float = float("inf"), static: bool = False) -> HeteroBatch:
     """Device-side builder for B environments at once: padded observation tensors
@@ -555,17 +572,25 @@ def from_padded_obs(gt: th.Tensor, ubs: th.Tensor, agent: th.Tensor, d_u2u: Opti
     deg_s, deg_n = th.empty(N, **i32), th.empty(N, **i32)
     L.check(L.lib().uavgnn_obs_degrees(gt.data_ptr(), M, Sg - 1, ubs.data_ptr(), U, Su - 1, N, deg_s.data_ptr(),
                                        deg_n.data_ptr(), L.stream()), "uavgnn_obs_degrees")
-    seen_off, near_off = th.zeros(N + 1, **i32), th.zeros(N + 1, **i32)
-    seen_off[1:] = th.cumsum(deg_s, 0)
-    near_off[1:] = th.cumsum(deg_n, 0)
+    seen_off, near_off = th.empty(N + 1, **i32), th.empty(N + 1, **i32)
+    deg_t = env_e = talk_off = env_base = None
     if with_comm:
         d_u2u = L.f32c(d_u2u)
         deg_t, env_e = th.empty(N, **i32), th.empty(B, **i32)
         L.check(L.lib().uavgnn_talk_degrees(d_u2u.data_ptr(), n, B, float(min(r_comm, 3.0e38)), deg_t.data_ptr(),
                                             env_e.data_ptr(), L.stream()), "uavgnn_talk_degrees")
-        talk_off, env_base = th.zeros(N + 1, **i32), th.zeros(B + 1, **i32)
-        talk_off[1:] = th.cumsum(deg_t, 0)
-        env_base[1:] = th.cumsum(env_e, 0)
+        talk_off, env_base = th.empty(N + 1, **i32), th.empty(B + 1, **i32)
+    if N <= _SCAN4_MAX_ROWS:
+        # all exclusive scans in one launch (seen / near / talk offsets over the agents, edge bases over the environments)
+        L.check(L.lib().uavgnn_offsets_scan4(deg_s.data_ptr(), N, seen_off.data_ptr(), deg_n.data_ptr(), N, near_off.data_ptr(),
+                                             L.ptr(deg_t), N if with_comm else 0, L.ptr(talk_off), L.ptr(env_e),
+                                             B if with_comm else 0, L.ptr(env_base), L.stream()), "uavgnn_offsets_scan4")
+    else:   # the time-batched builds ((T + 1) B n rows): one workgroup per array would walk them serially - multi-block scans
+        for off, deg in ((seen_off, deg_s), (near_off, deg_n), (talk_off, deg_t), (env_base, env_e)):
+            if off is not None:
+                off[0] = 0
+                th.cumsum(deg, 0, out=off[1:])
+    if with_comm:
         if not static:
             totals = th.stack((seen_off[-1], near_off[-1], talk_off[-1])).tolist()   # the one host sync: output sizes
     elif not static:
@@ -579,7 +604,7 @@ def from_padded_obs(gt: th.Tensor, ubs: th.Tensor, agent: th.Tensor, d_u2u: Opti
                                        near_off.data_ptr(), x_gt.data_ptr(), x_ubs.data_ptr(), L.stream()),
             "uavgnn_obs_compact")
     kw = dict(x_a=agent.view(N, -1), x_gt=x_gt, seen_off=seen_off, x_ubs=x_ubs, near_off=near_off,
-              graph_off=th.arange(0, N + 1, n, **i32),
+              graph_off=_uniform_graph_off(N, n, dev),
               hints={"max_graph_agents": n, "max_deg:seen": M, "max_deg:near": U})
     if with_comm:
         talk_src, talk_eid = th.empty(Et, **i32), th.empty(Et, **i32)

@@ -69,6 +69,15 @@ class SequenceReplay:
             self.size = min(self.size + E, self.capacity)
             self.ptr = 0
 
+    def stage_obs(self, tr: Dict[str, th.Tensor]) -> None:
+        """The observation half of the current transition (gt/ubs/agent/d_u2u/h/state BEFORE the action), written at the
+        current step WITHOUT advancing: a simulator that overwrites its observation buffers in place can be stepped before
+        ``push`` receives act / rew / done / next_* - no clone of the observation in between."""
+        t = self.ptr
+        for k in ("gt", "ubs", "agent", "d_u2u", "h", "state"):
+            if k in tr:
+                self.cur[k][:, t] = tr[k]
+
     def sample_indices(self, batch_size: int, generator: Optional[th.Generator] = None) -> th.Tensor:
         """Without replacement, like ``random.sample`` (buffer.py:37-39)."""
         assert self.size >= batch_size, "Insufficient samples for update."
