@@ -105,6 +105,7 @@ __global__ __launch_bounds__(kWave) void env_step_kernel(
   if (lane < n) CNT[lane] = 0;
   __syncthreads();
   const float* __restrict__ pg = pos_gts + static_cast<size_t>(b) * M * 2;
+  const double k_los = pow(10.0, c.eta_los / 20.0), k_nlos = pow(10.0, c.eta_nlos / 20.0);   // loop-invariant excess-loss factors
   // ---- step 1: distances (:135-141), float64 norm of (float32 GT position - float64 UBS position), stored float32 ----
   for (int k = lane; k < n * M; k += kWave) {
     const int i = k / M, m = k - i * M;
@@ -118,8 +119,7 @@ __global__ __launch_bounds__(kWave) void env_step_kernel(
     const double dd = sqrt(static_cast<double>(d * d) + c.h_ubs * c.h_ubs);
     const double q = 4.0 * 3.141592653589793 * c.fc * dd / 3e8;
     const double fspl = q * q;
-    const double pl = static_cast<double>(p_los) * fspl * pow(10.0, c.eta_los / 20.0) +
-                      static_cast<double>(1.f - p_los) * fspl * pow(10.0, c.eta_nlos / 20.0);
+    const double pl = static_cast<double>(p_los) * fspl * k_los + static_cast<double>(1.f - p_los) * fspl * k_nlos;
     const double ptxg = c.p_tx * (1.0 / pl);
     G[k] = ptxg;
     W[k] = d <= static_cast<float>(c.r_cov) ? static_cast<float>(ptxg) : 0.f;     // p_itf rows are float32 (:169,:187)
