@@ -112,14 +112,6 @@ int uavgnn_gatv2_bwd_generic(const float* x_src, int E, int F_src, const float* 
                      int nh, int D, float slope, const float* out, const float* d_out, int ld_out,
                      const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d, float* dattn,
                      float* dW_r, float* db_r, void* workspace, size_t workspace_bytes, uavgnn_stream_t stream);
-/* A/B: the same contract for F_src = 4, nh = 4, D = 64 with the per-(edge, channel) part of the backward on the matrix cores
- * (z^T tiles on fp32 MFMA, sign sums as a bf16 MFMA of +-1 signs against exactly split de x terms; csrc/gatv2.hip). Other
- * head layouts: UAVGNN_EUNSUPPORTED.  Measured slower than the VALU kernel at C3 (264 vs 230 us): not used by the library. */
-int uavgnn_gatv2_bwd_mfma(const float* x_src, int E, int F_src, const float* x_dst, int F_dst, const int32_t* seg_off,
-                     const int32_t* dst_order, int N, const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn,
-                     int nh, int D, float slope, const float* out, const float* d_out, int ld_out,
-                     const float* attn_save, float* dW_s, float* db_s, float* dW_d, float* db_d, float* dattn,
-                     float* dW_r, float* db_r, void* workspace, size_t workspace_bytes, uavgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * K3b  Targeted attention over the talk relation, forward.
@@ -264,10 +256,11 @@ int uavgnn_csc_transpose_env(const int32_t* talk_off, const int32_t* talk_src, c
  * algos/madrqn/learner.py:157-166): g[i] clamped to [-clip, clip] for i < n_clip (clip_grad_value_ on the policy network
  * only; clip <= 0: none; the clamped gradient is written back), torch.optim.AdamW step on (p, exp_avg, exp_avg_sq) with
  * decoupled weight decay, then p_targ <- polyak p_targ + (1 - polyak) p (p_targ may be NULL).  hyper: DEVICE array
- * {lr, t} (t = 1-based count of this step) so that a captured graph replays with current values.  16-byte aligned
+ * {lr, t} (t = 1-based count of this step) so that a captured graph replays with current values.  The betas are
+ * doubles and the bias corrections are formed in double, as torch.optim.AdamW does on the host.  16-byte aligned
  * buffers. */
 int uavgnn_adamw_polyak(float* p, float* g, float* exp_avg, float* exp_avg_sq, float* p_targ, long long n,
-                        long long n_clip, const float* hyper, float beta1, float beta2, float eps, float weight_decay,
+                        long long n_clip, const float* hyper, double beta1, double beta2, float eps, float weight_decay,
                         float clip, float polyak, uavgnn_stream_t stream);
 
 /* Batched simulator step of the multi-UBS coverage environment, B independent environments per launch (reference:

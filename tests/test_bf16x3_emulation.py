@@ -64,13 +64,3 @@ def test_six_products_reproduce_an_fp32_dot_product():
     assert err.mean() < 3.0 * plain.mean() + 1e-9                    # no worse than an fp32 pipeline in any meaningful sense
     dropped = sum(np.abs(sa[i].astype(np.float64) * sb[j].astype(np.float64)) for i, j in [(1, 2), (2, 1), (2, 2)])
     assert np.all(dropped <= 2.0 ** -23 * np.abs(a.astype(np.float64) * b.astype(np.float64)) + 1e-300)
-
-
-def test_sign_times_term_products_need_no_further_split():
-    """The A/B K1 backward (uavgnn_gatv2_bwd_mfma): +-1 signs against three bf16 terms - every product is a term itself."""
-    rng = np.random.default_rng(3)
-    q = rng.standard_normal(10000).astype(np.float32)
-    s = np.where(rng.random(10000) < 0.5, np.float32(-1), np.float32(1))
-    t = split3(q)
-    total = sum((s * ti).astype(np.float32).astype(np.float64) for ti in t)
-    assert np.array_equal(total, (s * q).astype(np.float64))

@@ -3,6 +3,7 @@ import math
 import types
 
 import numpy as np
+import pytest
 import torch as th
 
 from oracle.closed_form import closed_form_tensor
@@ -77,14 +78,26 @@ def test_sequence_replay_reproduces_the_reference_replay_buffer():
     """Row f2 against the reference's own ReplayBuffer (buffer.py:7-42) as filled by its learner.cache
     (learner.py:82-92) in a rollout crossing an episode end (tests/golden/replay_buffer.npz, make_golden.py `replay`):
     the same pushed transitions must leave the same sequences - cut every T pushes whatever the episode does, T+1
-    observations / hidden states / states per sequence, next_h zeroed at the episode end, reference graphs per step."""
+    observations / hidden states / states per sequence, next_h zeroed at the episode end, reference graphs per step.
+    Host ring + host graph builder here; the `-m gpu` twin below runs the device ring + the HIP builder."""
+    _check_replay_against_reference_buffer("cpu")
+
+
+@pytest.mark.gpu
+def test_sequence_replay_on_the_device_reproduces_the_reference_replay_buffer():
+    """Row f2 on the GPU: ring in HBM -> index gather -> HIP graph builder (csrc/build_graph.hip), bit-exact against
+    what the reference's ReplayBuffer + env wrapper produced from the same pushes."""
+    _check_replay_against_reference_buffer("cuda")
+
+
+def _check_replay_against_reference_buffer(device):
     import ast
     z = np.load(f"{GOLDEN}/replay_buffer.npz")
     meta = ast.literal_eval(str(z["meta"]))
     T, H, n, M = meta["T"], meta["H"], meta["n_agents"], meta["n_gts"]
     rb = SequenceReplay(capacity=10, max_seq_len=T, n_agents=n, n_gts=M, hidden_size=H, n_envs=1,
-                        state_dim=meta["state_dim"], r_comm=float(z["r_comm"]), rew_dim=n, device="cpu")
-    f = lambda k: th.as_tensor(z[k])  # noqa: E731
+                        state_dim=meta["state_dim"], r_comm=float(z["r_comm"]), rew_dim=n, device=device)
+    f = lambda k: th.as_tensor(z[k]).to(device)  # noqa: E731
     for i in range(meta["n_pushes"]):
         tr = {}
         for k in ("gt", "ubs", "agent", "d_u2u", "h", "state"):
@@ -96,31 +109,33 @@ def test_sequence_replay_reproduces_the_reference_replay_buffer():
         tr["done"] = f(f"push{i}:done").reshape(1, 1)
         rb.push(tr)
     assert len(rb) == meta["n_seqs"] == 4 and rb.ptr == meta["n_pushes"] - 4 * T
-    b = rb.gather(th.arange(4))
+    b = rb.gather(th.arange(4, device=device))
+    if device == "cuda":
+        assert all(g.agent_feat().is_cuda for g in b["obs"])
     for si in range(4):
         for t in range(T + 1):
             g = b["obs"][t]
             lo, hi = si * n, (si + 1) * n
             ref = {k.split(":")[-1]: z[k] for k in z.files if k.startswith(f"seq{si}:obs{t}:")}
-            assert np.array_equal(g.agent_feat()[lo:hi].numpy(), ref["x_a"].astype(np.float32))
+            assert np.array_equal(g.agent_feat()[lo:hi].cpu().numpy(), ref["x_a"].astype(np.float32))
             for et, kx, ko in (("seen", "x_gt", "seen_off"), ("near", "x_ubs", "near_off")):
                 x, off = g.relation_segments(et)
                 e0, e1 = int(off[lo]), int(off[hi])
-                assert np.array_equal((off[lo:hi + 1] - off[lo]).numpy(), ref[ko]), (si, t, et)
-                assert np.array_equal(x[e0:e1].numpy(), ref[kx].astype(np.float32)), (si, t, et)
+                assert np.array_equal((off[lo:hi + 1] - off[lo]).cpu().numpy(), ref[ko]), (si, t, et)
+                assert np.array_equal(x[e0:e1].cpu().numpy(), ref[kx].astype(np.float32)), (si, t, et)
             off, src = g.talk_csc()
             e0, e1 = int(off[lo]), int(off[hi])
-            assert np.array_equal((off[lo:hi + 1] - off[lo]).numpy(), ref["talk_off"])
-            assert np.array_equal((src[e0:e1] - lo).numpy(), ref["talk_src"])
+            assert np.array_equal((off[lo:hi + 1] - off[lo]).cpu().numpy(), ref["talk_off"])
+            assert np.array_equal((src[e0:e1] - lo).cpu().numpy(), ref["talk_src"])
         h_ref, T1 = z[f"seq{si}:h"], T + 1
-        assert np.array_equal(rb.mem["h"][si].numpy(), h_ref.astype(np.float32)) and h_ref.shape[0] == T1
-        assert np.array_equal(rb.mem["state"][si].numpy(), z[f"seq{si}:state"])
-        assert np.array_equal(b["acts"][:, si * n:(si + 1) * n].numpy(), z[f"seq{si}:act"])
-        assert np.array_equal(b["rews"][:, si].numpy(), z[f"seq{si}:rew"].reshape(T, n))
-        assert np.array_equal(b["dones"][:, si].numpy(), z[f"seq{si}:done"].reshape(T, 1))
+        assert np.array_equal(rb.mem["h"][si].cpu().numpy(), h_ref.astype(np.float32)) and h_ref.shape[0] == T1
+        assert np.array_equal(rb.mem["state"][si].cpu().numpy(), z[f"seq{si}:state"])
+        assert np.array_equal(b["acts"][:, si * n:(si + 1) * n].cpu().numpy(), z[f"seq{si}:act"])
+        assert np.array_equal(b["rews"][:, si].cpu().numpy(), z[f"seq{si}:rew"].reshape(T, n))
+        assert np.array_equal(b["dones"][:, si].cpu().numpy(), z[f"seq{si}:done"].reshape(T, 1))
     # h0 / h1 = the stored hidden states of the first two steps of every sequence (learner.py:113)
-    assert np.array_equal(b["h0"].numpy().reshape(4, n, H), np.stack([z[f"seq{s}:h"][0] for s in range(4)]).astype(np.float32))
-    assert np.array_equal(b["h1"].numpy().reshape(4, n, H), np.stack([z[f"seq{s}:h"][1] for s in range(4)]).astype(np.float32))
+    assert np.array_equal(b["h0"].cpu().numpy().reshape(4, n, H), np.stack([z[f"seq{s}:h"][0] for s in range(4)]).astype(np.float32))
+    assert np.array_equal(b["h1"].cpu().numpy().reshape(4, n, H), np.stack([z[f"seq{s}:h"][1] for s in range(4)]).astype(np.float32))
     # the episode ended inside sequence 3 (push 10 of 14): the hidden state after it is zero, the observation a reset
     assert float(np.abs(z["seq3:h"][1]).max()) == 0.0 and float(np.abs(z["seq3:h"][0]).max()) > 0.0
 

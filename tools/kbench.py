@@ -116,18 +116,6 @@ def main():
                 print(f"bwd {dist:5s} {et:4s} F={FS} generic kernel  {ms:8.4f} {by / ms / 1e6:9.1f} "
                       f"{by / ms / 1e6 / 80:6.2f} {2 * flops / ms / 1e9:8.2f} {2 * flops / ms / 1e9 / 1.573:6.2f}")
 
-            if FS == 4:    # A/B: the matrix-core backward (z^T on fp32 MFMA, sign sums as a bf16 MFMA)
-                def bwd_mfma():
-                    rc = lib.uavgnn_gatv2_bwd_mfma(x_src.data_ptr(), x_src.shape[0], FS, x_a.data_ptr(), 2, off.data_ptr(), ORDER, N,
-                                                   *[t.data_ptr() for t in p[:5]], 4, 64, 0.2, out.data_ptr(), d_out.data_ptr(),
-                                                   a.ld, a_save.data_ptr(), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
-                                                   g[3].data_ptr(), g[4].data_ptr(), g[5].data_ptr(), g[6].data_ptr(),
-                                                   ws.data_ptr(), wsb, st)
-                    assert rc == 0, rc
-                ms = time_ms(bwd_mfma, a.reps)
-                print(f"bwd {dist:5s} {et:4s} F={FS} matrix-core A/B {ms:8.4f} {by / ms / 1e6:9.1f} "
-                      f"{by / ms / 1e6 / 80:6.2f} {2 * flops / ms / 1e9:8.2f} {2 * flops / ms / 1e9 / 1.573:6.2f}")
-
 
 if __name__ == "__main__":
     main()

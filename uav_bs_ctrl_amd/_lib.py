@@ -43,9 +43,6 @@ SIGNATURES = {
     "uavgnn_gatv2_bwd_generic": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                   _c_int, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                   _c_fp, _c_fp, _c_fp, ctypes.c_void_p, ctypes.c_size_t, _c_st]),
-    "uavgnn_gatv2_bwd_mfma": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
-                                  _c_int, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
-                                  _c_fp, _c_fp, _c_fp, ctypes.c_void_p, ctypes.c_size_t, _c_st]),
     "uavgnn_talk_attn_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip,
                                       _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_int, _c_st]),
     "uavgnn_talk_attn_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip,
@@ -82,8 +79,8 @@ SIGNATURES = {
     "uavgnn_colsum_acc": (_c_int, [_c_fp, ctypes.c_longlong, _c_int, _c_int, _c_fp, _c_int, _c_st]),
     "uavgnn_env_state_dim": (_c_int, [_c_int, _c_int, _c_int]),
     "uavgnn_env_step": (_c_int, [ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double), _c_int] + [_c_fp] * 22 + [_c_st]),
-    "uavgnn_adamw_polyak": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, ctypes.c_longlong, _c_fp, _c_f32,
-                                     _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _c_st]),
+    "uavgnn_adamw_polyak": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, ctypes.c_longlong, _c_fp, ctypes.c_double,
+                                     ctypes.c_double, _c_f32, _c_f32, _c_f32, _c_f32, _c_st]),
     "uavgnn_gru_cell_supported": (_c_int, [_c_int, _c_int]),
     "uavgnn_gru_cell_fwd": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_st]),
     "uavgnn_gru_cell_x3_supported": (_c_int, [_c_int, _c_int]),

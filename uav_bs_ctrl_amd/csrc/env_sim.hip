@@ -64,13 +64,15 @@ __global__ __launch_bounds__(kWave) void env_step_kernel(
   // ---- LDS carve-up ------------------------------------------------------------------------------------------------
   float* DUG = reinterpret_cast<float*>(smem);            // [n][M] UBS-GT distances (float32, as the reference stores them)
   float* W = DUG + n * M;                                  // [n][M] float32(p_tx g [d <= r_cov]): interference weights
+  // the float64 arrays come first among the odd-sized ones: G starts at byte 8 n M, PU right behind it - both 8-byte
+  // aligned for every (n, M), odd M included (behind the three [M] float arrays PU would sit at 4 mod 8)
   double* G = reinterpret_cast<double*>(W + n * M);        // [n][M] p_tx * g (float64 numerator of the SINR)
-  float* AVG = reinterpret_cast<float*>(G + n * M);        // [M]
+  double* PU = G + n * M;                                  // [n][2]
+  float* AVG = reinterpret_cast<float*>(PU + 2 * n);       // [M]
   float* RATE = AVG + M;                                   // [M]
   float* SCR = RATE + M;                                   // [M] scratch (clipped averages, squares)
   float* ITF = SCR + M;                                    // [16]
-  double* PU = reinterpret_cast<double*>(ITF + 16);        // [n][2]
-  int* PR = reinterpret_cast<int*>(PU + 2 * n);            // [M] priorities in use
+  int* PR = reinterpret_cast<int*>(ITF + 16);              // [M] priorities in use
   int* GU = PR + M;                                        // [M] serving UBS per GT (-1)
   int* GR = GU + M;                                        // [M] RB per GT (-1)
   int* ASG = GR + M;                                       // [n][R] GT on RB c of UBS i (-1 = idle)

@@ -811,385 +811,6 @@ __global__ __launch_bounds__(kThreads) void gatv2_bwd_pair_kernel(
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// K1 backward of the `seen` relation (F_src = 4, nh = 4, D = 64) with the per-(edge, channel) part on the matrix cores.
-// Same decomposition as gatv2_bwd_kernel (one destination per wavefront, input-space sums, lrelu' = c_lin + c_abs sgn z):
-// what is left per (edge u, channel n) there is  s_un = sgn(z_un) de_uk  and the sums  S1[n] = sum_u s_un,
-// S2[n,:] = sum_u s_un x_u  - 5.5 packed VALU operations per (edge, channel), the whole cost of the kernel.  Here
-//   * z^T = X W_s^T + c runs on v_mfma_f32_16x16x4_f32 with the EDGES as rows (A = x of 16 edges, B = W_s of 16 channels,
-//     C = c[v, channel]): lane (g, j) receives z of channel j for edges 4g..4g+3 of both 16-edge halves of a 32-edge chunk;
-//   * those 8 signs, packed as bf16 +-1, ARE the A operand of a v_mfma_f32_16x16x32_bf16 (row = channel j, K slots
-//     8g..8g+7 <-> edges {4g+r, 16+4g+r}) whose B operand holds, per head k and K slot, the quantities
-//     q = de_uk * {x_u0..3, 1, x_v0, x_v1} split EXACTLY into three bf16 terms (bf16x3.h): sign x term products are exact, the
-//     accumulator is fp32.  Columns: MFMA a = terms 1, 2 of the 7 quantities, MFMA b = term 3.  With the x_v columns every
-//     S-dependent gradient term is LINEAR in sums over all (v, u) of a wavefront - c[v,n] S1_v[n] = W_d[n,:] . (x_v S1_v[n]) +
-//     (b_s + b_d)[n] S1_v[n] - so the 2 x 16 accumulator tiles persist over all destinations and are folded into the
-//     per-channel gradient rows ONCE per wavefront;
-//   * P[k,:] and Sb[k,:] come out of the B-operand preparation (16-lane DPP sums), everything else per destination (ReLU
-//     mask, G, T, de, the g Sb / c_lin P terms) is the generic kernel's code.
-// Per 32 edges x 256 channels: 32 fp32 MFMAs + 32 bf16 MFMAs + ~130 VALU for the sign packing + ~110 for the B operand,
-// against ~1760 packed VALU operations in the generic kernel.  Same partial-row layout and fixed-order reduction
-// (deterministic).  sgn(+0) = +1 here, -1 there: differs only where z is exactly zero.
-typedef float bw_f32x4 __attribute__((ext_vector_type(4)));
-typedef float bw_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bw_bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bw_bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned bw_u32x4 __attribute__((ext_vector_type(4)));
-
-struct BwSplit3 { unsigned h1, h2, h3; };
-__device__ __forceinline__ BwSplit3 bw_split_pair(float x, float y) {   // (x, y) -> three packed bf16 pairs, x = x1 + x2 + x3 exactly
-  BwSplit3 s;
-  bw_bf16x2 p = __builtin_convertvector(bw_f32x2{x, y}, bw_bf16x2);
-  s.h1 = __builtin_bit_cast(unsigned, p);
-  x -= __uint_as_float(s.h1 << 16);
-  y -= __uint_as_float(s.h1 & 0xffff0000u);
-  p = __builtin_convertvector(bw_f32x2{x, y}, bw_bf16x2);
-  s.h2 = __builtin_bit_cast(unsigned, p);
-  x -= __uint_as_float(s.h2 << 16);
-  y -= __uint_as_float(s.h2 & 0xffff0000u);
-  p = __builtin_convertvector(bw_f32x2{x, y}, bw_bf16x2);
-  s.h3 = __builtin_bit_cast(unsigned, p);
-  return s;
-}
-// (sgn a, sgn b) as packed bf16 +-1: low half <- a
-__device__ __forceinline__ unsigned bw_sign_pair(float a, float b, unsigned one) {   // one = 0x3f803f80 held in a VGPR
-  const unsigned hi = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);   // {b[31:16], a[31:16]}
-  return (hi & 0x80008000u) | (one & ~0x80008000u);                                                  // one v_bfi_b32
-}
-
-__global__ __launch_bounds__(kThreads, 2) void gatv2_bwd_seen_mfma_kernel(
-    const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off,
-    const int32_t* __restrict__ dst_order, int N,
-    const float* __restrict__ W_s, const float* __restrict__ b_s, const float* __restrict__ W_d,
-    const float* __restrict__ b_d, const float* __restrict__ attn, float slope, const float* __restrict__ out,
-    const float* __restrict__ d_out, int ld_out, const float* __restrict__ a_save, float* __restrict__ partial) {
-  constexpr int FS = 4, NH = 4, D = 64, H = NH * D, J = 4, KF = NH * FS, PARTS = kWave / KF, CT = H / 16;
-  constexpr int P = partial_len<FS>(H);
-  constexpr int ES = FS + 2 * NH;   // staged floats per edge: x[FS], de[NH], a[NH]
-  constexpr int NQ = 7;             // quantities per (edge, head): de x_u0..3, de, de x_v0, de x_v1
-
-  __shared__ float sW[H * FS];
-  __shared__ float sG[kWavesPerBlock][H];
-  __shared__ __attribute__((aligned(16))) float sCz[kWavesPerBlock][4 * H];   // c[v, n] four times per channel: the C operand is one 16-byte read
-  __shared__ float sGk[kWavesPerBlock][KF];
-  __shared__ float sPS[kWavesPerBlock][2 * KF];   // P[k][f] | Sb[k][f]
-  __shared__ __attribute__((aligned(16))) float sE[kWavesPerBlock][kWave * ES];
-  // B operand of the sign MFMAs: [head][mfma a / b][column 16][slot pair 16] packed bf16 pairs; 8 KB per wave
-  __shared__ __attribute__((aligned(16))) unsigned sBp[kWavesPerBlock][NH * 2 * 16 * 16];
-  float* const sRed = &sCz[0][0];   // the final fold reuses the C-operand rows (P = 12 H floats <= 16 H)
-  static_assert(P <= kWavesPerBlock * 4 * H, "partial row does not fit the aliased region");
-
-  const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int jj = lane & 15, gq = lane >> 4;     // MFMA view of the lane: column / row index jj, lane group gq
-  const float c_lin = 0.5f * (1.f + slope), c_abs = 0.5f * (1.f - slope);
-  unsigned one = 0x3f803f80u;                   // packed bf16 (1, 1); pinned in a VGPR so that the sign packing is perm + bfi
-  asm volatile("" : "+v"(one));
-
-  for (int i = tid; i < H * FS; i += kThreads) sW[i] = W_s[i];
-  for (int i = lane; i < NH * 2 * 16 * 16; i += kWave) sBp[wave][i] = 0u;   // unused columns stay zero for good
-
-  // ---- per-lane constants, channel mapping n = lane + 64 j (everything per destination) ----------------------------------
-  float Ws[J][FS], att[J], wd0[J], wd1[J], bc[J];
-  int kj[J];
-  float aWs[J][FS], abs_[J], aWd0[J], aWd1[J], abd[J], aatt[J], aWr0[J], aWr1[J], abr[J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int n = lane + kWave * j;
-    kj[j] = n / D;
-#pragma unroll
-    for (int f = 0; f < FS; ++f) {
-      Ws[j][f] = W_s[n * FS + f];
-      aWs[j][f] = 0.f;
-    }
-    att[j] = attn[n];
-    wd0[j] = W_d[n * 2 + 0];
-    wd1[j] = W_d[n * 2 + 1];
-    bc[j] = b_d[n] + b_s[n];
-    abs_[j] = aWd0[j] = aWd1[j] = abd[j] = aatt[j] = aWr0[j] = aWr1[j] = abr[j] = 0.f;
-  }
-  __syncthreads();
-  // ---- MFMA view: the persistent sign-sum accumulators (B operand of the z tiles: W_s[ct * 16 + jj][gq], read from LDS) -------
-  bw_f32x4 accA[CT], accB[CT];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct) {
-    accA[ct] = bw_f32x4{0.f, 0.f, 0.f, 0.f};
-    accB[ct] = bw_f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
-  float* __restrict__ gw = sG[wave];
-  float* __restrict__ czw = sCz[wave];
-  float* __restrict__ gk = sGk[wave];
-  float* __restrict__ ps = sPS[wave];
-  float* __restrict__ ew = sE[wave];
-  unsigned* __restrict__ bp = sBp[wave];
-
-  auto load_rows = [&](const int v, float (&o)[J], float (&gr)[J]) {
-    const float* __restrict__ orow = out + static_cast<size_t>(v) * ld_out;
-    const float* __restrict__ grow = d_out + static_cast<size_t>(v) * ld_out;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      o[j] = orow[lane + kWave * j];
-      gr[j] = grow[lane + kWave * j];
-    }
-  };
-
-  auto process = [&](const float (&o_)[J], const float (&gr_)[J], const int e0, const int deg, const float xv0,
-                     const float xv1) {
-    float g[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      g[j] = o_[j] > 0.f ? gr_[j] : 0.f;  // ReLU mask
-      aWr0[j] = fmaf(g[j], xv0, aWr0[j]);
-      aWr1[j] = fmaf(g[j], xv1, aWr1[j]);
-      abr[j] += g[j];
-    }
-    if (deg == 0) return;      // isolated destination: the aggregate (and with it b_s) does not reach the output
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      abs_[j] += g[j];
-      gw[lane + kWave * j] = g[j];
-      const float cv = fmaf(wd1[j], xv1, fmaf(wd0[j], xv0, bc[j]));          // c[v, n] for the C operand of the z tiles
-      *reinterpret_cast<float4*>(czw + 4 * (lane + kWave * j)) = make_float4(cv, cv, cv, cv);
-    }
-    wave_sync();
-    {  // G[k][f] = sum_d g[k,d] W_s[k,d,f]
-      const int kf = lane / PARTS, part = lane % PARTS;
-      const int k = kf / FS, f = kf % FS;
-      float gp = 0.f;
-      for (int d = part; d < D; d += PARTS) {
-        const int n = k * D + d;
-        gp = fmaf(gw[n], sW[n * FS + f], gp);
-      }
-#pragma unroll
-      for (int o = PARTS / 2; o > 0; o >>= 1) gp += __shfl_xor(gp, o);
-      if (part == 0) gk[kf] = gp;
-    }
-    wave_sync();
-    float T[NH];   // T[k] = sum_u a_uk (G[k].x_u)
-    {
-      float t[NH];
-#pragma unroll
-      for (int k = 0; k < NH; ++k) t[k] = 0.f;
-      for (int base = 0; base < deg; base += kWave) {
-        if (base + lane < deg) {
-          const int u = e0 + base + lane;
-          float x[FS];
-          load_row<FS>(x_src + static_cast<size_t>(u) * FS, x);
-#pragma unroll
-          for (int k = 0; k < NH; ++k) {
-            float dot = 0.f;
-#pragma unroll
-            for (int f = 0; f < FS; ++f) dot = fmaf(gk[k * FS + f], x[f], dot);
-            t[k] = fmaf(a_save[static_cast<size_t>(u) * NH + k], dot, t[k]);
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < NH; ++k) T[k] = wave_sum(t[k]);
-    }
-    float accP[FS], accSb[FS];   // lane group gq = head: P[gq][f], Sb[gq][f] (all 16 lanes of the group hold the sum)
-#pragma unroll
-    for (int f = 0; f < FS; ++f) accP[f] = accSb[f] = 0.f;
-
-    for (int base = 0; base < deg; base += kWave) {
-      {  // stage x_u, de_uk, a_uk of up to 64 edges in LDS (lane <-> edge); rows past the degree are zero
-        const bool valid = base + lane < deg;
-        const int u = e0 + base + lane;
-        float x[FS], de[NH], a[NH];
-        if (valid) {
-          load_row<FS>(x_src + static_cast<size_t>(u) * FS, x);
-#pragma unroll
-          for (int k = 0; k < NH; ++k) {
-            float dot = 0.f;
-#pragma unroll
-            for (int f = 0; f < FS; ++f) dot = fmaf(gk[k * FS + f], x[f], dot);
-            a[k] = a_save[static_cast<size_t>(u) * NH + k];
-            de[k] = a[k] * (dot - T[k]);
-          }
-        } else {
-#pragma unroll
-          for (int f = 0; f < FS; ++f) x[f] = 0.f;
-#pragma unroll
-          for (int k = 0; k < NH; ++k) de[k] = a[k] = 0.f;
-        }
-        *reinterpret_cast<float4*>(ew + lane * ES) = make_float4(x[0], x[1], x[2], x[3]);
-        *reinterpret_cast<float4*>(ew + lane * ES + FS) = make_float4(de[0], de[1], de[2], de[3]);
-        *reinterpret_cast<float4*>(ew + lane * ES + FS + NH) = make_float4(a[0], a[1], a[2], a[3]);
-      }
-      wave_sync();
-      for (int c32 = 0; c32 < kWave && base + c32 < deg; c32 += 32) {
-        // ---- B operand: lane = (slot pair sp = jj, head gq); K slot s = 8 g' + 4 eh + r <-> edge 16 eh + 4 g' + r of the chunk
-        {
-          const int s0 = 2 * jj;
-          const int er = c32 + 16 * ((s0 >> 2) & 1) + 4 * (s0 >> 3) + (s0 & 3);   // staged row of the first edge; second = er + 1
-          const float4 x0 = *reinterpret_cast<const float4*>(ew + er * ES), x1 = *reinterpret_cast<const float4*>(ew + (er + 1) * ES);
-          const float d0 = ew[er * ES + FS + gq], d1 = ew[(er + 1) * ES + FS + gq];
-          const float a0 = ew[er * ES + FS + NH + gq], a1 = ew[(er + 1) * ES + FS + NH + gq];
-          const float q0[NQ] = {d0 * x0.x, d0 * x0.y, d0 * x0.z, d0 * x0.w, d0, d0 * xv0, d0 * xv1};
-          const float q1[NQ] = {d1 * x1.x, d1 * x1.y, d1 * x1.z, d1 * x1.w, d1, d1 * xv0, d1 * xv1};
-          unsigned* __restrict__ bk = bp + gq * (2 * 16 * 16);
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const BwSplit3 sp3 = bw_split_pair(q0[q], q1[q]);
-            bk[q * 16 + jj] = sp3.h1;                   // MFMA a, column q:      term 1
-            bk[(NQ + q) * 16 + jj] = sp3.h2;            // MFMA a, column 7 + q:  term 2
-            bk[16 * 16 + q * 16 + jj] = sp3.h3;         // MFMA b, column q:      term 3
-          }
-          accP[0] += q0[0] + q1[0];                       // per-lane partial sums; one 16-lane reduction per destination
-          accP[1] += q0[1] + q1[1];
-          accP[2] += q0[2] + q1[2];
-          accP[3] += q0[3] + q1[3];
-          accSb[0] += fmaf(a0, x0.x, a1 * x1.x);
-          accSb[1] += fmaf(a0, x0.y, a1 * x1.y);
-          accSb[2] += fmaf(a0, x0.z, a1 * x1.z);
-          accSb[3] += fmaf(a0, x0.w, a1 * x1.w);
-        }
-        wave_sync();
-        // ---- z^T tiles, sign packing, sign MFMAs ----------------------------------------------------------------------
-        const float xa0 = ew[(c32 + jj) * ES + gq], xa1 = ew[(c32 + 16 + jj) * ES + gq];   // A operands: x of edge jj, feature gq
-#pragma unroll
-        for (int k = 0; k < NH; ++k) {
-          const bw_bf16x8 fba = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const bw_u32x4*>(bp + k * 512 + jj * 16 + 4 * gq));
-          const bw_bf16x8 fbb = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const bw_u32x4*>(bp + k * 512 + 256 + jj * 16 + 4 * gq));
-#pragma unroll
-          for (int c4 = 0; c4 < 4; ++c4) {
-            const int ct = 4 * k + c4;
-            const float wbv = sW[(ct * 16 + jj) * FS + gq];                            // B / C operands of the z tiles from LDS
-            const bw_f32x4 ci = *reinterpret_cast<const bw_f32x4*>(czw + 4 * (ct * 16 + jj));
-            const bw_f32x4 z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0, wbv, ci, 0, 0, 0);
-            const bw_f32x4 z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1, wbv, ci, 0, 0, 0);   // (an empty half: zero B rows)
-            const bw_u32x4 sg = bw_u32x4{bw_sign_pair(z0[0], z0[1], one), bw_sign_pair(z0[2], z0[3], one),
-                                         bw_sign_pair(z1[0], z1[1], one), bw_sign_pair(z1[2], z1[3], one)};
-            const bw_bf16x8 fa = __builtin_bit_cast(bw_bf16x8, sg);
-            accA[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fba, accA[ct], 0, 0, 0);
-            accB[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fbb, accB[ct], 0, 0, 0);
-          }
-        }
-        wave_sync();   // the next chunk overwrites the B operand
-      }
-      wave_sync();     // ... and the next 64 edges the staging rows
-    }
-#pragma unroll
-    for (int f = 0; f < FS; ++f) {
-      accP[f] = row16_allsum(accP[f]);
-      accSb[f] = row16_allsum(accSb[f]);
-    }
-    if (jj < FS) {     // lane (gq, jj < 4): P[gq][jj], Sb[gq][jj]
-      const float pv = jj == 0 ? accP[0] : jj == 1 ? accP[1] : jj == 2 ? accP[2] : accP[3];
-      const float sv = jj == 0 ? accSb[0] : jj == 1 ? accSb[1] : jj == 2 ? accSb[2] : accSb[3];
-      ps[gq * FS + jj] = pv;
-      ps[KF + gq * FS + jj] = sv;
-    }
-    wave_sync();
-    // ---- what is left per destination: the c_lin P and g Sb terms ---------------------------------------------------------
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int k = kj[j];
-      float wP = 0.f;
-#pragma unroll
-      for (int f = 0; f < FS; ++f) {
-        const float pkf = ps[k * FS + f], sbf = ps[KF + k * FS + f];
-        wP = fmaf(Ws[j][f], pkf, wP);
-        aWs[j][f] += att[j] * c_lin * pkf + g[j] * sbf;
-      }
-      aatt[j] = fmaf(c_lin, wP, aatt[j]);
-    }
-    wave_sync();
-  };
-
-  const int stride = gridDim.x * kWavesPerBlock;
-  const int it0 = blockIdx.x * kWavesPerBlock + wave;
-  if (it0 < N) {
-    float on[J], gn[J];
-    int vn = dst_order ? dst_order[it0] : it0;
-    load_rows(vn, on, gn);
-    for (int it = it0; it < N; it += stride) {
-      const int v = vn;
-      float oc[J], gc[J];
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        oc[j] = on[j];
-        gc[j] = gn[j];
-      }
-      if (it + stride < N) {   // rows of the next destination are in flight while this one computes
-        vn = dst_order ? dst_order[it + stride] : it + stride;
-        load_rows(vn, on, gn);
-      }
-      const int e0 = seg_off[v];
-      process(oc, gc, e0, seg_off[v + 1] - e0, x_dst[2 * v], x_dst[2 * v + 1]);
-    }
-  }
-
-  // ---- fold the sign sums into the per-channel rows: channel n = lane + 64 j sits in tile (lane >> 4) + 4 j, row lane & 15 ----
-  // accumulator tile: lane (g', c) register r = S[channel 16 ct + 4 g' + r][column c]; through LDS as [tile 4][row 16][col 32]
-  {
-    float* __restrict__ sq = reinterpret_cast<float*>(bp);   // 2048 floats = the wave's B-operand region
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      wave_sync();
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {
-        const int ct = 4 * j + t4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sq[(t4 * 16 + 4 * gq + r) * 32 + jj] = accA[ct][r];
-          sq[(t4 * 16 + 4 * gq + r) * 32 + 16 + jj] = accB[ct][r];
-        }
-      }
-      wave_sync();
-      const float* __restrict__ row = sq + (gq * 16 + jj) * 32;
-      float Q[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) Q[q] = (row[q] + row[NQ + q]) + row[16 + q];   // terms 1 + 2 + 3
-      float wS2 = 0.f;
-#pragma unroll
-      for (int f = 0; f < FS; ++f) {
-        wS2 = fmaf(Ws[j][f], Q[f], wS2);
-        aWs[j][f] = fmaf(att[j] * c_abs, Q[f], aWs[j][f]);
-      }
-      aatt[j] = fmaf(c_abs, wS2 + fmaf(wd0[j], Q[5], fmaf(wd1[j], Q[6], bc[j] * Q[4])), aatt[j]);
-      const float ac = att[j] * c_abs;
-      abs_[j] = fmaf(ac, Q[4], abs_[j]);
-      abd[j] = fmaf(ac, Q[4], abd[j]);
-      aWd0[j] = fmaf(ac, Q[5], aWd0[j]);
-      aWd1[j] = fmaf(ac, Q[6], aWd1[j]);
-    }
-  }
-
-  // fold the 4 waves in fixed order through LDS, then one partial row per workgroup
-  __syncthreads();   // sRed aliases the C-operand rows: every wave must be past its last destination
-  for (int w = 0; w < kWavesPerBlock; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int n = lane + kWave * j;
-        auto put = [&](int idx, float val) { sRed[idx] = (w == 0) ? val : sRed[idx] + val; };
-#pragma unroll
-        for (int f = 0; f < FS; ++f) put(n * FS + f, aWs[j][f]);
-        int o = H * FS;
-        put(o + n, abs_[j]);
-        o += H;
-        put(o + 2 * n, aWd0[j]);
-        put(o + 2 * n + 1, aWd1[j]);
-        o += 2 * H;
-        put(o + n, abd[j]);
-        o += H;
-        put(o + n, aatt[j]);
-        o += H;
-        put(o + 2 * n, aWr0[j]);
-        put(o + 2 * n + 1, aWr1[j]);
-        o += 2 * H;
-        put(o + n, abr[j]);
-      }
-    }
-    __syncthreads();
-  }
-  float* __restrict__ prow = partial + static_cast<size_t>(blockIdx.x) * P;
-  for (int i = tid; i < P; i += kThreads) prow[i] = sRed[i];
-}
-
 template <int FS, int NH, int D>
 int launch_fwd(const float* x_src, const float* x_dst, const int32_t* seg_off, const int32_t* dst_order, int N,
                const float* W_s,
@@ -1308,7 +929,7 @@ extern "C" size_t uavgnn_gatv2_bwd_workspace_bytes(int F_src, int H) {
 }
 
 // variant: 0 = generic kernel only (one destination per wavefront), 1 = automatic (pair kernel for low-degree two-feature
-// relations, else generic), 2 = matrix-core kernel for four-feature relations (A/B)
+// relations, else generic)
 static int gatv2_bwd_checked(int variant, const float* x_src, int E, int F_src, const float* x_dst, int F_dst,
                              const int32_t* seg_off, const int32_t* dst_order, int N, const float* W_s, const float* b_s,
                              const float* W_d, const float* b_d, const float* attn, int nh, int D, float slope,
@@ -1334,19 +955,6 @@ static int gatv2_bwd_checked(int variant, const float* x_src, int E, int F_src, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
   const bool sparse_hint = static_cast<long long>(E) < 16LL * N;
-  // A/B entry uavgnn_gatv2_bwd_mfma: `seen` at the headline head layout with the per-(edge, channel) part on the matrix cores
-  // (measured 264 us vs 230 us for the generic kernel at C3: not the default)
-  if (variant == 2) {
-    if (!(F_src == 4 && nh == 4 && D == 64)) return UAVGNN_EUNSUPPORTED;
-    const int grid = bwd_blocks(N);
-    hipLaunchKernelGGL(gatv2_bwd_seen_mfma_kernel, dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, dst_order, N, W_s,
-                       b_s, W_d, b_d, attn, slope, out, d_out, ld_out, attn_save, ws);
-    int rc = launch_status();
-    if (rc) return rc;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((partial_len<4>(H) + kWave - 1) / kWave), dim3(1024), 0, st, ws, grid,
-                       partial_len<4>(H), gp);
-    return launch_status();
-  }
   // low-degree two-feature relations (`near`): two destinations per wavefront (any degree is correct; pays for mean <= 8)
   if (variant == 1 && F_src == 2 && nh == 4 && D == 64 && E > 0 && static_cast<long long>(E) <= 8LL * N && (ld_out % 4) == 0 &&
       ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(W_s) |
@@ -1385,17 +993,6 @@ extern "C" int uavgnn_gatv2_bwd_generic(const float* x_src, int E, int F_src, co
                                         float* dattn, float* dW_r, float* db_r, void* workspace, size_t workspace_bytes,
                                         uavgnn_stream_t stream) {
   return gatv2_bwd_checked(0, x_src, E, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, nh, D, slope, out,
-                           d_out, ld_out, attn_save, dW_s, db_s, dW_d, db_d, dattn, dW_r, db_r, workspace, workspace_bytes,
-                           stream);
-}
-
-extern "C" int uavgnn_gatv2_bwd_mfma(const float* x_src, int E, int F_src, const float* x_dst, int F_dst,
-                                     const int32_t* seg_off, const int32_t* dst_order, int N, const float* W_s,
-                                     const float* b_s, const float* W_d, const float* b_d, const float* attn, int nh, int D,
-                                     float slope, const float* out, const float* d_out, int ld_out, const float* attn_save,
-                                     float* dW_s, float* db_s, float* dW_d, float* db_d, float* dattn, float* dW_r,
-                                     float* db_r, void* workspace, size_t workspace_bytes, uavgnn_stream_t stream) {
-  return gatv2_bwd_checked(2, x_src, E, F_src, x_dst, F_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, nh, D, slope, out,
                            d_out, ld_out, attn_save, dW_s, db_s, dW_d, db_d, dattn, dW_r, db_r, workspace, workspace_bytes,
                            stream);
 }

@@ -14,13 +14,18 @@ namespace {
 __global__ __launch_bounds__(256) void adamw_polyak_kernel(float* __restrict__ p, float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v,
                                                            float* __restrict__ p_targ, long long n, long long n_clip,
-                                                           const float* __restrict__ hyper, float beta1, float beta2,
+                                                           const float* __restrict__ hyper, double beta1_d, double beta2_d,
                                                            float eps, float weight_decay, float clip, float polyak) {
+  // The scalars are formed in DOUBLE, as torch.optim.AdamW forms them on the host (Python floats): in fp32,
+  // 1 - 0.999f^t is off by ~1.3e-5 relative for the first ~1000 steps (float32(0.999) != 0.999 and the subtraction
+  // cancels), which would scale every early step by ~6e-6 - above fp32 round-off.  Once per thread: free.
   const float lr = hyper[0], t = hyper[1];
-  const float bc1 = 1.f - powf(beta1, t);
-  const float inv_sqrt_bc2 = rsqrtf(1.f - powf(beta2, t));
-  const float step_size = lr / bc1;
-  const float decay = 1.f - lr * weight_decay;
+  const double bc1 = 1.0 - pow(beta1_d, static_cast<double>(t));
+  const float sqrt_bc2 = static_cast<float>(sqrt(1.0 - pow(beta2_d, static_cast<double>(t))));
+  const float step_size = static_cast<float>(static_cast<double>(lr) / bc1);
+  const float decay = static_cast<float>(1.0 - static_cast<double>(lr) * static_cast<double>(weight_decay));
+  const float beta2 = static_cast<float>(beta2_d);
+  const float w1 = static_cast<float>(1.0 - beta1_d), w2 = static_cast<float>(1.0 - beta2_d);
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x * 4;
   for (long long i = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {
@@ -44,9 +49,9 @@ __global__ __launch_bounds__(256) void adamw_polyak_kernel(float* __restrict__ p
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         ps[r] *= decay;
-        ms[r] = beta1 * ms[r] + (1.f - beta1) * gs[r];
-        vs[r] = beta2 * vs[r] + (1.f - beta2) * gs[r] * gs[r];
-        const float denom = sqrtf(vs[r]) * inv_sqrt_bc2 + eps;
+        ms[r] = ms[r] + w1 * (gs[r] - ms[r]);                 // exp_avg.lerp_(grad, 1 - beta1)
+        vs[r] = beta2 * vs[r] + w2 * gs[r] * gs[r];           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        const float denom = sqrtf(vs[r]) / sqrt_bc2 + eps;
         ps[r] -= step_size * (ms[r] / denom);
       }
       *reinterpret_cast<float4*>(p + i) = p4;
@@ -66,9 +71,9 @@ __global__ __launch_bounds__(256) void adamw_polyak_kernel(float* __restrict__ p
           g[q] = gq;
         }
         float pq = p[q] * decay;
-        const float mq = beta1 * m[q] + (1.f - beta1) * gq;
-        const float vq = beta2 * v[q] + (1.f - beta2) * gq * gq;
-        pq -= step_size * (mq / (sqrtf(vq) * inv_sqrt_bc2 + eps));
+        const float mq = m[q] + w1 * (gq - m[q]);
+        const float vq = beta2 * v[q] + w2 * gq * gq;
+        pq -= step_size * (mq / (sqrtf(vq) / sqrt_bc2 + eps));
         p[q] = pq; m[q] = mq; v[q] = vq;
         if (p_targ != nullptr) p_targ[q] = polyak * p_targ[q] + (1.f - polyak) * pq;
       }
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256) void adamw_polyak_kernel(float* __restrict__ p
 using namespace uavgnn;
 
 extern "C" int uavgnn_adamw_polyak(float* p, float* g, float* exp_avg, float* exp_avg_sq, float* p_targ, long long n,
-                                   long long n_clip, const float* hyper, float beta1, float beta2, float eps,
+                                   long long n_clip, const float* hyper, double beta1, double beta2, float eps,
                                    float weight_decay, float clip, float polyak, uavgnn_stream_t stream) {
   if (n < 0 || n_clip < 0 || n_clip > n || !p || !g || !exp_avg || !exp_avg_sq || !hyper) return UAVGNN_EINVAL;
   for (const float* q : {p, g, exp_avg, exp_avg_sq, p_targ})

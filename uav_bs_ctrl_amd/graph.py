@@ -428,8 +428,14 @@ def merge(graphs: Sequence[HeteroBatch]) -> HeteroBatch:
     ntypes = list(graphs[0]._num_nodes)
     num_nodes = {nt: max(g._num_nodes.get(nt, 0) for g in graphs) for nt in ntypes}
     rels = {}
+    def has_edges(g, c):
+        r = g._rels[c]
+        if r.off.is_cuda:   # no device->host sync for a structural question: the edge ARRAYS say it
+            return (r.src.numel() if r.src is not None else g._num_nodes.get(c[0], 0)) > 0
+        return r.num_edges > 0
+
     for c in graphs[0]._rels:
-        holders = [g for g in graphs if c in g._rels and g._rels[c].num_edges > 0]
+        holders = [g for g in graphs if c in g._rels and has_edges(g, c)]
         if len(holders) > 1:
             raise NotImplementedError("merge of two non-empty copies of one relation")
         if holders:
@@ -452,7 +458,7 @@ def merge(graphs: Sequence[HeteroBatch]) -> HeteroBatch:
     n_ag = num_nodes.get("agent", 0)
     dev = next((fr["feat"].device for nt, fr in feat.items() if nt == "agent" and "feat" in fr),
                graphs[0]._rels[next(iter(graphs[0]._rels))].off.device if graphs[0]._rels else None)
-    talk_holder = next((g for g in graphs if TALK in g._rels and g._rels[TALK].num_edges > 0), None)
+    talk_holder = next((g for g in graphs if TALK in g._rels and has_edges(g, TALK)), None)
     hints: Dict[str, int] = {}
     for g in graphs:
         for k, v in g.hints.items():
@@ -598,16 +604,19 @@ def from_padded_obs(gt: th.Tensor, ubs: th.Tensor, agent: th.Tensor, d_u2u: Opti
     if static:
         totals = [N * M, N * U, N * n if with_comm else 0]
     Es, En, Et = totals
-    x_gt = th.empty((Es, Sg - 1), dtype=th.float32, device=dev)
-    x_ubs = th.empty((En, Su - 1), dtype=th.float32, device=dev)
+    # static: arrays at CAPACITY, only the first E rows are written by the compaction - the rest is zero-filled (a memset is
+    # capturable) so that no op over all rows can ever pick up uninitialised pool memory
+    alloc = th.zeros if static else th.empty
+    x_gt = alloc((Es, Sg - 1), dtype=th.float32, device=dev)
+    x_ubs = alloc((En, Su - 1), dtype=th.float32, device=dev)
     L.check(L.lib().uavgnn_obs_compact(gt.data_ptr(), M, Sg - 1, ubs.data_ptr(), U, Su - 1, N, seen_off.data_ptr(),
                                        near_off.data_ptr(), x_gt.data_ptr(), x_ubs.data_ptr(), L.stream()),
             "uavgnn_obs_compact")
     kw = dict(x_a=agent.view(N, -1), x_gt=x_gt, seen_off=seen_off, x_ubs=x_ubs, near_off=near_off,
               graph_off=_uniform_graph_off(N, n, dev),
-              hints={"max_graph_agents": n, "max_deg:seen": M, "max_deg:near": U})
+              hints={"max_graph_agents": n, "max_deg:seen": M, "max_deg:near": U, **({"static": 1} if static else {})})
     if with_comm:
-        talk_src, talk_eid = th.empty(Et, **i32), th.empty(Et, **i32)
+        talk_src, talk_eid = alloc(Et, **i32), alloc(Et, **i32)
         L.check(L.lib().uavgnn_talk_compact(d_u2u.data_ptr(), n, B, float(min(r_comm, 3.0e38)), talk_off.data_ptr(),
                                             env_base.data_ptr(), talk_src.data_ptr(), talk_eid.data_ptr(), L.stream()),
                 "uavgnn_talk_compact")

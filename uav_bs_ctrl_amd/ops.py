@@ -352,12 +352,15 @@ class _GruCellFused(th.autograd.Function):
         inp, h = L.f32c(inp), L.f32c(h)
         p = [L.f32c(t.detach()) for t in (W_ih, b_ih, W_hh, b_hh)]
         h2, pre = _gru_cell_launch(inp, h, *p, save=bool(train))
+        ctx.have_pre = bool(train)
         if train:
             ctx.save_for_backward(inp, h, pre, p[0], p[2])
         return h2
 
     @staticmethod
     def backward(ctx, d_h2):
+        if not ctx.have_pre:
+            raise L.UavGnnError("gru_cell: backward through a forward that saved no pre-activations (train=False)")
         inp, h, pre, W_ih, W_hh = ctx.saved_tensors
         d_gi, d_gh, dh = _gru_gates_bwd_from_pre(pre, h, L.f32c(d_h2))
         d_inp = _mm_nn(d_gi, W_ih) if ctx.needs_input_grad[0] else None
@@ -376,7 +379,9 @@ def gru_cell(inp, h, cell):
     """nn.GRUCell(inp, h) with `cell`'s parameters: fused kernel when the shape has an instantiation, else vendor GEMMs +
     the gate kernel."""
     if gru_cell_supported(inp, h):
-        train = th.is_grad_enabled() and (inp.requires_grad or h.requires_grad or cell.weight_ih.requires_grad)
+        # ANY differentiable input makes autograd run the backward, which reads the saved [N, 4H] pre-activation sets
+        train = th.is_grad_enabled() and any(t.requires_grad for t in (inp, h, cell.weight_ih, cell.bias_ih,
+                                                                       cell.weight_hh, cell.bias_hh))
         return _GruCellFused.apply(inp, h, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, train)
     gi = linear(inp, cell.weight_ih, cell.bias_ih)
     gh = linear(h, cell.weight_hh, cell.bias_hh)
@@ -543,7 +548,11 @@ class WeightGradSink:
 
     def __init__(self):
         self.slots = {}      # (key, chunk count) -> (buffer, flush_fn)
-        self.owned = set()   # data_ptr of the d h buffers the fused step's backward handed to autograd (private)
+        # d h buffer the fused step's backward handed to autograd LAST (private), keyed by its address.  The entry holds a
+        # strong reference: while it is alive the allocator cannot hand that address to another tensor, so an incoming
+        # gradient with this data_ptr IS this storage (a bare set of addresses could match a recycled block).  At most
+        # one entry: whatever the very next step does not consume is dropped.
+        self.owned = {}
 
     @staticmethod
     def _chunks(n):
@@ -584,6 +593,7 @@ class WeightGradSink:
             if fn is not None:
                 fn(buf.sum(0))
         self.slots = {}
+        self.owned.clear()
 
 
 def _wgrad(dy, x):
@@ -685,6 +695,7 @@ class _TarmacStep(th.autograd.Function):
         q = th.addmm(b_out, h2, W_out.t())
         ctx.dims = (M, K)
         ctx.split, ctx.env, ctx.dx_out, ctx.fused_gru = split, env, dx_out, fused
+        ctx.have_pre = bool(train) or not fused
         ctx.save_for_backward(x, h, proj, inp, gi, gh, h2, a_save, Wp, W_ih, W_hh, W_out, talk_off, talk_src, t_off,
                               t_dst, t_pos)
         return q, h2
@@ -695,16 +706,19 @@ class _TarmacStep(th.autograd.Function):
          t_pos) = ctx.saved_tensors
         M, K = ctx.dims
         N, H = x.shape
+        if not ctx.have_pre:    # gi would be the [N, H] placeholder: reading 4H floats per row from it is out of bounds
+            raise L.UavGnnError("tarmac_step: backward through a forward that saved no pre-activations (train=False)")
         sink = GRAD_SINK
         dq = L.f32c(dq) if dq is not None else th.zeros((N, W_out.shape[0]), dtype=th.float32, device=x.device)
         if dh2 is None:
             dh2_tot = th.mm(dq, W_out)
-        elif sink is not None and dh2.is_contiguous() and dh2.data_ptr() in sink.owned:
+        elif (sink is not None and dh2.is_contiguous() and dh2.dtype == th.float32 and dh2.shape == (N, H)
+              and sink.owned.get(dh2.data_ptr()) is not None):
             # inside the learner's BPTT the incoming d h' is the buffer the NEXT step's backward of this very op
-            # allocated and returned (registered in sink.owned): nobody else holds it, so accumulate in place instead of
-            # copying 33 MB into a fresh output first.  Any other gradient tensor (a hook's, retain_grad's, one autograd
-            # summed from several consumers) is left untouched.
-            sink.owned.discard(dh2.data_ptr())
+            # allocated and returned (registered in sink.owned and kept alive there): nobody else holds it, so accumulate
+            # in place instead of copying 33 MB into a fresh output first.  Any other gradient tensor (a hook's,
+            # retain_grad's, one autograd summed from several consumers) lives at another address and is left untouched.
+            sink.owned.clear()
             dh2_tot = dh2.addmm_(dq, W_out)
         else:
             dh2_tot = th.addmm(dh2, dq, W_out)
@@ -719,7 +733,8 @@ class _TarmacStep(th.autograd.Function):
         d_inp = _mm_nn(d_gi, W_ih)                                         # [N, H + M]: d x | d c
         _mm_nn(d_gh, W_hh, out=dh, accumulate=True)
         if sink is not None:
-            sink.owned.add(dh.data_ptr())
+            sink.owned.clear()
+            sink.owned[dh.data_ptr()] = dh
         ld = M + 2 * K
         d_proj = th.empty((N, ld), dtype=th.float32, device=x.device)
         _launch_talk_bwd(ctx.env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld,
@@ -791,7 +806,10 @@ def tarmac_step(x, h, g, comm, f_out, stacked=None, dx_out=None):
         else:
             _add_grad(params[name], grad)
 
-    train = th.is_grad_enabled() and (x.requires_grad or h.requires_grad or cell.weight_ih.requires_grad)
+    # ANY differentiable input (a trainable Q head over a frozen encoder / GRU included) makes autograd run the backward,
+    # which reads the saved pre-activation sets
+    train = th.is_grad_enabled() and any(t.requires_grad for t in (x, h, Wp, bp, cell.weight_ih, cell.bias_ih,
+                                                                   cell.weight_hh, cell.bias_hh, f_out.weight, f_out.bias))
     return _TarmacStep.apply(x, h, Wp, bp, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, f_out.weight,
                              f_out.bias, M, K, off, src, t_off, t_dst, t_pos, split, env, dx_out, train)
 
