@@ -239,12 +239,19 @@ def cpu_baseline(n, M, dist_name, T_s=2, budget_s=24.0):
                 sec_per_cycle=sweep[best]["sec_per_cycle_median"])
 
 
-def end_to_end(learner, a, device, cycles=2):
+def end_to_end(learner, a, device, mode="random", cycles=2):
     """SURVEY 8f rows f1 + f2 + f3 inside the timed region (reported NEXT TO the headline, whose graphs are synthetic as
     BASELINE.json asks): B environments of the batched device simulator (csrc/env_sim.hip; exp3 'DenseHotSpot' physics,
-    maps.py:82-111, at n x M) are rolled out for T steps with the policy - simulator step, device graph construction,
-    act, replay push per step - then ONE update consumes the B stored sequences (graphs of all T+1 steps rebuilt from the
-    replay's padded tensors).  env-steps/s = B T / cycle time.  Random initial policy: ~95 % of the agents see no GT."""
+    maps.py:82-111, at n x M) are rolled out for T steps - simulator step, device graph construction, act, replay push
+    per step - then ONE update consumes the B stored sequences (graphs of all T+1 steps rebuilt from the replay's padded
+    tensors).  env-steps/s = B T / cycle time.  Two operating points of the `seen` relation:
+      mode "random"  - epsilon = 1, the uniformly random policy the reference starts training with (run.py:59-60,
+                       learner.py:73-80), UBSs placed on the grid as maps.py:96-111 does: sparse `seen`;
+      mode "hotspot" - UBSs placed ON the GT hotspot and held there (the policy forward and the action selection still
+                       run, the simulator is stepped with the hover action): dense `seen`, what a trained policy's
+                       rollouts look like.
+    (An untrained network's near-greedy argmax, epsilon = 0.05, walks every UBS into a wall: visibility 3e-4, measured in
+    round 2 - a zero-degree workload that says nothing.)"""
     from uav_bs_ctrl_amd import from_padded_obs
     from uav_bs_ctrl_amd.replay import SequenceReplay
     from uav_bs_ctrl_amd.sim import BatchedUbsCoverageEnv, MapParams
@@ -263,10 +270,16 @@ def end_to_end(learner, a, device, cycles=2):
         spot = th.randint(0, 26, (B, 1, 2), device=device, generator=gen).double() * grid
         grp = spot + th.randint(0, 4, (B, M // 5, 2), device=device, generator=gen).double() * grid
         gts = grp.repeat_interleave(5, 1) + 100.0 * (th.rand(B, M, 2, device=device, generator=gen, dtype=th.float64) - 0.5)
-        ubs = th.randint(0, 30, (B, n, 2), device=device, generator=gen).double() * grid
-        return ubs, gts.clamp(0, mp.range_pos).float()
+        if mode == "hotspot":   # inside the 800 m x 800 m hotspot, at least 2 safe distances apart (distinct 100 m cells)
+            cell = th.stack([th.randperm(64, device=device, generator=gen)[:n] for _ in range(B)])          # [B, n]
+            ubs = spot + th.stack((cell % 8, cell // 8), -1).double() * 100.0 + 50.0
+        else:
+            ubs = th.randint(0, 30, (B, n, 2), device=device, generator=gen).double() * grid
+        return ubs.clamp(0, mp.range_pos), gts.clamp(0, mp.range_pos).float()
 
     zero_done = th.zeros(B, 1, device=device)
+
+    vis = []
 
     def cycle():
         ubs, gts = positions()
@@ -275,8 +288,11 @@ def end_to_end(learner, a, device, cycles=2):
         for t in range(T):
             g = from_padded_obs(o["gt"], o["ubs"], o["agent"], o["d_u2u"], r_comm=mp.r_comm, static=STATIC)
             rb.stage_obs(dict(gt=o["gt"], ubs=o["ubs"], agent=o["agent"], d_u2u=o["d_u2u"], h=h.view(B, n, -1)))
-            acts, h2 = learner.act(g, h, 0.05)
+            acts, h2 = learner.act(g, h, 1.0 if mode == "random" else 0.05)
+            if mode == "hotspot":
+                acts = th.zeros_like(acts)        # hover: the UBSs stay on the hotspot
             o, rew, done, _ = env.step(acts)      # overwrites the observation buffers in place: they are in the replay already
+            vis.append(o["gt"][..., 0].mean())
             rb.push(dict(act=acts.view(B, n), rew=rew.float(), done=zero_done, next_gt=o["gt"], next_ubs=o["ubs"],
                          next_agent=o["agent"], next_d_u2u=o["d_u2u"], next_h=h2.view(B, n, -1)))
             h = h2
@@ -294,17 +310,20 @@ def end_to_end(learner, a, device, cycles=2):
 
     cycle()
     th.cuda.synchronize()
+    vis.clear()
     t0 = time.perf_counter()
     for _ in range(cycles):
         out = cycle()
     th.cuda.synchronize()
     dt = (time.perf_counter() - t0) / cycles
     served = float((env.out["gt_ubs"] >= 0).float().mean())
-    seen = float(env.out["obs_gt"][..., 0].mean())
+    seen = float(th.stack(vis).mean())            # over every step of the timed cycles, not just the last one
     return dict(value=B * T / dt, unit="env-steps/s", ms_per_cycle=1e3 * dt, cycles=cycles, loss=float(out["LossQ"]),
+                mode=mode, policy=("uniformly random actions (epsilon = 1)" if mode == "random" else
+                                   "policy forward + selection run, simulator stepped with the hover action"),
                 includes="batched device simulator (f3) + device graph construction (f1) + tensor replay (f2) + act + update",
                 physics=f"DenseHotSpot-style map at {n} x {M}: 5 RBs, r_cov 100 m, r_sns 400 m, range 6 km, dt 40 s",
-                mean_gt_visibility=seen, mean_gt_served=served)
+                mean_gt_visibility=seen, mean_d_seen=seen * M, mean_gt_served=served)
 
 
 def main():
@@ -321,6 +340,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the simulator-inclusive figure (rows f1+f2+f3)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (smoke test)")
+    ap.add_argument("--rho", type=int, default=32, help="replay ratio of the extra `replay_ratio_leg` (headline: 1)")
+    ap.add_argument("--no-rho-leg", action="store_true", help="skip the replay-ratio leg (one cycle with rho chunks per update)")
     ap.add_argument("--no-fp32-leg", action="store_true",
                     help="skip the second timing with the bf16x3 kernels off (fp32-MFMA GRU cell, vendor fp32 GEMMs)")
     a = ap.parse_args()
@@ -398,11 +419,13 @@ def main():
 
     if rank == 0:
         env_steps = world * a.B * a.T * a.steps
+        # SURVEY 8d names: C3 = BASELINE configs[2] (8 x 80, B = 4096); anything else is labelled by its own sizes
+        label = {(8, 80, 4096): "C3", (4, 40, 1024): "C2", (16, 200, 1024): "C5 (per-GPU shard)"}.get((a.n, a.M, a.B), "custom")
         res = {
             "metric": "env-steps/sec (MADRQN, 8 UBS x 80 GT)", "value": env_steps / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C3: {a.n} UBS x {a.M} GT, exp3 MADRQN (GATv2 obs-encoder + TarMAC), "
+            "config": {"workload": f"{label}: {a.n} UBS x {a.M} GT, exp3 MADRQN (GATv2 obs-encoder + TarMAC), "
                                    f"B={a.B} env graphs/GPU, T={a.T}, D-{a.dist}, replay ratio 1: one step = {a.T} "
                                    f"act forwards + 1 update ({2 * a.T + 1} forwards + BPTT backward + AdamW)",
                        "global_batch": world * a.B, "seq_len": a.T, "parallelism": f"dp{world}"},
@@ -503,19 +526,46 @@ def main():
                 gc.collect()
                 gc.disable()
                 t1 = time.perf_counter()
-                for _ in range(2):
+                for _ in range(5):
                     step()
                 th.cuda.synchronize()
                 e1 = time.perf_counter() - t1
                 gc.enable()
-                res["fp32_mfma_leg"] = {"value": world * a.B * a.T * 2 / e1, "unit": "env-steps/s", "steps": 2,
-                                        "ms_per_step": 1e3 * e1 / 2,
+                res["fp32_mfma_leg"] = {"value": world * a.B * a.T * 5 / e1, "unit": "env-steps/s", "steps": 5,
+                                        "ms_per_step": 1e3 * e1 / 5,
                                         "config": "UAVGNN_GRU_X3=0 UAVGNN_GEMM_X3=0: GRU cell on fp32 MFMA (csrc/gru_fused.hip), "
                                                   "every dense layer on the vendor fp32 GEMM"}
             finally:
                 ops.GRU_X3 = ops.GEMM_X3 = True
+        if world == 1 and not a.no_rho_leg:
+            # the reference's own replay ratio (run.py:55-57,:97: 32 stored sequences per T steps of one environment):
+            # T act forwards on B environments + ONE optimizer step over rho chunks of B sequences (gradient accumulation)
+            rho = a.rho
+
+            def step_rho():
+                obs = [g.fresh() for g in batch["obs"]]
+                fb = dict(batch, obs=obs, obs_all=batch["obs_all"].fresh(), obs_all_next=batch["obs_all_next"].fresh())
+                h = learner.init_hidden(a.B)
+                for t in range(a.T):
+                    _, h = learner.act(obs[t].fresh(), h, 0.05)
+                return learner.update([fb] * rho)
+            th.cuda.synchronize()
+            gc.collect()
+            gc.disable()
+            t1 = time.perf_counter()
+            step_rho()
+            th.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+            gc.enable()
+            res["replay_ratio_leg"] = {"rho": rho, "value": a.B * a.T / e1, "unit": "env-steps/s", "steps": 1,
+                                       "ms_per_step": 1e3 * e1, "sequences_per_update": rho * a.B,
+                                       "transitions_trained_per_s": rho * a.B * a.T / e1,
+                                       "config": f"{a.T} act forwards on B environments + one optimizer step over {rho} chunks "
+                                                 f"of B sequences (the same synthetic chunk {rho} times; gradients accumulated "
+                                                 "in the flat buffer, ONE clip + AdamW + polyak)"}
         if world == 1 and not a.no_end_to_end:
-            res["end_to_end"] = end_to_end(learner, a, device)
+            res["end_to_end"] = end_to_end(learner, a, device, "random")
+            res["end_to_end_hotspot"] = end_to_end(learner, a, device, "hotspot")
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.n, a.M, a.dist)
         print(json.dumps(res), flush=True)

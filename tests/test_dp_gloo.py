@@ -159,3 +159,18 @@ def test_flat_grad_buffer_views_and_clip():
     fb.zero_()                               # ... zero_() re-attaches them
     assert all(p.grad is not None and p.grad.data_ptr() == q for p, q in zip(net.parameters(), ptrs))
     assert float(fb.flat.abs().sum()) == 0.0
+
+
+def test_replay_ratio_chunks_accumulate_to_the_concatenated_batch_step():
+    """learner.update([chunk_0, .., chunk_{rho-1}]) (gradient accumulation, the reference's replay ratio as chunks of B
+    sequences) takes the same step as ONE update on the concatenated batch: same loss, same parameters afterwards."""
+    th.manual_seed(5)
+    L1, L2 = _learner(), _learner()
+    L2.policy_net.load_state_dict(L1.policy_net.state_dict())
+    L2.target_net.load_state_dict(L1.target_net.state_dict())
+    b0, b1 = _make_batch(20, 2), _make_batch(21, 2)
+    out1 = L1.update([b0, b1])
+    out2 = L2.update(_concat(b0, b1))
+    assert abs(float(out1["LossQ"]) - float(out2["LossQ"])) <= 1e-6 * max(1.0, abs(float(out2["LossQ"])))
+    for (k, p1), (_, p2) in zip(L1.policy_net.named_parameters(), L2.policy_net.named_parameters()):
+        assert float((p1 - p2).abs().max()) <= 1e-6, k

@@ -20,9 +20,9 @@ def _loss(q, h2, wq, wh):
     return (q * wq).sum() + (h2 * wh).sum()
 
 
-# Absolute floor for gradients that are analytically zero (d/d f_sign.bias: a constant added to every signature cancels
-# in the softmax) or sums of O(1) terms that cancel to ~0: there max|ref| is itself rounding noise of the float64 run.
-GRAD_FLOOR = 2e-6
+# No blanket absolute floor: gradients that are analytically zero (d/d f_sign.bias: a constant added to every signature
+# cancels in the softmax) or that cancel to ~0 are covered by grad_close's "4x the fp32 CPU oracle's own absolute error".
+GRAD_FLOOR = 0.0
 
 
 def _oracle32_golden(name):
@@ -137,7 +137,7 @@ def test_exp3_disc_comm_vs_oracle(exact_ties, talk):
     def oracle(dtype):
         pp = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in p64.items()}
         gg = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in g.items()}
-        hh = h.to(dtype).requires_grad_(True)
+        hh = h.detach().clone().to(dtype).requires_grad_(True)
         q_, h_ = R.gnn_agent_forward(gg, hh, pp, cfg, gumbel=gum.to(dtype))
         return q_, h_, th.autograd.grad(_loss(q_, h_, wq.to(dtype), wh.to(dtype)), list(pp.values()) + [hh])
     q64, h64, g64 = oracle(th.float64)
@@ -280,7 +280,7 @@ def test_other_head_configurations_vs_oracle(H, nh):
     def oracle(dtype):
         pp = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in p64.items()}
         gg = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in g.items()}
-        hh = h.to(dtype).requires_grad_(True)
+        hh = h.detach().clone().to(dtype).requires_grad_(True)
         q_, h_ = R.gnn_agent_forward(gg, hh, pp, cfg)
         return q_, h_, th.autograd.grad(_loss(q_, h_, wq.to(dtype), wh.to(dtype)), list(pp.values()) + [hh])
     q64, h64, g64 = oracle(th.float64)
@@ -388,7 +388,7 @@ def test_talk_attention_kernel_vs_oracle(N, max_deg, K, M):
         assert_close(c, c64, 1e-5, f"c uniform={uniform}")
         got = th.autograd.grad((c * w.cuda()).sum(), [vd] if uniform else [sd, qd, vd])
         for a, b, b32, nm in zip(got, g64, g32, ["d_v"] if uniform else ["d_s", "d_q", "d_v"]):
-            grad_close(a, b, f"K3b N={N} deg<={max_deg} K={K} M={M}: {nm} uniform={uniform}", ref32=b32, floor=1e-6)
+            grad_close(a, b, f"K3b N={N} deg<={max_deg} K={K} M={M}: {nm} uniform={uniform}", ref32=b32)
 
 
 @pytest.mark.parametrize("N,H", [(1000, 256), (33, 30), (5, 7)])
@@ -729,7 +729,7 @@ def test_talk_attention_per_graph_kernels_vs_oracle_and_per_destination_kernels(
         assert_close(c, c64, 1e-5, f"c uniform={uniform}")
         assert_close(c, c2, 2e-6, f"c env vs dst uniform={uniform}")
         for a, b, b32, b2, nm in zip(got, g64, g32, got2, ["d_v"] if uniform else ["d_s", "d_q", "d_v"]):
-            grad_close(a, b, f"K3b per graph K={K} M={M}: {nm} uniform={uniform}", ref32=b32, floor=1e-6)
+            grad_close(a, b, f"K3b per graph K={K} M={M}: {nm} uniform={uniform}", ref32=b32)
             assert_close(a, b2, 1e-5, f"{nm} env vs dst uniform={uniform}", floor=1e-6)
 
 
@@ -763,7 +763,7 @@ def test_talk_attention_per_graph_kernels_with_parallel_edges():
     c32 = R.segment_sum(v32[src.long()] * R.segment_softmax(e32, dst, N), dst, N)
     g32 = th.autograd.grad((c32 * w.float()).sum(), [s32, q32, v32])
     for a, b, b32, nm in zip(got, g64, g32, ["d_s", "d_q", "d_v"]):
-        grad_close(a, b, f"K3b parallel edges: {nm}", ref32=b32, floor=1e-6)
+        grad_close(a, b, f"K3b parallel edges: {nm}", ref32=b32)
     # duplicates are summed in CSC order by the lane of the first one (no float atomics): bit-exact run to run
     for _ in range(5):
         c2 = ops.talk_attention(sd, qd, vd, g, 1.0 / K)
@@ -1421,7 +1421,7 @@ def test_fused_gru_cell_kernel_vs_oracle(N, K_in, H):
     for key, (out, got) in res.items():
         assert_close(out, ref, 1e-5, f"h' (fused, x3)={key}")
         for a, b, b32, nm in zip(got, gref, g32, ["d_inp", "d_h", "dW_ih", "dW_hh", "db_ih", "db_hh"]):
-            grad_close(a, b, f"K4 N={N} K={K_in} H={H} (fused, x3)={key}: {nm}", ref32=b32, floor=1e-5)
+            grad_close(a, b, f"K4 N={N} K={K_in} H={H} (fused, x3)={key}: {nm}", ref32=b32)
 
 
 @pytest.mark.parametrize("M,N,K,transpose", [(4096, 256, 512, False), (5000, 512, 256, True), (4097, 128, 96, False),
@@ -1499,9 +1499,13 @@ def test_fused_gru_cell_operand_range():
         inp, h = th.randn(N, K_in, generator=gen) * 2.0 ** e, th.randn(N, H, generator=gen) * 2.0 ** e
         with th.no_grad():
             ref = c64(inp.double(), h.double())
+            ref32 = cell.cpu()(inp, h)            # ATen's fp32 cell on the host: what fp32 arithmetic delivers here
+            cell = cell.cuda()
             out = ops.gru_cell(inp.cuda(), h.cuda(), cell)
         assert ops.gru_cell_supported(inp.cuda(), h.cuda())
-        assert_close(out, ref, 1e-5, f"h' at 2^{e}")
+        # at 2^12 the pre-activations are O(10^3) with an fp32 error of O(10^-3): wherever a gate is NOT saturated that
+        # error is multiplied by |h| ~ 10^3 - any fp32 cell shows it, so the bound is grad_close's (1e-5 or 4x fp32's own)
+        grad_close(out, ref, f"K4 operand range: h' at 2^{e}", ref32=ref32)
 
 
 def test_linear_layers_take_the_bf16x3_kernel_and_match_vendor_path():

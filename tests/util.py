@@ -75,11 +75,14 @@ def load_learner_golden(name="learner_update_tarmac", dtype=th.float64, device="
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Gradient rule (north_star: 1e-5 relative fp32).  A gradient is a long fp32 reduction over edges / agents / time steps,
-# so fp32 arithmetic itself - in ANY order - may sit above 1e-5 of the float64 value.  The bound is therefore
-#     max(1e-5, 4 x the float32 CPU oracle's own error against the float64 oracle on the same inputs)
-# measured in the same mixed norm as assert_close, and every comparison is RECORDED (measured error, the fp32 oracle's
-# error, the bound) into gpurun_out/grad_errors.jsonl so that the table under profiles/ says how large the errors are.
+# Gradient rule (north_star: 1e-5 relative fp32).  A gradient is a long fp32 reduction over edges / agents / time steps
+# with cancellation, so fp32 arithmetic itself - in ANY summation order - may sit above 1e-5 of the float64 value (and a
+# gradient that is analytically zero, e.g. d/d f_sign.bias, is pure rounding noise on both sides).  Element i passes when
+#     |got_i - ref64_i|  <=  max( 1e-5 (max|ref64| + |ref64_i|),  4 E32 ),
+# E32 = the largest absolute error of the float32 CPU oracle against the float64 oracle on the same tensor: 1e-5 wherever
+# fp32 can hold it, otherwise no worse than 4x what fp32 arithmetic itself delivers.  No blanket floor.  Every comparison
+# is RECORDED (measured relative error, the fp32 oracle's, which clause decided) in gpurun_out/grad_errors.jsonl; the table
+# under profiles/ is made from it by tools/grad_error_table.py.
 GRAD_BASE = 1e-5
 GRAD_FACTOR = 4.0
 _GRAD_LOG = os.path.join(os.path.dirname(GOLDEN), os.pardir, "gpurun_out", "grad_errors.jsonl")
@@ -101,21 +104,33 @@ def needed_rel(actual, ref, floor=0.0):
     return float((err / den.clamp_min(1e-300)).max())
 
 
-def grad_close(actual, ref64, what, ref32=None, floor=0.0, bound=None):
+def grad_close(actual, ref64, what, ref32=None, floor=0.0):
     """Assert a gradient against the float64 oracle under the rule above and record the measurement.  ref32: the same
-    gradient from the float32 CPU oracle (None: the bound is the plain 1e-5, or `bound` when the caller states one)."""
+    gradient from the float32 CPU oracle; `floor`: an explicit absolute floor for comparisons that have no fp32 oracle."""
     import json
-    got = needed_rel(actual, ref64, floor)
-    cpu32 = None if ref32 is None else needed_rel(ref32, ref64, floor)
-    lim = bound if bound is not None else max(GRAD_BASE, GRAD_FACTOR * (cpu32 or 0.0))
+    a = actual.detach().double().cpu()
+    r = ref64.detach().double().cpu()
+    assert a.shape == r.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(r.shape)}"
+    raw = needed_rel(a, r)
+    e32 = cpu32 = None
+    if ref32 is not None:
+        r32 = ref32.detach().double().cpu()
+        e32 = float((r32 - r).abs().max()) if r.numel() else 0.0
+        cpu32 = needed_rel(r32, r)
+    abs_floor = max(floor, GRAD_FACTOR * (e32 or 0.0))
+    err = (a - r).abs()
+    lim = th.clamp(GRAD_BASE * (float(r.abs().max()) + r.abs()) if r.numel() else err, min=abs_floor)
+    ok = bool((err <= lim).all()) if r.numel() else True
     try:
         os.makedirs(os.path.dirname(_GRAD_LOG), exist_ok=True)
         with open(_GRAD_LOG, "a") as f:
-            f.write(json.dumps(dict(test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], what=what,
-                                    rel_err=got, cpu_fp32_rel_err=cpu32, bound=lim, floor=floor,
-                                    max_abs_ref=float(ref64.detach().abs().max()) if ref64.numel() else 0.0)) + "\n")
+            f.write(json.dumps(dict(test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], what=what, rel_err=raw,
+                                    cpu_fp32_rel_err=cpu32, max_abs_err=float(err.max()) if r.numel() else 0.0,
+                                    cpu_fp32_max_abs_err=e32, abs_floor=abs_floor,
+                                    max_abs_ref=float(r.abs().max()) if r.numel() else 0.0,
+                                    decided_by=("1e-5" if raw <= GRAD_BASE else "4x fp32 oracle error" if ok else "FAIL"))) + "\n")
     except OSError:
         pass
-    assert got <= lim, (f"{what}: gradient rel err {got:.3e} > bound {lim:.3e} "
-                        f"(fp32 CPU oracle's own error vs float64: {cpu32 if cpu32 is None else format(cpu32, '.3e')})")
-    return got
+    assert ok, (f"{what}: gradient rel err {raw:.3e} (max abs {float(err.max()):.3e}) exceeds max(1e-5 relative, "
+                f"{abs_floor:.3e} absolute = 4x the fp32 CPU oracle's own error {e32})")
+    return raw

@@ -99,6 +99,12 @@ class GraphedUpdate:
 
         gu = GraphedUpdate(learner, B, T, n, M, r_comm)
         out = gu(batch)      # batch: gt [B,T+1,n,M,5], ubs, agent, d_u2u, h [B,T+1,n,H], act [B,T,n], rew [B,T,rd], done [B,T,1]
+
+    Data-parallel runs (``learner.needs_collective()``): the gradient all-reduce is NOT captured.  The update is cut at
+    its only collective into TWO graphs - ``accumulate`` (graph construction, 2T+1 forwards, backward into the flat gradient
+    buffer) and ``apply`` (clip + AdamW + polyak) - with the RCCL all-reduce of the flat buffer issued eagerly on the same
+    stream between the two replays: the capture never depends on what the communicator does under stream capture, and a
+    rank that replays while another is still capturing cannot dead-lock inside a captured collective.
     """
 
     def __init__(self, learner, B: int, T: int, n: int, M: int, r_comm: float = float("inf"), rew_dim: Optional[int] = None,
@@ -117,29 +123,39 @@ class GraphedUpdate:
         # warm-up updates run for real (they would move the parameters): snapshot and restore around them
         snap = {k: [t.clone() for t in (learner.flat.flat, learner.flat_target, learner.optimizer.m, learner.optimizer.v,
                                         learner.optimizer.hyper)] for k in ("s",)}["s"]
+        self.split = learner.needs_collective()
         side = th.cuda.Stream()
         side.wait_stream(th.cuda.current_stream())
         with th.cuda.stream(side):
             for _ in range(warmup):
                 self._body()
         th.cuda.current_stream().wait_stream(side)
-        with th.cuda.graph(self.graph):
-            self.out = self._body()
+        if self.split:
+            self.graph_tail = th.cuda.CUDAGraph()
+            with th.cuda.graph(self.graph):
+                self.out = self.learner.accumulate(self._batch())
+            with th.cuda.graph(self.graph_tail, pool=self.graph.pool()):
+                self.learner.apply()
+        else:
+            with th.cuda.graph(self.graph):
+                self.out = self._body()
         th.cuda.synchronize()
         for dst, src in zip((learner.flat.flat, learner.flat_target, learner.optimizer.m, learner.optimizer.v,
                              learner.optimizer.hyper), snap):
             dst.copy_(src)
 
     def _body(self) -> Dict:
+        return self.learner.update(self._batch())
+
+    def _batch(self) -> Dict:
         T, B, n, M = self.T, self.B, self.n, self.M
         o = self.obs
         obs = [from_padded_obs(o.gt[t], o.ubs[t], o.agent[t], o.d_u2u[t], self.r_comm, static=True) for t in range(T + 1)]
         flat = lambda x, lo: x[lo:].reshape((-1,) + x.shape[2:])  # noqa: E731
         obs_all = from_padded_obs(flat(o.gt, 0), flat(o.ubs, 0), flat(o.agent, 0), None, self.r_comm, static=True)
         obs_next = from_padded_obs(flat(o.gt, 1), flat(o.ubs, 1), flat(o.agent, 1), None, self.r_comm, static=True)
-        batch = dict(obs=obs, obs_all=obs_all, obs_all_next=obs_next, h0=self.h0, h1=self.h1, acts=self.acts,
-                     rews=self.rews, dones=self.dones)
-        return self.learner.update(batch)
+        return dict(obs=obs, obs_all=obs_all, obs_all_next=obs_next, h0=self.h0, h1=self.h1, acts=self.acts,
+                    rews=self.rews, dones=self.dones)
 
     def load(self, m: Dict[str, th.Tensor]) -> None:
         """m: a gathered batch in ``SequenceReplay.mem`` layout (leading dims [B, T+1] / [B, T])."""
@@ -157,4 +173,7 @@ class GraphedUpdate:
             self.load(m)
         self.learner.optimizer.sync_lr()
         self.graph.replay()
+        if self.split:
+            self.learner.grads.all_reduce_mean_(self.learner.group)
+            self.graph_tail.replay()
         return self.out

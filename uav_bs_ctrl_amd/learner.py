@@ -224,28 +224,53 @@ class MultiAgentQLearner:
         target = rews + self.gamma * (1 - dones) * next_vals
         return F.mse_loss(qvals, target), agent_out, target_out
 
-    def update(self, batch: Dict) -> Dict:
+    def update(self, batch) -> Dict:
+        """One gradient step = ``accumulate`` (loss + backward into the flat gradient buffer) -> the ONE collective of the
+        data path -> ``apply`` (clip + AdamW + polyak).  ``batch``: a batch dict, or a LIST of equally sized batch dicts
+        whose gradients are accumulated before the one optimizer step (replay ratio rho = len(list): the reference
+        consumes 32 stored sequences per T environment steps of ONE environment - run.py:55-57,:97 - i.e. rho = 32; at B
+        environments per GPU that is rho chunks of B sequences).  The loss is the MSE over ALL chunks (the mean of the
+        chunk means), so the step equals the step on the concatenated batch."""
+        out = self.accumulate(batch)
+        self.grads.all_reduce_mean_(self.group)           # the only collective of the data path
+        self.apply()
+        return out
+
+    def needs_collective(self) -> bool:
+        return bool(dist.is_available() and dist.is_initialized() and
+                    (dist.get_world_size(self.group) > 1 or self.grads.force_collective))
+
+    def accumulate(self, batch) -> Dict:
+        """Zero the flat gradient buffer, then loss + backward of every chunk into it (learner.py:110-157)."""
+        chunks = batch if isinstance(batch, (list, tuple)) else [batch]
         self.grads.zero_()
-        # weight gradients of the fused recurrent step are accumulated in place across the T+1 steps and folded into
-        # the flat gradient buffer once (ops.WeightGradSink); everything else reaches it through autograd
+        # weight gradients of the fused recurrent step are accumulated in place across the T+1 steps (and across the
+        # chunks) and folded into the flat gradient buffer once (ops.WeightGradSink); everything else reaches it through
+        # autograd
         ops.GRAD_SINK = sink = ops.WeightGradSink() if self.device.type == "cuda" else None
+        loss = None
         try:
-            loss, agent_out, _ = self.loss(batch)
-            loss.backward()
+            for b in chunks:
+                loss_b, agent_out, _ = self.loss(b)
+                if len(chunks) > 1:
+                    loss_b = loss_b / len(chunks)
+                loss_b.backward()
+                loss = loss_b.detach() if loss is None else loss + loss_b.detach()
             if sink is not None:
                 sink.flush()
         finally:
             ops.GRAD_SINK = None
-        self.grads.all_reduce_mean_(self.group)           # the only collective of the data path
-        if self.fused_tail:
-            # clip_grad_value_(policy_net.parameters(), 1) (the mixer is NOT clipped, learner.py:159) + AdamW step +
-            # polyak of target net / target mixer (learner.py:157-166): one launch over the flat buffers
+        return dict(LossQ=loss, QVals=agent_out.detach())
+
+    def apply(self) -> None:
+        """clip_grad_value_(policy_net.parameters(), 1) (the mixer is NOT clipped, learner.py:159) + AdamW step + polyak
+        of target net / target mixer (learner.py:157-166)."""
+        if self.fused_tail:     # one launch over the flat buffers
             if not self.flat.intact():
                 raise L.UavGnnError("a parameter was moved out of the learner's flat buffer (module.to() / p.data = ... "
                                     "after the learner was built): rebuild the learner")
             self.optimizer.step()
-            return dict(LossQ=loss.detach(), QVals=agent_out.detach())
-        # == nn.utils.clip_grad_value_(policy_net.parameters(), 1): the mixer is NOT clipped (learner.py:159)
+            return
         self.grads.flat[:self.n_policy].clamp_(-1.0, 1.0)
         self.optimizer.step()
         with th.no_grad():                                # polyak (learner.py:163-166)
@@ -256,7 +281,6 @@ class MultiAgentQLearner:
                 mt = list(self.target_mixer.parameters())
                 th._foreach_mul_(mt, self.polyak)
                 th._foreach_add_(mt, list(self.mixer.parameters()), alpha=1 - self.polyak)
-        return dict(LossQ=loss.detach(), QVals=agent_out.detach())
 
     # ---- checkpoints (same keys as learner.py:175-201) -------------------------------------------------------------
     def save_checkpoint(self, path: str, stamp: dict) -> None:
