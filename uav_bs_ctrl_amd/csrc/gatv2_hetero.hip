@@ -32,6 +32,9 @@
 namespace uavgnn {
 namespace {
 
+#ifndef K1_ABLATE
+#define K1_ABLATE 0   // 1 (tools/ubench/k1_env_bench.hip only): `phases` bit 5 skips the score tile of phase N, bit 6 its row stores
+#endif
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWave * kWavesPerBlock;
 constexpr int NH = 4;
@@ -434,6 +437,9 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
                 x_ubs + static_cast<size_t>(base + 8 + slot < my_deg ? my_e0 + base + 8 + slot : 0) * FS_N);
           const float xB = (g == 0) ? xc.x : (g == 1) ? xc.y : xv_g;
           float e;
+#if K1_ABLATE
+          if (phases & 32) e = xB; else
+#endif
           UAVGNN_TILE_SCORE(Wa, att, cconst, wlin, xB, e)
           if (valid) {
             if (a_save_n != nullptr) a_save_n[static_cast<size_t>(my_e0 + base + slot) * NH + g] = e;
@@ -474,10 +480,16 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
             const float agg = has * fmaf(ws[r][1], sA1, fmaf(ws[r][0], sA0, bsn[r]));
             op[r] = fmaxf(agg + fmaf(wrn[r][1], xa1, fmaf(wrn[r][0], xa0, brn[r])), 0.f);
           }
+#if K1_ABLATE
+          if (!(phases & 64) || o.x == 123.456f)
+#endif
           *reinterpret_cast<float4*>(rowA + H + 4 * lane) = o;
           if (flags & 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) op[r] = fmaxf(fmaf(wrs[r][1], xa1, fmaf(wrs[r][0], xa0, brs[r])), 0.f);
+#if K1_ABLATE
+            if (!(phases & 64) || o.x == 123.456f)
+#endif
             *reinterpret_cast<float4*>(rowA + 4 * lane) = o;
           }
         }
@@ -491,10 +503,16 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
             const float agg = has * fmaf(ws[r][1], sB1, fmaf(ws[r][0], sB0, bsn[r]));
             op[r] = fmaxf(agg + fmaf(wrn[r][1], xb1, fmaf(wrn[r][0], xb0, brn[r])), 0.f);
           }
+#if K1_ABLATE
+          if (!(phases & 64) || o.x == 123.456f)
+#endif
           *reinterpret_cast<float4*>(rowB + H + 4 * lane) = o;
           if (flags & 2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) op[r] = fmaxf(fmaf(wrs[r][1], xb1, fmaf(wrs[r][0], xb0, brs[r])), 0.f);
+#if K1_ABLATE
+            if (!(phases & 64) || o.x == 123.456f)
+#endif
             *reinterpret_cast<float4*>(rowB + 4 * lane) = o;
           }
         }
@@ -534,11 +552,14 @@ extern "C" int uavgnn_gatv2_hetero_fwd_phases(const float* x_gt, int E_seen, con
   if (N == 0) return 0;
   RelParams ps{seen_params[0], seen_params[1], seen_params[2], seen_params[3], seen_params[4], seen_params[5], seen_params[6]};
   RelParams pn{near_params[0], near_params[1], near_params[2], near_params[3], near_params[4], near_params[5], near_params[6]};
-  const int grid = capped_grid(N, kWavesPerBlock, 512);   // persistent: 2 workgroups per CU
+  int grid = capped_grid(N, kWavesPerBlock, 512);   // persistent: 2 workgroups per CU
+#if K1_ABLATE
+  if (const char* gs = getenv("K1_GRID")) grid = atoi(gs);
+#endif
   if (E_near == 0) x_ubs = x_dst;   // masked slots read row 0 of x_ubs: any valid address will do when there are no edges
   hipLaunchKernelGGL(gatv2_hetero_fwd_kernel, dim3(grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream), x_gt,
                      seen_off, seen_order, x_ubs, near_off, x_dst, N, E_seen, ps, pn, slope, out, ld_out, attn_save_seen,
-                     attn_save_near, phases & 3);
+                     attn_save_near, K1_ABLATE ? phases : (phases & 3));
   return launch_status();
 }
 
