@@ -430,6 +430,7 @@ def main():
                                    f"act forwards + 1 update ({2 * a.T + 1} forwards + BPTT backward + AdamW)",
                        "global_batch": world * a.B, "seq_len": a.T, "parallelism": f"dp{world}"},
             "loss": loss,
+            "params_checksum": [float(ck[0]), float(ck[1])],   # sum / sum of squares of the policy parameters after the timed steps
             "step_ms_device": [round(marks[i - 1].elapsed_time(marks[i]), 1) for i in range(1, len(marks))],
         }
         # ---- roofline of the dominant message-passing kernel: K1 forward, BOTH relations (one fused launch) ----------

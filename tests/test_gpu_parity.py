@@ -1089,6 +1089,116 @@ def test_rccl_path_at_world_size_one_equals_the_non_distributed_step():
     assert abs(loss - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))
 
 
+def _nccl_graphed_worker(port, q):
+    """world size 1 over RCCL: GraphedUpdate must cut the capture at the collective (two graphs + an eager all-reduce of the
+    flat gradient buffer between their replays) and leave the same parameters as eager non-distributed updates."""
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    th.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=th.device("cuda", 0))
+    try:
+        from uav_bs_ctrl_amd import batch as hb_batch
+        from uav_bs_ctrl_amd.graphs import GraphedUpdate
+        from uav_bs_ctrl_amd.replay import SequenceReplay
+        dev, (E, n, M, T, Bs) = th.device("cuda"), (12, 4, 30, 4, 6)
+        L1, L2 = _graph_learner(n, T, seed=1), _graph_learner(n, T, seed=1)
+        L2.grads.force_collective = True
+        assert L2.needs_collective() and not L1.needs_collective()
+        rb = SequenceReplay(capacity=E, max_seq_len=T, n_agents=n, n_gts=M, hidden_size=256, n_envs=E, state_dim=0,
+                            r_comm=0.9, device=dev)
+        gen = th.Generator(device=dev).manual_seed(7)
+
+        def obs():
+            gt, ub, ag, d = _padded_obs(gen, (E,), n, M, dev)
+            return dict(gt=gt, ubs=ub, agent=ag, d_u2u=d, h=0.1 * th.randn(E, n, 256, device=dev, generator=gen),
+                        state=th.zeros(E, 0, device=dev))
+        cur = obs()
+        for t in range(T):
+            nxt = obs()
+            tr = dict(cur, act=th.randint(9, (E, n), device=dev, generator=gen), rew=th.rand(E, n, device=dev, generator=gen),
+                      done=(th.rand(E, 1, device=dev, generator=gen) < 0.2).float())
+            tr.update({"next_" + k: v for k, v in nxt.items()})
+            rb.push(tr)
+            cur = nxt
+        gu = GraphedUpdate(L2, Bs, T, n, M, r_comm=0.9)
+        split = bool(gu.split)
+        losses = []
+        for it in range(2):
+            idx = rb.sample_indices(Bs, gen)
+            b = rb.gather(idx)
+            b["obs_all"] = hb_batch(b["obs"])
+            out_e = L1.update(b)
+            out_g = gu({k: v.index_select(0, idx) for k, v in rb.mem.items()})
+            losses.append((float(out_e["LossQ"]), float(out_g["LossQ"])))
+        th.cuda.synchronize()
+        scale = float(L1.flat.flat.abs().max())
+        q.put(("ok", split, losses, float((L1.flat.flat - L2.flat.flat).abs().max()) / scale,
+               float((L1.flat_target - L2.flat_target).abs().max()) / scale, float(L2.optimizer.hyper[1])))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put(("err", traceback.format_exc() + repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_graphed_update_is_cut_at_the_rccl_collective_and_equals_eager_updates():
+    """the hipGraph-captured update with the gradient all-reduce in the loop.  The all-reduce is NOT
+    captured: the update is two graphs (accumulate / apply) around an eager RCCL all-reduce of the flat buffer."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_nccl_graphed_worker, args=(port, q))
+    pr.start()
+    try:
+        res = q.get(timeout=300)
+    finally:
+        pr.join(timeout=60)
+        if pr.is_alive():
+            pr.kill()
+    assert res[0] == "ok", res[1]
+    _, split, losses, d_pol, d_tgt, steps = res
+    assert split, "the capture was not cut at the collective"
+    for le, lg in losses:
+        assert abs(le - lg) <= 1e-5 * max(1.0, abs(le)), (le, lg)
+    assert d_pol <= 1e-5 and d_tgt <= 1e-5 and steps == 2.0, (d_pol, d_tgt, steps)
+
+
+def test_bench_step_under_force_dist_equals_the_plain_run():
+    """bench.py's own step() (rollout forwards + update on the HIP agent) launched the way the driver launches a rank -
+    torch.distributed.run, RCCL initialised, the flat gradient buffer pushed through the all-reduce at world size 1 - must
+    leave the SAME parameter checksum and loss as the plain single-process run."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    small = ["--gpus", "1", "--steps", "2", "--warmup", "0", "--B", "32", "--T", "4", "--no-cpu-baseline", "--no-end-to-end",
+             "--no-fp32-leg", "--no-rho-leg"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    plain = subprocess.run([sys.executable, "bench.py", *small], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    distd = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", *small, "--force-dist"],
+                           cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert distd.returncode == 0, distd.stderr[-2000:]
+    a = json.loads(plain.stdout.strip().splitlines()[-1])
+    b = json.loads(distd.stdout.strip().splitlines()[-1])
+    assert a["params_checksum"] == b["params_checksum"], (a["params_checksum"], b["params_checksum"])
+    assert a["loss"] == b["loss"] and b["n_gpus"] == 1
+
+
 @pytest.mark.parametrize("B,n,M,dist,seed", [(16, 8, 80, "dense", 0), (64, 8, 80, "env", 1), (9, 5, 40, "ragged", 2),
                                              (7, 16, 30, "ragged", 3), (1, 1, 12, "ragged", 4), (33, 3, 100, "env", 5)])
 def test_fused_hetero_k1_equals_per_relation_kernels(B, n, M, dist, seed):
