@@ -271,7 +271,7 @@ def end_to_end(learner, a, device, mode="random", cycles=2):
         grp = spot + th.randint(0, 4, (B, M // 5, 2), device=device, generator=gen).double() * grid
         gts = grp.repeat_interleave(5, 1) + 100.0 * (th.rand(B, M, 2, device=device, generator=gen, dtype=th.float64) - 0.5)
         if mode == "hotspot":   # inside the 800 m x 800 m hotspot, at least 2 safe distances apart (distinct 100 m cells)
-            cell = th.stack([th.randperm(64, device=device, generator=gen)[:n] for _ in range(B)])          # [B, n]
+            cell = th.rand(B, 64, device=device, generator=gen).argsort(1)[:, :n]                             # [B, n] distinct cells
             ubs = spot + th.stack((cell % 8, cell // 8), -1).double() * 100.0 + 50.0
         else:
             ubs = th.randint(0, 30, (B, n, 2), device=device, generator=gen).double() * grid

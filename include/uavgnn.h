@@ -325,6 +325,16 @@ void uavgnn_gemm_x3_set_variant(int variant);   /* A/B of tools/gemm_x3_probe.py
 int uavgnn_split_bf16x3(const float* W, int ld, int R, int C, int transpose, void* planes, uavgnn_stream_t stream);
 int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const void* planes, int N, const float* bias, float* Y, int ldy,
                       int epilogue, uavgnn_stream_t stream);
+
+/* Weight gradient of a dense layer on the bf16x3 arithmetic (csrc/gemm_tn_x3.hip): partials[s][Mo, Ko] (+)= dY[rows_s, :Mo]^T
+ * X[rows_s, :Ko] for the S contiguous row chunks rows_s of the n_rows rows (chunk = ceil(n_rows / S) rounded up to 32 rows);
+ * the caller sums the S partial products in a fixed order.  dY [n_rows, >= Mo] (row stride ldy), X [n_rows, >= Ko] (row
+ * stride ldx), fp32, unit inner stride, any 4-byte alignment; partials [S, Mo, Ko] fp32, fully overwritten unless
+ * `accumulate`.  Replaces autograd's dW = dy^T x of nn.Linear / nn.GRUCell (gnn_agents.py:99, :243-246, :43-46 under
+ * learner.py:157).  uavgnn_gemm_tn_x3_chunks: the S this library would pick (output tiles x S fills the chip). */
+int uavgnn_gemm_tn_x3_chunks(long long n_rows, int Mo, int Ko);
+int uavgnn_gemm_tn_x3(const float* dY, int ldy, int Mo, const float* X, int ldx, int Ko, long long n_rows, float* partials,
+                      int S, int accumulate, uavgnn_stream_t stream);
 int uavgnn_gru_gates_bwd_fused(const float* pre, const float* h, const float* d_hout, int N, int H, float* d_gi, float* d_gh,
                                float* d_h, uavgnn_stream_t stream);
 

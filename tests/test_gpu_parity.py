@@ -1618,6 +1618,41 @@ def test_fused_gru_cell_operand_range():
         grad_close(out, ref, f"K4 operand range: h' at 2^{e}", ref32=ref32)
 
 
+@pytest.mark.parametrize("n,Mo,Ko,views", [(32768, 768, 320, False), (5000, 96, 256, True), (4097, 9, 256, False),
+                                           (70001, 256, 512, False), (4096, 130, 70, True)])
+def test_gemm_tn_bf16x3_weight_gradient_vs_float64(n, Mo, Ko, views, monkeypatch):
+    """csrc/gemm_tn_x3.hip (dW = dy^T x: contraction over the agent axis, operands transposed on their way into LDS, row
+    chunks summed in a fixed order) against the float64 product: the layer shapes of the path (W_ih, stacked projections, Q
+    head, f_aggr), row counts that do not fill the last 32-row slice / chunk, output sizes that do not fill the 128 x 128
+    tile, column-sliced operand views, accumulate mode; error measured like an fp32 GEMM's (relative to sum |a b|) next to the
+    vendor GEMM's on the same data; bit-reproducible."""
+    from uav_bs_ctrl_amd import ops
+    monkeypatch.setattr(ops, "GEMM_TN_MIN_ROWS", 4096)      # the dispatcher takes the kernel from 2^18 rows; test it from 4096
+    gen = th.Generator().manual_seed(n + Mo + Ko)
+    dy_full = (th.randn(n, Mo + (8 if views else 0), generator=gen) * 0.3).cuda()
+    x_full = th.randn(n, Ko + (4 if views else 0), generator=gen).cuda()
+    dy, x = dy_full[:, (8 if views else 0):], x_full[:, :Ko]
+    assert ops.gemm_tn_x3_supported(dy, x)
+    ref = dy.double().t() @ x.double()
+    scale = dy.double().abs().t() @ x.double().abs()
+    part = ops.gemm_tn_x3(dy, x)
+    out = part.sum(0)
+    assert out.shape == (Mo, Ko)
+    err = float(((out.double() - ref).abs() / scale).max())
+    err_vendor = float((((dy.t() @ x).double() - ref).abs() / scale).max())
+    assert err <= max(2.0 * err_vendor, 1e-6), (err, err_vendor)
+    assert_close(out, ref, 1e-5, "dW", floor=1e-5 * float(scale.max()) * 1e-2)
+    assert th.equal(ops.gemm_tn_x3(dy, x), part), "not bit-reproducible"
+    acc = part.clone()
+    ops.gemm_tn_x3(dy, x, acc, accumulate=True)
+    assert_close(acc.sum(0), 2 * ref, 1e-5, "accumulate mode", floor=1e-5 * float(scale.max()) * 1e-2)
+    # the autograd paths that use it: ops.linear's weight gradient and the plain (sink-less) _wgrad
+    W = th.randn(Mo, Ko, generator=gen).cuda().requires_grad_(True)
+    xg = x.contiguous()
+    (ops.linear(xg, W) * dy).sum().backward()
+    assert_close(W.grad, ref, 1e-5, "ops.linear dW", floor=1e-5 * float(scale.max()) * 1e-2)
+
+
 def test_linear_layers_take_the_bf16x3_kernel_and_match_vendor_path():
     """ops.linear / linear_relu forward and input gradient at an encoder-layer shape go through csrc/gemm_x3.hip (the span
     counter moves) and agree with the vendor-GEMM path within the fp32 tolerance, weight / bias gradients included."""

@@ -470,6 +470,35 @@ def _mm_nn(dy, W, out=None, accumulate=False):
     return out.addmm_(dy, W) if accumulate else th.mm(dy, W, out=out)
 
 
+GEMM_TN_X3 = os.environ.get("UAVGNN_GEMM_TN_X3", "1") != "0"   # weight gradients on the bf16 matrix cores (csrc/gemm_tn_x3.hip)
+# Measured against the vendor's batched split-K fp32 GEMM (tools/gemm_tn_probe.py, profiles/r03_gemm_tn_probe.txt): BOTH operands
+# have to be split and transposed inside the kernel, which bounds it at 95-108 TFLOP/s fp32-equivalent = the vendor's 106-108
+# at the per-step shapes (32 768 rows; 0.4-0.6 x on the 96- and 9-row outputs), 142 vs 134 at the time-batched encoder shape
+# (1.67 M rows).  Only the latter takes the kernel; its error against float64 is 0.5-0.8 x the vendor's on every shape.
+GEMM_TN_MIN_ROWS = 1 << 18
+
+
+def gemm_tn_x3_supported(dy, x) -> bool:
+    return bool(GEMM_X3 and GEMM_TN_X3 and dy.is_cuda and dy.dtype == th.float32 and x.dtype == th.float32 and dy.dim() == 2
+                and x.dim() == 2 and dy.shape[0] == x.shape[0] and dy.shape[0] >= GEMM_TN_MIN_ROWS and dy.stride(1) == 1
+                and x.stride(1) == 1 and dy.shape[1] > 0 and x.shape[1] > 0)
+
+
+def gemm_tn_x3(dy, x, partials=None, accumulate=False):
+    """partials [S, out, in] (+)= chunked dy^T x (csrc/gemm_tn_x3.hip; the caller sums over S).  Caller checks
+    gemm_tn_x3_supported()."""
+    lib = L.lib()
+    n, Mo, Ko = dy.shape[0], dy.shape[1], x.shape[1]
+    if partials is None:
+        S = lib.uavgnn_gemm_tn_x3_chunks(n, Mo, Ko)
+        partials = th.empty((S, Mo, Ko), dtype=th.float32, device=dy.device)
+    with KERNEL_TIMER.span("gemm_tn_x3", (n, Mo, Ko)):
+        rc = lib.uavgnn_gemm_tn_x3(dy.data_ptr(), dy.stride(0), Mo, x.data_ptr(), x.stride(0), Ko, n, partials.data_ptr(),
+                                   partials.shape[0], int(accumulate), L.stream())
+    L.check(rc, "uavgnn_gemm_tn_x3")
+    return partials
+
+
 class _LinearSplitK(th.autograd.Function):
     """y = x W^T (+ b) on the vendor GEMM (hipBLASLt/rocBLAS fp32), with a weight-gradient path shaped for this
     workload: N_a is 10^4..10^5 rows while W is at most 768 x 512, so dW = dY^T X has a tiny output and a huge
@@ -494,7 +523,9 @@ class _LinearSplitK(th.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = _mm_nn(dy, W)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and gemm_tn_x3_supported(dy, x):
+            dW = gemm_tn_x3(dy, x).sum(0)
+        elif ctx.needs_input_grad[1]:
             n = x.shape[0]
             S = 1   # row chunks of >= 2048: S = 16 at N_a = 32768 (measured best or within 10 % on every layer shape)
             while S < 64 and n % (2 * S) == 0 and n // (2 * S) >= 2048:
@@ -563,6 +594,15 @@ class WeightGradSink:
 
     def weight(self, key, dy, x, flush_fn):
         """buffer[S, out, in] += chunked dy^T x"""
+        if gemm_tn_x3_supported(dy, x):      # bf16x3 kernel: accumulates into its own [S, out, in] partials in place
+            S = L.lib().uavgnn_gemm_tn_x3_chunks(x.shape[0], dy.shape[1], x.shape[1])
+            key = (key, "tn", S)
+            slot = self.slots.get(key)
+            if slot is None:
+                buf = th.zeros((S, dy.shape[1], x.shape[1]), dtype=th.float32, device=x.device)
+                self.slots[key] = slot = (buf, flush_fn)
+            gemm_tn_x3(dy, x, slot[0], accumulate=True)
+            return
         n, S = x.shape[0], self._chunks(x.shape[0])
         key = (key, S)          # one slot per chunk count: a change of N mid-accumulation never drops a partial sum
         slot = self.slots.get(key)
@@ -598,6 +638,8 @@ class WeightGradSink:
 
 def _wgrad(dy, x):
     """dy^T x with the reduction over rows split into chunks (see _LinearSplitK)."""
+    if gemm_tn_x3_supported(dy, x):
+        return gemm_tn_x3(dy, x).sum(0)
     n, S = x.shape[0], WeightGradSink._chunks(x.shape[0])
     if S == 1:
         return th.mm(dy.t(), x)
