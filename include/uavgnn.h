@@ -150,14 +150,19 @@ int uavgnn_gru_gates_bwd(const float* gi, const float* gh, const float* h, const
 
 /* ------------------------------------------------------------------------------------------------------------------
  * K5  DiscreteComm message passing (gnn_agents.py:166-178,:189): per edge F.gumbel_softmax(logits[src].view(msg,2),
- * tau, hard=True) with the Gumbel noise given explicitly ([E, msg, 2], CSC order), per destination the element-wise
- * max over in-edges.  logits[N, 2*msg] (ld) are the per-SOURCE-node encoder outputs.  c[N, 2*msg] is overwritten
- * (zeros for nodes without in-edges); y0_save[E, msg] and sel[N, 2*msg] (CSC position that owns each channel's
- * gradient: the first in-edge whose hard bit is set, else the first in-edge) feed the backward.
+ * tau, hard=True), per destination the element-wise max over in-edges.  The Gumbel noise is either given explicitly
+ * (gumbel [E, msg, 2], CSC order: fixtures carrying the reference's own draws) or, with gumbel == NULL, drawn inside the
+ * kernel: Philox4x32-10 keyed by the 64-bit seed rng[0], counter (CSC position, channel, step rng[1]), g = -log(-log(u));
+ * rng is a DEVICE array {seed, step} (a captured graph replays with the current step; the caller advances it).
+ * uavgnn_gumbel_noise writes that same stream as an [E, msg, 2] tensor (tests).  logits[N, 2*msg] (ld) are the
+ * per-SOURCE-node encoder outputs.  c[N, 2*msg] is overwritten (zeros for nodes without in-edges); y0_save[E, msg] and
+ * sel[N, 2*msg] (CSC position that owns each channel's gradient: the first in-edge whose hard bit is set, else the first
+ * in-edge) feed the backward.
  */
-int uavgnn_disc_comm_fwd(const float* logits, int ld, const float* gumbel, int msg, const int32_t* talk_off,
-                         const int32_t* talk_src, int N, float inv_tau, float* c, int ld_c, float* y0_save,
-                         int32_t* sel, uavgnn_stream_t stream);
+int uavgnn_disc_comm_fwd(const float* logits, int ld, const float* gumbel, const long long* rng, int msg,
+                         const int32_t* talk_off, const int32_t* talk_src, int N, float inv_tau, float* c, int ld_c,
+                         float* y0_save, int32_t* sel, uavgnn_stream_t stream);
+int uavgnn_gumbel_noise(const long long* rng, long long E, int msg, float* out, uavgnn_stream_t stream);
 /* d_c[N, 2*msg] -> d_logits[N, 2*msg] (overwritten), straight-through estimator; gather over the transposed CSC. */
 int uavgnn_disc_comm_bwd(const float* d_c, int ld_dc, const float* y0_save, const int32_t* sel, int msg,
                          const int32_t* t_off, const int32_t* t_dst, const int32_t* t_pos, int N, float inv_tau,

@@ -157,6 +157,74 @@ def test_exp3_disc_comm_vs_oracle(exact_ties, talk):
     assert th.isfinite(q2).all()
 
 
+def _philox4x32_10(c, k):
+    """numpy Philox4x32-10 (test infrastructure): c [n, 4] uint32 counters, k (k0, k1)."""
+    import numpy as np
+    c = c.astype(np.uint64).copy()
+    k0, k1 = np.uint64(k[0]), np.uint64(k[1])
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c = np.stack([(hi1 ^ c[:, 1] ^ k0) & mask, lo1, (hi0 ^ c[:, 3] ^ k1) & mask, lo0], 1)
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return c.astype(np.uint32)
+
+
+def test_disc_comm_in_kernel_gumbel_noise():
+    """K5 with the noise drawn INSIDE the kernel (Philox4x32-10 keyed by the seed, counter = (CSC position, channel, step)):
+    (1) the stream equals a numpy Philox + float64 -log(-log(u)) (known answers for the published algorithm), has Gumbel(0, 1)
+    moments, depends on seed and step and on nothing else; (2) the fused forward / backward are BIT-identical to the
+    injected-noise path fed with the materialised stream; (3) the module is reproducible from torch.manual_seed."""
+    import numpy as np
+    from uav_bs_ctrl_amd import ops
+    E, M = 5000, 64
+    seed = 0x1234567890ABCDEF & (2 ** 62 - 1)
+    rng = th.tensor([seed, 7], dtype=th.int64, device="cuda")
+    noise = ops.gumbel_noise(rng, E, M)
+    e_idx, i_idx = np.meshgrid(np.arange(40), np.arange(M), indexing="ij")
+    ctr = np.stack([e_idx.ravel(), i_idx.ravel(), np.full(e_idx.size, 7), np.zeros(e_idx.size)], 1).astype(np.uint32)
+    r = _philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32))
+    u = ((r[:, :2] >> 8).astype(np.float64) + 0.5) * 2.0 ** -24
+    ref = -np.log(-np.log(u))
+    got = noise[:40].cpu().double().numpy().reshape(-1, 2)
+    assert np.allclose(got, ref, rtol=2e-6, atol=2e-6), float(np.abs(got - ref).max())
+    x = noise.double()
+    n_s = x.numel()
+    assert abs(float(x.mean()) - 0.5772156649) < 5 * (1.6449 / n_s) ** 0.5
+    assert abs(float(x.var()) - 1.6449340668) < 0.02
+    assert th.equal(ops.gumbel_noise(rng, E, M), noise)
+    rng2 = th.tensor([seed, 8], dtype=th.int64, device="cuda")
+    assert not th.equal(ops.gumbel_noise(rng2, E, M), noise)
+    # (2) fused vs injected
+    g = to_batch(synth_graph(24, 8, 80, "env", seed=8, talk="sparse"))
+    Et = g.number_of_edges("talk")
+    gen = th.Generator().manual_seed(3)
+    logits_a = th.randn(24 * 8, 2 * M, generator=gen).cuda().requires_grad_(True)
+    logits_b = logits_a.detach().clone().requires_grad_(True)
+    w = th.randn(24 * 8, 2 * M, generator=gen).cuda()
+    c_a = ops.disc_comm_aggregate(logits_a, None, g, tau=0.5, rng=rng)
+    c_b = ops.disc_comm_aggregate(logits_b, ops.gumbel_noise(rng, Et, M), g, tau=0.5)
+    assert th.equal(c_a, c_b)
+    (c_a * w).sum().backward()
+    (c_b * w).sum().backward()
+    assert th.equal(logits_a.grad, logits_b.grad)
+    # (3) the module: reproducible from torch's seed, a new draw per forward
+    cfg = dict(EXP3, c="disc")
+    net = agent_from_params(default_init_params(cfg, seed=4), cfg)
+    h = th.zeros(24 * 8, 256, device="cuda")
+    outs = []
+    for _ in range(2):
+        th.manual_seed(11)
+        net.f_comm.rng_state = None
+        with th.no_grad():
+            q1, _ = net(g, h)
+            q2, _ = net(g, h)
+        outs.append((q1, q2))
+    assert th.equal(outs[0][0], outs[1][0]) and th.equal(outs[0][1], outs[1][1])
+    assert not th.equal(outs[0][0], outs[0][1]) and int(net.f_comm.rng_state[1]) == 2
+
+
 def test_backward_is_deterministic():
     p64 = default_init_params(EXP3, seed=2)
     g = synth_graph(32, 8, 80, "ragged", seed=5)

@@ -48,8 +48,9 @@ SIGNATURES = {
     "uavgnn_talk_attn_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip,
                                       _c_ip, _c_ip, _c_ip, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_int,
                                       _c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_st]),
-    "uavgnn_disc_comm_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_f32, _c_fp, _c_int, _c_fp,
+    "uavgnn_disc_comm_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_f32, _c_fp, _c_int, _c_fp,
                                       _c_ip, _c_st]),
+    "uavgnn_gumbel_noise": (_c_int, [_c_fp, ctypes.c_longlong, _c_int, _c_fp, _c_st]),
     "uavgnn_disc_comm_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_ip, _c_int, _c_ip, _c_ip, _c_ip, _c_int, _c_f32, _c_fp,
                                       _c_int, _c_st]),
     "uavgnn_obs_degrees": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip, _c_st]),

@@ -249,7 +249,11 @@ class EdgeConv(nn.Module):
 class DiscreteComm(nn.Module):
     """1-bit-per-channel messages via hard Gumbel-softmax (tau = 0.5), OR-aggregation (max), decoder, GRU
     (gnn_agents.py:151-193).  The logits depend on the SOURCE node only, so they are computed per node; the Gumbel
-    noise is per edge and can be injected (``gumbel`` [E, msg, 2] in CSC order) for reproducibility."""
+    noise is per edge: injected (``gumbel`` [E, msg, 2] in CSC order: fixtures carrying the reference's draws) or, by
+    default, drawn INSIDE K5 by a counter-based generator (Philox keyed by ``rng_state[0]``, counter = (CSC position,
+    channel, ``rng_state[1]``)) - the [E, msg, 2] tensor of F.gumbel_softmax's noise never exists.  ``rng_state`` is a device
+    int64 {seed, step} buffer (not part of the state_dict): seeded from torch's generator on first use, the step advances by
+    one per forward (an in-place device add: graph-capturable), so a run is reproducible from torch.manual_seed."""
 
     def __init__(self, args):
         super().__init__()
@@ -259,16 +263,22 @@ class DiscreteComm(nn.Module):
         self.f_dec = nn.Linear(2 * self._msg_size, 2 * self._msg_size)
         self.f_udt = nn.GRUCell(H + 2 * self._msg_size, H)
         self.gumbel = None   # optional injected noise, consumed by the next forward
+        self.rng_state = None
 
     def forward(self, g, x, h):
         g = _parent(g)
         H = self._hidden_size
         logits = ops.linear(x, self.f_enc.weight[:, :H], self.f_enc.bias) + ops.linear(h.detach(), self.f_enc.weight[:, H:])
         noise, self.gumbel = self.gumbel, None
+        rng = None
         if noise is None:
-            E = g.number_of_edges("talk")
-            noise = -th.empty(E, self._msg_size, 2, device=x.device, dtype=x.dtype).exponential_().log()
-        c = ops.disc_comm_aggregate(logits, noise, g, tau=0.5)
+            if self.rng_state is None or self.rng_state.device != x.device:
+                seed = int(th.randint(0, 2 ** 62, (1,)).item())      # from torch's (seedable) default generator
+                self.rng_state = th.tensor([seed, 0], dtype=th.int64, device=x.device)
+            rng = self.rng_state
+        c = ops.disc_comm_aggregate(logits, noise, g, tau=0.5, rng=rng)
+        if rng is not None:
+            rng[1:].add_(1)
         c = ops.linear(c, self.f_dec.weight, self.f_dec.bias)
         return _gru(self.f_udt, (x, c), h)
 

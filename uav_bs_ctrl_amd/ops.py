@@ -860,19 +860,23 @@ class _DiscComm(th.autograd.Function):
     """K5.  Hard Gumbel-softmax messages (straight-through) + OR (max) aggregation of DiscreteComm."""
 
     @staticmethod
-    def forward(ctx, logits, gumbel, talk_off, talk_src, t_off, t_dst, t_pos, inv_tau):
-        L.require_gpu(logits, gumbel, talk_off, talk_src)
-        logits, gumbel = L.f32c(logits), L.f32c(gumbel)
+    def forward(ctx, logits, gumbel, talk_off, talk_src, t_off, t_dst, t_pos, inv_tau, rng=None):
+        L.require_gpu(logits, gumbel, talk_off, talk_src, rng)
+        logits = L.f32c(logits)
         N, M2 = logits.shape
         M = M2 // 2
         E = talk_src.shape[0]
-        if gumbel.numel() != E * M2:
-            raise L.UavGnnError(f"disc_comm: gumbel noise must be [E={E}, msg={M}, 2]")
+        if gumbel is not None:
+            gumbel = L.f32c(gumbel)
+            if gumbel.numel() != E * M2:
+                raise L.UavGnnError(f"disc_comm: gumbel noise must be [E={E}, msg={M}, 2]")
+        elif rng is None or rng.dtype != th.int64 or rng.numel() != 2:
+            raise L.UavGnnError("disc_comm: either the Gumbel noise or a device int64 {seed, step} pair is required")
         c = th.empty((N, M2), dtype=th.float32, device=logits.device)
         y0 = th.empty((max(E, 1), M), dtype=th.float32, device=logits.device)
         sel = th.empty((N, M2), dtype=th.int32, device=logits.device)
         with KERNEL_TIMER.span("disc_comm_fwd"):
-            rc = L.lib().uavgnn_disc_comm_fwd(logits.data_ptr(), M2, gumbel.data_ptr(), M, L.ptr(talk_off),
+            rc = L.lib().uavgnn_disc_comm_fwd(logits.data_ptr(), M2, L.ptr(gumbel), L.ptr(rng), M, L.ptr(talk_off),
                                               L.ptr(talk_src), N, float(inv_tau), c.data_ptr(), M2, y0.data_ptr(),
                                               sel.data_ptr(), L.stream())
         L.check(rc, "uavgnn_disc_comm_fwd")
@@ -891,12 +895,20 @@ class _DiscComm(th.autograd.Function):
                                               L.ptr(t_off), L.ptr(t_dst), L.ptr(t_pos), N, ctx.inv_tau,
                                               d_logits.data_ptr(), d_logits.stride(0), L.stream())
         L.check(rc, "uavgnn_disc_comm_bwd")
-        return d_logits, None, None, None, None, None, None, None
+        return d_logits, None, None, None, None, None, None, None, None
 
 
-def disc_comm_aggregate(logits, gumbel, g, tau=0.5):
+def disc_comm_aggregate(logits, gumbel, g, tau=0.5, rng=None):
     """Hard Gumbel-softmax messages + OR aggregation of DiscreteComm (gnn_agents.py:166-178).  logits [N, 2*msg] per
-    source node, gumbel [E, msg, 2] in CSC order."""
+    source node; gumbel [E, msg, 2] in CSC order, or None with rng = device int64 {seed, step}: the noise is drawn inside
+    the kernel (counter-based Philox keyed by the seed, counter = (CSC position, channel, step))."""
     off, src = g.talk_csc()
     t_off, t_dst, t_pos = _talk_transpose_if_needed(g, logits)
-    return _DiscComm.apply(logits, gumbel, off, src, t_off, t_dst, t_pos, 1.0 / tau)
+    return _DiscComm.apply(logits, gumbel, off, src, t_off, t_dst, t_pos, 1.0 / tau, rng)
+
+
+def gumbel_noise(rng, E, msg):
+    """The [E, msg, 2] noise tensor the in-kernel generator of K5 draws for rng = {seed, step} (tests)."""
+    out = th.empty((E, msg, 2), dtype=th.float32, device=rng.device)
+    L.check(L.lib().uavgnn_gumbel_noise(rng.data_ptr(), E, msg, out.data_ptr(), L.stream()), "uavgnn_gumbel_noise")
+    return out
