@@ -40,13 +40,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
     k1 += 0xBB67AE85u;
   }
 }
-// the two Gumbel draws of (edge position e, channel i) at `step`: u = (24 random bits + 1/2) 2^-24 in (0, 1)
+// the two Gumbel draws of (edge position e, channel i) at `step`: u = (23 random bits + 1/2) 2^-23 in (0, 1)
 __device__ __forceinline__ float2 gumbel_pair(unsigned long long seed, unsigned long long step, int e, int i) {
   uint32_t c[4] = {static_cast<uint32_t>(e), static_cast<uint32_t>(i), static_cast<uint32_t>(step),
                    static_cast<uint32_t>(step >> 32)};
   philox4x32_10(c, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
-  const float u0 = (static_cast<float>(c[0] >> 8) + 0.5f) * 5.9604644775390625e-8f;
-  const float u1 = (static_cast<float>(c[1] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+  const float u0 = (static_cast<float>(c[0] >> 9) + 0.5f) * 1.1920928955078125e-7f;   // k + 1/2 is exact in fp32 for k < 2^23
+  const float u1 = (static_cast<float>(c[1] >> 9) + 0.5f) * 1.1920928955078125e-7f;
   return make_float2(-logf(-logf(u0)), -logf(-logf(u1)));
 }
 
