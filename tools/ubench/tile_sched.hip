@@ -196,6 +196,109 @@ __global__ __launch_bounds__(256, 2) void k_tile_bf16(const float* __restrict__ 
   if (den + s0 + s1 + s2 + s3 == 12345.f) out[0] = m;
 }
 
+// ---- round 3: the same bf16x3-in-K tile with a LEAN operand layout: lane (j, g) owns ONLY feature g of edge j.  K group g
+// (8 slots) holds the six products of feature g: A = (w1 w1 | w2 w2 | w1 w3 | 0 0), B = (x1 x2 | x1 x2 | x3 x1 | 0 0), so a
+// lane splits ONE value per tile (3 cvt + 2 and + 2 sub + 2 bfi = 9 VALU instead of two packed splits + 12 selects).
+// NOFMA = true: the |z| FMAs do not read the MFMA results (upper bound of what MFMA / VALU overlap can give).
+template <int DEPTH, bool NOFMA>
+__global__ __launch_bounds__(256, 2) void k_tile_bf16_lean(const float* __restrict__ w, float* __restrict__ out, int tiles) {
+  const int lane = threadIdx.x & 63;
+  float att[CT][4];
+  f32x4 cinit[CT];
+  u32x4 Wa[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const float wv = w[(ct * 64 + lane) & 1023];
+    const Split3 sp = split_pair(wv, wv);
+    Wa[ct] = u32x4{sp.h1, sp.h2, (sp.h1 & 0xffffu) | (sp.h3 & 0xffff0000u), 0u};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      att[ct][r] = w[(ct * 4 + r + lane) & 1023] * 0.01f;
+      cinit[ct][r] = w[(ct * 4 + r + 2 * lane) & 1023];
+    }
+  }
+  float m = -INFINITY, den = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float4 xe = make_float4(w[lane], w[lane + 1], w[lane + 2], w[lane + 3]);
+  float xg = w[lane + 7];       // the lane's own feature of its edge
+  for (int t = 0; t < tiles; ++t) {
+    // B operand of the lane's K group: one three-way split
+    bf16x2 p = __builtin_convertvector(f32x2{xg, xg}, bf16x2);
+    const unsigned h1 = __builtin_bit_cast(unsigned, p);
+    const float r1 = xg - __uint_as_float(h1 & 0xffff0000u);
+    p = __builtin_convertvector(f32x2{r1, r1}, bf16x2);
+    const unsigned h2 = __builtin_bit_cast(unsigned, p);
+    const float r2 = r1 - __uint_as_float(h2 & 0xffff0000u);
+    p = __builtin_convertvector(f32x2{r2, r2}, bf16x2);
+    const unsigned h3 = __builtin_bit_cast(unsigned, p);
+    const unsigned x12 = (h1 & 0xffffu) | (h2 & 0xffff0000u);
+    const u32x4 xb = u32x4{x12, x12, (h3 & 0xffffu) | (h1 & 0xffff0000u), 0u};
+    const bf16x8 xB = __builtin_bit_cast(bf16x8, xb);
+    float pe[4][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { pe[k][0] = att[k][0] * xg; pe[k][1] = 0.f; }
+    f32x4 z[CT];
+#pragma unroll
+    for (int ct = 0; ct < DEPTH && ct < CT; ++ct)
+      z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wa[ct]), xB, cinit[ct], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int k = ct / 4;
+      if (!NOFMA) {
+        pe[k][0] = fmaf(att[ct][0], fabsf(z[ct][0]), pe[k][0]);
+        pe[k][1] = fmaf(att[ct][1], fabsf(z[ct][1]), pe[k][1]);
+        pe[k][0] = fmaf(att[ct][2], fabsf(z[ct][2]), pe[k][0]);
+        pe[k][1] = fmaf(att[ct][3], fabsf(z[ct][3]), pe[k][1]);
+      } else {
+        pe[k][0] = fmaf(att[ct][0], fabsf(att[ct][1]), pe[k][0]);
+        pe[k][1] = fmaf(att[ct][1], fabsf(att[ct][2]), pe[k][1]);
+        pe[k][0] = fmaf(att[ct][2], fabsf(att[ct][3]), pe[k][0]);
+        pe[k][1] = fmaf(att[ct][3], fabsf(att[ct][0]), pe[k][1]);
+        if (ct == CT - 1) {
+          _Pragma("unroll") for (int c2 = 0; c2 < CT; ++c2) pe[0][0] += z[c2][0];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ct + DEPTH < CT) {
+        z[ct + DEPTH] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wa[ct + DEPTH]), xB, cinit[ct + DEPTH], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    float e = reduce_heads(pe[0][0] + pe[0][1], pe[1][0] + pe[1][1], pe[2][0] + pe[2][1], pe[3][0] + pe[3][1]);
+    const float mn = fmaxf(m, e);
+    const float sc = __builtin_amdgcn_exp2f(m - mn);
+    const float pp = __builtin_amdgcn_exp2f(e - mn);
+    den = fmaf(den, sc, pp);
+    s0 = fmaf(s0, sc, pp * xe.x);
+    s1 = fmaf(s1, sc, pp * xe.y);
+    s2 = fmaf(s2, sc, pp * xe.z);
+    s3 = fmaf(s3, sc, pp * xe.w);
+    m = mn;
+    xg = xg * 0.999f + 0.001f * pp;
+    xe.x = xe.x * 0.999f + 0.001f * pp; xe.y += 0.001f; xe.z -= 0.001f; xe.w = xe.w * 0.999f;
+  }
+  if (den + s0 + s1 + s2 + s3 == 12345.f) out[0] = m;
+}
+
+template <int DEPTH, bool NOFMA>
+void run_bf16_lean(const float* w, float* out, int wps, const char* name) {
+  const int tiles = 4000;
+  const int blocks = 256 * wps;
+  auto launch = [&] { hipLaunchKernelGGL((k_tile_bf16_lean<DEPTH, NOFMA>), dim3(blocks), dim3(256), 0, 0, w, out, tiles); };
+  launch();
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0);
+  for (int i = 0; i < 3; ++i) launch();
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1000.0 / 3;
+  const double ns = us * 1e3 / (double(tiles) * wps);
+  printf("%-48s waves/SIMD=%d  %8.1f us  %7.1f ns per tile per SIMD  (= %6.0f cyc @2.0GHz)\n", name, wps, us, ns, ns * 2.0);
+}
+
 template <int DEPTH, bool WLDS>
 void run_bf16(const float* w, float* out, int wps, const char* name) {
   const int tiles = 4000;
@@ -236,6 +339,14 @@ int main() {
     run<16, false, 0, 1>(w, out, wps, "compiler order, FMAs independent of z");
     run<16, false, 0, 3>(w, out, wps, "16 MFMA + sum(z) only (no |z| FMAs)");
     run<16, true, 0, 3>(w, out, wps, "16 MFMA + sum(z) only, pinned");
+    run_bf16_lean<1, false>(w, out, wps, "bf16x3-in-K LEAN (lane = one feature), depth 1");
+    run_bf16_lean<2, false>(w, out, wps, "bf16x3-in-K LEAN (lane = one feature), depth 2");
+    run_bf16_lean<4, false>(w, out, wps, "bf16x3-in-K LEAN (lane = one feature), depth 4");
+    run_bf16_lean<3, false>(w, out, wps, "bf16x3-in-K LEAN (lane = one feature), depth 3");
+    run_bf16_lean<6, false>(w, out, wps, "bf16x3-in-K LEAN (lane = one feature), depth 6");
+    run_bf16_lean<8, false>(w, out, wps, "bf16x3-in-K LEAN (lane = one feature), depth 8");
+    run_bf16_lean<16, false>(w, out, wps, "bf16x3-in-K LEAN (lane = one feature), depth 16");
+    run_bf16_lean<2, true>(w, out, wps, "bf16x3-in-K LEAN, FMAs independent of z, depth 2");
     run_bf16<1, false>(w, out, wps, "bf16x3-in-K score MFMA, depth 1, W in registers");
     run_bf16<2, false>(w, out, wps, "bf16x3-in-K score MFMA, depth 2, W in registers");
     run_bf16<4, false>(w, out, wps, "bf16x3-in-K score MFMA, depth 4, W in registers");

@@ -32,6 +32,9 @@
 namespace uavgnn {
 namespace {
 
+#ifndef K1_BF16Z
+#define K1_BF16Z 1    // 1: the score GEMM z = W x + c on v_mfma_f32_16x16x32_bf16 with exact three-way operand splits; 0: fp32 MFMA
+#endif
 #ifndef K1_ABLATE
 #define K1_ABLATE 0   // 1 (tools/ubench/k1_env_bench.hip only): `phases` bit 5 skips the score tile of phase N, bit 6 its row stores
 #endif
@@ -108,19 +111,82 @@ struct RelParams {   // one GATv2Conv: fc_src, fc_dst, attn, res_fc (DGL layout,
 // The instruction order is PINNED (sched_barrier): MFMA ct+1 is issued, then the four |z| FMAs of tile ct run in its
 // shadow.  Left to itself hipcc hoists / sinks the FMAs around the MFMAs and the tile takes ~10 % longer
 // (tools/ubench/tile_sched.hip: 510 vs 455-463 ns per tile per SIMD at two waves per SIMD).
-#define UAVGNN_TILE_SCORE(WA, ATT, CINIT, WLIN, XB, E_OUT)                                              \
+#if K1_BF16Z
+// ---- the score GEMM on the bf16 matrix cores -------------------------------------------------------------------------
+// fp32 MFMA on gfx950 issues at the fp32 VECTOR rate and does not overlap the VALU work of the same SIMD (measured additive:
+// profiles/r03_k1_env_ablation.txt, tools/ubench/tile_sched.hip), so the 16 fp32 MFMAs of a row tile cost as much as its
+// ~105 VALU instructions.  The K = 4 contraction is therefore laid out over the K = 32 of ONE v_mfma_f32_16x16x32_bf16 per
+// channel tile: K group g (8 slots, = lane group g on both operands) holds the six bf16 x bf16 products of feature g -
+//     A = (w1 w1 | w2 w2 | w1 w3 | 0 0)      B = (x1 x2 | x1 x2 | x3 x1 | 0 0)      w = w1 + w2 + w3, x = x1 + x2 + x3 exactly
+// (bf16x3.h: every product exact in the fp32 accumulator, the three dropped ones <= 2^-23 |w x|: one fp32 rounding).  A lane
+// owns ONE feature of its edge (the value it already loads as the fp32 B operand), so the B operand is one three-way split per
+// tile (9 VALU); the A operands are split once per wavefront (64 VGPRs instead of 16).  The destination term stays the fp32 C
+// operand.  tools/ubench/tile_sched.hip: 354 ns per tile per SIMD against 454 for the fp32 MFMA tile (2 waves per SIMD).
+typedef __bf16 k1_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 k1_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float k1_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned k1_u32x4 __attribute__((ext_vector_type(4)));
+struct K1Split { unsigned h1, h2, h3; };   // (t1 | t1 << 16) of the three terms
+__device__ __forceinline__ K1Split k1_split(float x) {
+  K1Split s;
+  k1_bf16x2 p = __builtin_convertvector(k1_f32x2{x, x}, k1_bf16x2);
+  s.h1 = __builtin_bit_cast(unsigned, p);
+  const float r1 = x - __uint_as_float(s.h1 & 0xffff0000u);
+  p = __builtin_convertvector(k1_f32x2{r1, r1}, k1_bf16x2);
+  s.h2 = __builtin_bit_cast(unsigned, p);
+  const float r2 = r1 - __uint_as_float(s.h2 & 0xffff0000u);
+  p = __builtin_convertvector(k1_f32x2{r2, r2}, k1_bf16x2);
+  s.h3 = __builtin_bit_cast(unsigned, p);
+  return s;
+}
+__device__ __forceinline__ k1_u32x4 k1_a_operand(float w) {   // (w1 w1 | w2 w2 | w1 w3 | 0 0)
+  const K1Split s = k1_split(w);
+  return k1_u32x4{s.h1, s.h2, (s.h1 & 0xffffu) | (s.h3 & 0xffff0000u), 0u};
+}
+__device__ __forceinline__ k1_bf16x8 k1_b_operand(float x) {   // (x1 x2 | x1 x2 | x3 x1 | 0 0)
+  const K1Split s = k1_split(x);
+  const unsigned x12 = (s.h1 & 0xffffu) | (s.h2 & 0xffff0000u);
+  return __builtin_bit_cast(k1_bf16x8, k1_u32x4{x12, x12, (s.h3 & 0xffffu) | (s.h1 & 0xffff0000u), 0u});
+}
+#define K1_WA_T k1_u32x4
+#define K1_WA_INIT(w) k1_a_operand(w)
+#define K1_MFMA(WA_ct, XBOP, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k1_bf16x8, WA_ct), XBOP, C, 0, 0, 0)
+#define K1_XB_OP(xb) k1_b_operand(xb)
+// phase N: the channel bias b_s + b_d rides in the free K slots (A: b1 b2 | b3 0 in the last word of lane groups 0 / 1, B: 1 1
+// | 1 0 there), so the C operand is the inline constant 0 and no register holds it
+__device__ __forceinline__ k1_u32x4 k1_a_operand_bias(float w, float bias, int g) {
+  k1_u32x4 a = k1_a_operand(w);
+  const K1Split b = k1_split(bias);
+  a[3] = g == 0 ? ((b.h1 & 0xffffu) | (b.h2 & 0xffff0000u)) : g == 1 ? (b.h3 & 0xffffu) : 0u;
+  return a;
+}
+__device__ __forceinline__ k1_bf16x8 k1_b_operand_one(float x, unsigned one_word) {
+  const K1Split s = k1_split(x);
+  const unsigned x12 = (s.h1 & 0xffffu) | (s.h2 & 0xffff0000u);
+  return __builtin_bit_cast(k1_bf16x8, k1_u32x4{x12, x12, (s.h3 & 0xffffu) | (s.h1 & 0xffff0000u), one_word});
+}
+#else
+#define K1_WA_T float
+#define K1_WA_INIT(w) (w)
+#define K1_MFMA(WA_ct, XBOP, C) __builtin_amdgcn_mfma_f32_16x16x4f32(WA_ct, XBOP, C, 0, 0, 0)
+#define K1_XB_OP(xb) (xb)
+#endif
+#define UAVGNN_TILE_SCORE(WA, ATT, CINIT, WLIN, XB, E_OUT) UAVGNN_TILE_SCORE_(WA, ATT, CINIT, WLIN, XB, K1_XB_OP(XB), E_OUT)
+#define K1_INDEX(A) A
+#define UAVGNN_TILE_SCORE_(WA, ATT, CINIT, WLIN, XB, XBOP, E_OUT)                                       \
   {                                                                                                     \
     float pe[NH][2];                                                                                    \
     _Pragma("unroll") for (int k = 0; k < NH; ++k) {                                                    \
       pe[k][0] = WLIN[k] * (XB);                                                                        \
       pe[k][1] = 0.f;                                                                                   \
     }                                                                                                   \
-    f32x4 z_cur = __builtin_amdgcn_mfma_f32_16x16x4f32(WA[0], (XB), CINIT[0], 0, 0, 0);                 \
+    const auto xb_op = XBOP;                                                                            \
+    f32x4 z_cur = K1_MFMA(WA[0], xb_op, CINIT(0));                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                 \
       f32x4 z_nxt = z_cur;                                                                              \
       if (ct + 1 < CT) {                                                                                \
-        z_nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(WA[ct + 1], (XB), CINIT[ct + 1], 0, 0, 0);         \
+        z_nxt = K1_MFMA(WA[ct + 1], xb_op, CINIT(ct + 1));                                              \
         __builtin_amdgcn_sched_barrier(0);                                                              \
       }                                                                                                 \
       const int k = ct / TPH;                                                                           \
@@ -200,32 +266,19 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
 
   // =========================== phase S: `seen` on the destinations that have in-edges ===============================
   if (it0 < N && (phases & 1) && E_seen > 0) {
-    float Wa[CT], att[CT][4], wlin[NH];
+    K1_WA_T Wa[CT];
+    float att[CT][4], wlin[NH];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      Wa[ct] = sWs[(ct * 16 + j) * FS_S + g];
+      Wa[ct] = K1_WA_INIT(sWs[(ct * 16 + j) * FS_S + g]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) att[ct][r] = c_abs * sAs[ct * 16 + 4 * g + r];
     }
 #pragma unroll
     for (int k = 0; k < NH; ++k) wlin[k] = c_lin * sWa[0][k * 4 + g];
-    // lane <-> channels 4*lane .. 4*lane+3 (head g)
-    float wd[4][2], bc[4], wr[4][2], br[4], bs[4];
-    {
-      const float4 bs4 = reinterpret_cast<const float4*>(sBss)[lane];
-      const float4 bd4 = reinterpret_cast<const float4*>(sBds)[lane];
-      const float4 wd_lo = reinterpret_cast<const float4*>(sWds)[2 * lane], wd_hi = reinterpret_cast<const float4*>(sWds)[2 * lane + 1];
-      const float4 wr_lo = reinterpret_cast<const float4*>(sWrs)[2 * lane], wr_hi = reinterpret_cast<const float4*>(sWrs)[2 * lane + 1];
-      const float4 br4 = reinterpret_cast<const float4*>(sBrs)[lane];
-      bs[0] = bs4.x; bs[1] = bs4.y; bs[2] = bs4.z; bs[3] = bs4.w;
-      bc[0] = bs4.x + bd4.x; bc[1] = bs4.y + bd4.y; bc[2] = bs4.z + bd4.z; bc[3] = bs4.w + bd4.w;
-      wd[0][0] = wd_lo.x; wd[0][1] = wd_lo.y; wd[1][0] = wd_lo.z; wd[1][1] = wd_lo.w;
-      wd[2][0] = wd_hi.x; wd[2][1] = wd_hi.y; wd[3][0] = wd_hi.z; wd[3][1] = wd_hi.w;
-      wr[0][0] = wr_lo.x; wr[0][1] = wr_lo.y; wr[1][0] = wr_lo.z; wr[1][1] = wr_lo.w;
-      wr[2][0] = wr_hi.x; wr[2][1] = wr_hi.y; wr[3][0] = wr_hi.z; wr[3][1] = wr_hi.w;
-      br[0] = br4.x; br[1] = br4.y; br[2] = br4.z; br[3] = br4.w;
-    }
-
+    // The per-destination constants of the prologue / epilogue (lane <-> channels 4*lane .. 4*lane+3: fc_dst, res_fc rows,
+    // biases) are READ FROM LDS where they are used, once per destination: the bf16 A operands take 64 VGPRs (K1_BF16Z) and
+    // 28 more registers held across the tile loop would spill.
     // inputs of the row tile that is processed next (possibly the first tile of the next destination)
     float4 xr;
     float xBn;
@@ -240,14 +293,16 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
 
     auto process = [&](const int v, const int ce0, const int cdeg, const float cxv0, const float cxv1, const int n_e0,
                        const int n_deg) {
-      float res[4];
-      f32x4 cv;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        res[r] = fmaf(wr[r][1], cxv1, fmaf(wr[r][0], cxv0, br[r]));
-        cv[r] = fmaf(wd[r][1], cxv1, fmaf(wd[r][0], cxv0, bc[r]));
+      {
+        const float4 bs4 = reinterpret_cast<const float4*>(sBss)[lane], bd4 = reinterpret_cast<const float4*>(sBds)[lane];
+        const float4 wd_lo = reinterpret_cast<const float4*>(sWds)[2 * lane], wd_hi = reinterpret_cast<const float4*>(sWds)[2 * lane + 1];
+        f32x4 cv;
+        cv[0] = fmaf(wd_lo.y, cxv1, fmaf(wd_lo.x, cxv0, bs4.x + bd4.x));
+        cv[1] = fmaf(wd_lo.w, cxv1, fmaf(wd_lo.z, cxv0, bs4.y + bd4.y));
+        cv[2] = fmaf(wd_hi.y, cxv1, fmaf(wd_hi.x, cxv0, bs4.z + bd4.z));
+        cv[3] = fmaf(wd_hi.w, cxv1, fmaf(wd_hi.z, cxv0, bs4.w + bd4.w));
+        *reinterpret_cast<f32x4*>(cw + 4 * lane) = cv;
       }
-      *reinterpret_cast<f32x4*>(cw + 4 * lane) = cv;
       wave_sync_lds();
       f32x4 cinit[CT];   // C operand: destination term for channels ct*16 + 4g + r
 #pragma unroll
@@ -263,7 +318,8 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
           request(more ? ce0 + base + 16 : n_e0, more ? cdeg - base - 16 : n_deg);
         }
         float e;
-        UAVGNN_TILE_SCORE(Wa, att, cinit, wlin, xB, e)
+#define K1_CINIT_S(ct) cinit[ct]
+        UAVGNN_TILE_SCORE(Wa, att, K1_CINIT_S, wlin, xB, e)
         if (valid) {
           if (a_save_s != nullptr) a_save_s[static_cast<size_t>(ce0 + base + j) * NH + g] = e;
           const float mn = fmaxf(m, e);
@@ -297,6 +353,11 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
       // ---- epilogue: lane <-> 4 consecutive channels of head g; every lane of the row holds sv already -------
       float4 o;
       float* op = reinterpret_cast<float*>(&o);
+      const float4 bs4 = reinterpret_cast<const float4*>(sBss)[lane], br4 = reinterpret_cast<const float4*>(sBrs)[lane];
+      const float4 wr_lo = reinterpret_cast<const float4*>(sWrs)[2 * lane], wr_hi = reinterpret_cast<const float4*>(sWrs)[2 * lane + 1];
+      const float bs[4] = {bs4.x, bs4.y, bs4.z, bs4.w};
+      const float res[4] = {fmaf(wr_lo.y, cxv1, fmaf(wr_lo.x, cxv0, br4.x)), fmaf(wr_lo.w, cxv1, fmaf(wr_lo.z, cxv0, br4.y)),
+                            fmaf(wr_hi.y, cxv1, fmaf(wr_hi.x, cxv0, br4.z)), fmaf(wr_hi.w, cxv1, fmaf(wr_hi.z, cxv0, br4.w))};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const f32x4 w = *reinterpret_cast<const f32x4*>(sWs + (4 * lane + r) * FS_S);
@@ -349,39 +410,58 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
 
   // ================= phase N: `near`, two destinations per row tile, + residual-only `seen` rows ====================
   if (phases & 2) {
-    float Wa[CT], att[CT][4], wlin[NH];
+    K1_WA_T Wa[CT];
+    float att[CT][4], wlin[NH];
+#if K1_BF16Z
+    const unsigned one_word = g == 0 ? 0x3F803F80u : g == 1 ? 0x00003F80u : 0u;   // bf16 1.0 against the bias slots of the A operand
+    const f32x4 czero = {0.f, 0.f, 0.f, 0.f};
+#define K1_CINIT_N(ct) czero
+#define K1_XBOP_N(xb) k1_b_operand_one(xb, one_word)
+#else
     f32x4 cconst[CT];
+#define K1_CINIT_N(ct) cconst[ct]
+#define K1_XBOP_N(xb) (xb)
+#endif
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int row = ct * 16 + j;
-      Wa[ct] = (g < 2) ? sWn[row * FS_N + g] : sWdn[row * 2 + (g - 2)];
+      const float wv = (g < 2) ? sWn[row * FS_N + g] : sWdn[row * 2 + (g - 2)];
+#if K1_BF16Z
+      Wa[ct] = k1_a_operand_bias(wv, sBCn[row], g);
+#else
+      Wa[ct] = wv;
+#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ch = ct * 16 + 4 * g + r;
         att[ct][r] = c_abs * sAn[ch];
+#if !K1_BF16Z
         cconst[ct][r] = sBCn[ch];
+#endif
       }
     }
 #pragma unroll
     for (int k = 0; k < NH; ++k) wlin[k] = (g < 2) ? c_lin * sWa[1][k * 4 + g] : 0.f;
     // epilogue constants, lane <-> channels 4*lane .. 4*lane+3
-    float ws[4][2], bsn[4], wrn[4][2], brn[4], wrs[4][2], brs[4];
-    {
-      const float4 bs4 = reinterpret_cast<const float4*>(sBsn)[lane];
-      const float4 ws_lo = reinterpret_cast<const float4*>(sWn)[2 * lane], ws_hi = reinterpret_cast<const float4*>(sWn)[2 * lane + 1];
-      const float4 wn_lo = reinterpret_cast<const float4*>(sWrn)[2 * lane], wn_hi = reinterpret_cast<const float4*>(sWrn)[2 * lane + 1];
-      const float4 wq_lo = reinterpret_cast<const float4*>(sWrs)[2 * lane], wq_hi = reinterpret_cast<const float4*>(sWrs)[2 * lane + 1];
-      const float4 bn4 = reinterpret_cast<const float4*>(sBrn)[lane], bq4 = reinterpret_cast<const float4*>(sBrs)[lane];
-      bsn[0] = bs4.x; bsn[1] = bs4.y; bsn[2] = bs4.z; bsn[3] = bs4.w;
-      ws[0][0] = ws_lo.x; ws[0][1] = ws_lo.y; ws[1][0] = ws_lo.z; ws[1][1] = ws_lo.w;
-      ws[2][0] = ws_hi.x; ws[2][1] = ws_hi.y; ws[3][0] = ws_hi.z; ws[3][1] = ws_hi.w;
-      wrn[0][0] = wn_lo.x; wrn[0][1] = wn_lo.y; wrn[1][0] = wn_lo.z; wrn[1][1] = wn_lo.w;
-      wrn[2][0] = wn_hi.x; wrn[2][1] = wn_hi.y; wrn[3][0] = wn_hi.z; wrn[3][1] = wn_hi.w;
-      wrs[0][0] = wq_lo.x; wrs[0][1] = wq_lo.y; wrs[1][0] = wq_lo.z; wrs[1][1] = wq_lo.w;
-      wrs[2][0] = wq_hi.x; wrs[2][1] = wq_hi.y; wrs[3][0] = wq_hi.z; wrs[3][1] = wq_hi.w;
-      brn[0] = bn4.x; brn[1] = bn4.y; brn[2] = bn4.z; brn[3] = bn4.w;
-      brs[0] = bq4.x; brs[1] = bq4.y; brs[2] = bq4.z; brs[3] = bq4.w;
-    }
+#define K1_EPI_CONSTS                                                                                                              \
+      float ws[4][2], bsn[4], wrn[4][2], brn[4], wrs[4][2], brs[4];                                                                \
+      {                                                                                                                            \
+        const float4 bs4 = reinterpret_cast<const float4*>(sBsn)[lane];                                                            \
+        const float4 ws_lo = reinterpret_cast<const float4*>(sWn)[2 * lane], ws_hi = reinterpret_cast<const float4*>(sWn)[2 * lane + 1];   \
+        const float4 wn_lo = reinterpret_cast<const float4*>(sWrn)[2 * lane], wn_hi = reinterpret_cast<const float4*>(sWrn)[2 * lane + 1]; \
+        const float4 wq_lo = reinterpret_cast<const float4*>(sWrs)[2 * lane], wq_hi = reinterpret_cast<const float4*>(sWrs)[2 * lane + 1]; \
+        const float4 bn4 = reinterpret_cast<const float4*>(sBrn)[lane], bq4 = reinterpret_cast<const float4*>(sBrs)[lane];          \
+        bsn[0] = bs4.x; bsn[1] = bs4.y; bsn[2] = bs4.z; bsn[3] = bs4.w;                                                            \
+        ws[0][0] = ws_lo.x; ws[0][1] = ws_lo.y; ws[1][0] = ws_lo.z; ws[1][1] = ws_lo.w;                                            \
+        ws[2][0] = ws_hi.x; ws[2][1] = ws_hi.y; ws[3][0] = ws_hi.z; ws[3][1] = ws_hi.w;                                            \
+        wrn[0][0] = wn_lo.x; wrn[0][1] = wn_lo.y; wrn[1][0] = wn_lo.z; wrn[1][1] = wn_lo.w;                                        \
+        wrn[2][0] = wn_hi.x; wrn[2][1] = wn_hi.y; wrn[3][0] = wn_hi.z; wrn[3][1] = wn_hi.w;                                        \
+        wrs[0][0] = wq_lo.x; wrs[0][1] = wq_lo.y; wrs[1][0] = wq_lo.z; wrs[1][1] = wq_lo.w;                                        \
+        wrs[2][0] = wq_hi.x; wrs[2][1] = wq_hi.y; wrs[3][0] = wq_hi.z; wrs[3][1] = wq_hi.w;                                        \
+        brn[0] = bn4.x; brn[1] = bn4.y; brn[2] = bn4.z; brn[3] = bn4.w;                                                            \
+        brs[0] = bq4.x; brs[1] = bq4.y; brs[2] = bq4.z; brs[3] = bq4.w;                                                            \
+      }
+    K1_EPI_CONSTS
     const int half = j >> 3, slot = j & 7;
     const int P = (N + 1) >> 1;     // destination pairs (2p, 2p+1)
 
@@ -440,7 +520,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
 #if K1_ABLATE
           if (phases & 32) e = xB; else
 #endif
-          UAVGNN_TILE_SCORE(Wa, att, cconst, wlin, xB, e)
+          UAVGNN_TILE_SCORE_(Wa, att, K1_CINIT_N, wlin, xB, K1_XBOP_N(xB), e)
           if (valid) {
             if (a_save_n != nullptr) a_save_n[static_cast<size_t>(my_e0 + base + slot) * NH + g] = e;
             const float mn = fmaxf(m, e);
