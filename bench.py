@@ -112,10 +112,10 @@ def alg_k1_fwd(E_s, E_n, N, save_s, save_n):
 
 
 def measured_traffic(dist_name, n_inf, n_tr, B, n, M):
-    """HBM bytes per fused K1 launch from the committed rocprofv3 PMC passes (profiles/r02_k1_hetero_traffic.json; method
+    """HBM bytes per fused K1 launch from the committed rocprofv3 PMC passes (profiles/r03_k1_hetero_traffic.json; method
     and gfx950 correction are documented there), averaged over the inference / training launches of a step like
     ``achieved``.  (None, None) when the workload is not the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r02_k1_hetero_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_k1_hetero_traffic.json")
     if not os.path.exists(path) or (B, n, M) != (4096, 8, 80):
         return None, None
     t = json.load(open(path)).get(dist_name)
@@ -123,7 +123,7 @@ def measured_traffic(dist_name, n_inf, n_tr, B, n, M):
         return None, None
     by = {k: (2.0 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0 for k, v in t.items()}
     src = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/k1_run.py on this workload, stamped in "
-           "profiles/r02_k1_hetero_traffic.json (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not "
+           "profiles/r03_k1_hetero_traffic.json (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not "
            "collected inside this run")
     return (n_inf * by["inference"] + n_tr * by["training"]) / (n_inf + n_tr), src
 
@@ -512,15 +512,16 @@ def main():
         if sec:
             res["roofline_secondary"] = sec
         res["kernel_ms_per_launch"] = {n: round(v["avg_ms"], 4) for n, v in ktimes.items()}
-        res["arithmetic"] = ("fp32 in / out / accumulate everywhere.  K1, K3b, K5 and all pointwise kernels: fp32 FMA / fp32 MFMA.  "
-                             "GRU cell (csrc/gru_x3.hip) and the dense layers whose output tiles by 128 columns (csrc/gemm_x3.hip): "
-                             "each fp32 operand is split EXACTLY into 3 bf16 terms and each fp32 product is the fp32-accumulated "
-                             "sum of 6 exact bf16 x bf16 MFMA products (dropped terms <= 2^-23 |a b|); measured error vs fp64 is "
-                             "BELOW the vendor fp32 GEMM's on the same data (profiles/r02_gemm_x3_probe.txt, "
-                             "profiles/r02_gru_probe_fused_vs_vendor.txt).  `fp32_mfma_leg` is the same cycle with those two "
-                             "kernels switched to fp32 MFMA / vendor fp32 GEMMs (UAVGNN_GRU_X3=0 UAVGNN_GEMM_X3=0).")
+        res["arithmetic"] = ("fp32 in / out / accumulate everywhere.  K3b, K5 and all pointwise kernels: fp32 FMA.  The score GEMM of K1 "
+                             "(csrc/gatv2_hetero.hip), the GRU cell (csrc/gru_x3.hip), the dense layers whose output tiles by 128 "
+                             "columns (csrc/gemm_x3.hip) and the time-batched encoder weight gradient (csrc/gemm_tn_x3.hip): each "
+                             "fp32 operand is split EXACTLY into 3 bf16 terms and each fp32 product is the fp32-accumulated sum of 6 "
+                             "exact bf16 x bf16 MFMA products (dropped terms <= 2^-23 |a b|); measured error vs fp64 is BELOW the "
+                             "vendor fp32 GEMM's on the same data (profiles/r02_gemm_x3_probe.txt, profiles/r03_gru_probe.txt, "
+                             "profiles/r03_gemm_tn_probe.txt).  `fp32_mfma_leg` is the same cycle with all of them switched to fp32 "
+                             "MFMA / vendor fp32 GEMMs (UAVGNN_GRU_X3=0 UAVGNN_GEMM_X3=0 UAVGNN_K1_BF16Z=0).")
         if world == 1 and not a.no_fp32_leg:
-            ops.GRU_X3 = ops.GEMM_X3 = False
+            ops.GRU_X3 = ops.GEMM_X3 = ops.K1_BF16Z = False
             try:
                 step()
                 th.cuda.synchronize()
@@ -534,10 +535,11 @@ def main():
                 gc.enable()
                 res["fp32_mfma_leg"] = {"value": world * a.B * a.T * 5 / e1, "unit": "env-steps/s", "steps": 5,
                                         "ms_per_step": 1e3 * e1 / 5,
-                                        "config": "UAVGNN_GRU_X3=0 UAVGNN_GEMM_X3=0: GRU cell on fp32 MFMA (csrc/gru_fused.hip), "
-                                                  "every dense layer on the vendor fp32 GEMM"}
+                                        "config": "UAVGNN_GRU_X3=0 UAVGNN_GEMM_X3=0 UAVGNN_K1_BF16Z=0: GRU cell on fp32 MFMA "
+                                                  "(csrc/gru_fused.hip), every dense layer on the vendor fp32 GEMM, K1's score GEMM "
+                                                  "on fp32 MFMA (csrc/gatv2_hetero_f32.hip): no bf16 instruction anywhere"}
             finally:
-                ops.GRU_X3 = ops.GEMM_X3 = True
+                ops.GRU_X3 = ops.GEMM_X3 = ops.K1_BF16Z = True
         if world == 1 and not a.no_rho_leg:
             # the reference's own replay ratio (run.py:55-57,:97: 32 stored sequences per T steps of one environment):
             # T act forwards on B environments + ONE optimizer step over rho chunks of B sequences (gradient accumulation)

@@ -88,7 +88,9 @@ int uavgnn_gatv2_hetero_fwd(const float* x_gt, int E_seen, const int32_t* seen_o
                             uavgnn_stream_t stream);
 /* Same contract with only some phases of the kernel executed (bit 0: `seen` row tiles of the non-isolated destinations,
  * bit 1: `near` + residual-only `seen` rows); phases = 3 is uavgnn_gatv2_hetero_fwd.  In-library ablation reference for
- * benchmarks - output rows of the skipped phase are left untouched. */
+ * benchmarks - output rows of the skipped phase are left untouched.  Bit 8 (256): the score GEMM of both phases on fp32 MFMA
+ * (csrc/gatv2_hetero_f32.hip) instead of the bf16 matrix cores with exact three-way operand splits - same results to fp32
+ * rounding; the A/B reference and the strict-fp32 leg of bench.py. */
 int uavgnn_gatv2_hetero_fwd_phases(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order,
                                    const float* x_ubs, int E_near, const int32_t* near_off, const float* x_dst, int N,
                                    const float* const* seen_params, const float* const* near_params, int nh, int D,

@@ -1318,6 +1318,41 @@ def test_fused_hetero_k1_equals_per_relation_kernels(B, n, M, dist, seed):
         assert_close(gf[k], gp[k], 2e-5, f"grad {k} through fused-forward attention weights", floor=1e-6)
 
 
+def test_fused_hetero_k1_bf16_score_gemm_equals_the_fp32_mfma_build(monkeypatch):
+    """The score GEMM of the fused K1 forward on the bf16 matrix cores (exact three-way operand splits, six products per fp32
+    product; phase N with the channel bias in the free K slots) against the fp32-MFMA build of the same kernel
+    (csrc/gatv2_hetero_f32.hip, phases bit 8): output rows and saved attention weights to fp32 rounding, on dense, env and
+    ragged degree distributions - and the fp32 build really is a different kernel."""
+    from uav_bs_ctrl_amd import ops
+    from uav_bs_ctrl_amd.agents.gnn_agents import GraphObservationEncoder
+    import types
+    th.manual_seed(3)
+    enc = GraphObservationEncoder(dict(agent=2, ubs=2, gt=4), types.SimpleNamespace(n_heads=4, hidden_size=256)).cuda()
+    with th.no_grad():
+        for c in enc.f_conv.values():
+            for b in (c.fc_src.bias, c.fc_dst.bias, c.res_fc.bias):
+                b.normal_(0, 0.1)
+    for dist_name, B, n, M in (("dense", 64, 8, 80), ("env", 256, 8, 80), ("ragged", 33, 5, 200)):
+        hb = to_batch(synth_graph(B, n, M, dist_name, seed=B))
+        rels = [(*hb.relation_segments(et), hb.relation_order(et), enc.f_conv[et]) for et in ("seen", "near")]
+        outs = []
+        for flag in (True, False):
+            monkeypatch.setattr(ops, "K1_BF16Z", flag)
+            with th.no_grad():
+                outs.append(ops.hetero_gatv2(hb.agent_feat(), 4, rels))
+        assert not th.equal(outs[0], outs[1]), "both arms ran the same kernel"
+        assert_close(outs[0], outs[1], 2e-6, f"{dist_name}: bf16x3 score GEMM vs fp32 MFMA")
+        xa = hb.agent_feat().clone().requires_grad_(False)
+        monkeypatch.setattr(ops, "K1_BF16Z", True)
+        o1 = ops.hetero_gatv2(xa, 4, rels)
+        g1 = th.autograd.grad(o1.square().sum(), [enc.f_conv["seen"].fc_src.weight, enc.f_conv["near"].attn])
+        monkeypatch.setattr(ops, "K1_BF16Z", False)
+        o2 = ops.hetero_gatv2(xa, 4, rels)
+        g2 = th.autograd.grad(o2.square().sum(), [enc.f_conv["seen"].fc_src.weight, enc.f_conv["near"].attn])
+        for a, b in zip(g1, g2):
+            assert_close(a, b, 1e-5, f"{dist_name}: gradients through the saved attention weights")
+
+
 def test_fused_hetero_k1_raw_rows_vs_oracle():
     """The [N, 2H] row block of the fused launch against the float64 oracle, relation by relation (before f_aggr)."""
     from uav_bs_ctrl_amd import ops

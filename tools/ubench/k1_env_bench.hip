@@ -3,6 +3,7 @@
 // variants can be compared for equality.  argv[1]: dist (env | dense | zero), argv[2]: B (default 4096).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iuav_bs_ctrl_amd/csrc [-D...] tools/ubench/k1_env_bench.hip -o tools/ubench/bin/k1_env_bench
 #define K1_ABLATE 1
+#define K1_STANDALONE 1
 #include "../../uav_bs_ctrl_amd/csrc/gatv2_hetero.hip"
 #include <algorithm>
 #include <cstdio>

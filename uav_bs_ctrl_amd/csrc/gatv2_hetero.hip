@@ -6,7 +6,7 @@
 // Every persistent wavefront runs two phases:
 //
 //  S  the `seen` relation of the destinations that HAVE in-edges, one destination at a time on 16-edge row tiles - the
-//     formulation of gatv2_mfma.hip (Z^T = W_s X^T + c[v] on v_mfma_f32_16x16x4_f32, |z| half of the leaky ReLU as one
+//     formulation of gatv2_mfma.hip (Z^T = W_s X^T + c[v] on the matrix cores, |z| half of the leaky ReLU as one
 //     |.|-modifier FMA per channel, permlane head reduction, log2-domain online softmax, input-space aggregation) with
 //     three changes: lane <-> FOUR CONSECUTIVE channels in the per-destination prologue / epilogue (one 16-byte LDS
 //     write, five 16-byte LDS reads and one 16-byte row store instead of 4 + 32 + 4 dword operations), the first row tile
@@ -25,7 +25,9 @@
 //     where one destination per tile wastes 9/16 and the lane <-> channel kernel (gatv2_small.hip) spends ~350 VALU
 //     instructions per destination.
 //
-// fp32 MFMA is bit-for-bit an fmaf chain, so numerics equal the per-relation kernels' up to summation order.
+// Arithmetic: fp32 in / out / accumulate.  The score GEMM runs on the bf16 matrix cores as six exact bf16 products per fp32
+// product (K1_BF16Z, below): results equal the per-relation fp32-MFMA kernels' to fp32 rounding (1e-9 relative on the output
+// checksum), not bit for bit.
 // Instantiated for D = 64 (H = 256: every BASELINE configuration); other shapes use the per-relation kernels.
 #include "common.h"
 
@@ -606,11 +608,41 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
 
 using namespace uavgnn;
 
+// The file is compiled twice: as itself (score GEMM on the bf16 matrix cores) and through gatv2_hetero_f32.hip
+// (-> K1_BF16Z = 0, K1_F32_TU: the fp32-MFMA score GEMM of rounds 1-2, reachable as phases bit 8 = the A/B and strict-fp32 leg).
+namespace uavgnn {
+#if defined(K1_F32_TU)
+int gatv2_hetero_launch_f32(
+#else
+int gatv2_hetero_launch_f32(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order, const float* x_ubs,
+                            const int32_t* near_off, const float* x_dst, int N, const float* const* seen_params,
+                            const float* const* near_params, float slope, float* out, int ld_out, float* attn_save_seen,
+                            float* attn_save_near, int phases, hipStream_t st);
+static int gatv2_hetero_launch(
+#endif
+    const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order, const float* x_ubs,
+    const int32_t* near_off, const float* x_dst, int N, const float* const* seen_params, const float* const* near_params,
+    float slope, float* out, int ld_out, float* attn_save_seen, float* attn_save_near, int phases, hipStream_t st) {
+  RelParams ps{seen_params[0], seen_params[1], seen_params[2], seen_params[3], seen_params[4], seen_params[5], seen_params[6]};
+  RelParams pn{near_params[0], near_params[1], near_params[2], near_params[3], near_params[4], near_params[5], near_params[6]};
+  int grid = capped_grid(N, kWavesPerBlock, 512);   // persistent: 2 workgroups per CU
+#if K1_ABLATE
+  if (const char* gs = getenv("K1_GRID")) grid = atoi(gs);
+#endif
+  hipLaunchKernelGGL(gatv2_hetero_fwd_kernel, dim3(grid), dim3(kThreads), 0, st, x_gt, seen_off, seen_order, x_ubs, near_off,
+                     x_dst, N, E_seen, ps, pn, slope, out, ld_out, attn_save_seen, attn_save_near,
+                     K1_ABLATE ? phases : (phases & 3));
+  return launch_status();
+}
+}  // namespace uavgnn
+
+#if !defined(K1_F32_TU)
 extern "C" int uavgnn_gatv2_hetero_supported(int F_seen, int F_near, int F_dst, int nh, int D) {
   return (F_seen == FS_S && F_near == FS_N && F_dst == 2 && nh == NH && D == ::uavgnn::D) ? 1 : 0;
 }
 
-// phases: bit 0 = phase S, bit 1 = phase N.  3 = the kernel; 1 / 2 are benchmark ablations (tools/kbench_hetero.py).
+// phases: bit 0 = phase S, bit 1 = phase N (3 = the kernel; 1 / 2 are benchmark ablations, tools/kbench_hetero.py);
+// bit 8 (UAVGNN_K1_FP32_MFMA) = the score GEMM on fp32 MFMA instead of the bf16 matrix cores.
 extern "C" int uavgnn_gatv2_hetero_fwd_phases(const float* x_gt, int E_seen, const int32_t* seen_off,
                                               const int32_t* seen_order, const float* x_ubs, int E_near,
                                               const int32_t* near_off, const float* x_dst, int N,
@@ -630,19 +662,16 @@ extern "C" int uavgnn_gatv2_hetero_fwd_phases(const float* x_gt, int E_seen, con
     if ((reinterpret_cast<uintptr_t>(seen_params[i]) & 15) || (reinterpret_cast<uintptr_t>(near_params[i]) & 15))
       return UAVGNN_EUNSUPPORTED;
   if (N == 0) return 0;
-  RelParams ps{seen_params[0], seen_params[1], seen_params[2], seen_params[3], seen_params[4], seen_params[5], seen_params[6]};
-  RelParams pn{near_params[0], near_params[1], near_params[2], near_params[3], near_params[4], near_params[5], near_params[6]};
-  int grid = capped_grid(N, kWavesPerBlock, 512);   // persistent: 2 workgroups per CU
-#if K1_ABLATE
-  if (const char* gs = getenv("K1_GRID")) grid = atoi(gs);
-#endif
   if (E_near == 0) x_ubs = x_dst;   // masked slots read row 0 of x_ubs: any valid address will do when there are no edges
-  hipLaunchKernelGGL(gatv2_hetero_fwd_kernel, dim3(grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream), x_gt,
-                     seen_off, seen_order, x_ubs, near_off, x_dst, N, E_seen, ps, pn, slope, out, ld_out, attn_save_seen,
-                     attn_save_near, K1_ABLATE ? phases : (phases & 3));
-  return launch_status();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#if !defined(K1_STANDALONE)
+  if (phases & 256)
+    return gatv2_hetero_launch_f32(x_gt, E_seen, seen_off, seen_order, x_ubs, near_off, x_dst, N, seen_params, near_params,
+                                   slope, out, ld_out, attn_save_seen, attn_save_near, phases, st);
+#endif
+  return gatv2_hetero_launch(x_gt, E_seen, seen_off, seen_order, x_ubs, near_off, x_dst, N, seen_params, near_params, slope,
+                             out, ld_out, attn_save_seen, attn_save_near, phases, st);
 }
-
 
 extern "C" int uavgnn_gatv2_hetero_fwd(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order,
                                        const float* x_ubs, int E_near, const int32_t* near_off, const float* x_dst, int N,
@@ -652,3 +681,4 @@ extern "C" int uavgnn_gatv2_hetero_fwd(const float* x_gt, int E_seen, const int3
   return uavgnn_gatv2_hetero_fwd_phases(x_gt, E_seen, seen_off, seen_order, x_ubs, E_near, near_off, x_dst, N, seen_params,
                                         near_params, nh, D_, slope, out, ld_out, attn_save_seen, attn_save_near, 3, stream);
 }
+#endif

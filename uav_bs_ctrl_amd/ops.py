@@ -12,6 +12,9 @@ from . import _lib as L
 
 NEG_SLOPE = 0.2  # DGL GATv2Conv default, not overridden at gnn_agents.py:93-96
 HETERO_FUSED = True   # K1 forward of both encoder relations in one launch (csrc/gatv2_hetero.hip); False: per relation
+# K1's score GEMM on the bf16 matrix cores (exact three-way splits: fp32-level accuracy); False: the fp32-MFMA build of the same
+# kernel (csrc/gatv2_hetero_f32.hip) - the A/B reference and the K1 part of bench.py's strict-fp32 leg
+K1_BF16Z = os.environ.get("UAVGNN_K1_BF16Z", "1") != "0"
 
 
 class _KernelTimer:
@@ -98,10 +101,10 @@ class _HeteroGATv2(th.autograd.Function):
         if fused:
             (xs, so, oo, pS, brS, needS, aS, _, _), (xn, no, _, pN, brN, needN, aN, _, _) = prepared
             with KERNEL_TIMER.span("gatv2_hetero_fwd", (xs.shape[0], xn.shape[0], N, int(needS), int(needN))):
-                rc = L.lib().uavgnn_gatv2_hetero_fwd(L.ptr(xs), xs.shape[0], L.ptr(so), L.ptr(oo), L.ptr(xn), xn.shape[0],
-                                                     L.ptr(no), L.ptr(x_dst), N, L.ptr_array(pS + [brS]),
-                                                     L.ptr_array(pN + [brN]), nh, D, NEG_SLOPE, out.data_ptr(), R * H,
-                                                     L.ptr(aS), L.ptr(aN), L.stream())
+                rc = L.lib().uavgnn_gatv2_hetero_fwd_phases(L.ptr(xs), xs.shape[0], L.ptr(so), L.ptr(oo), L.ptr(xn), xn.shape[0],
+                                                            L.ptr(no), L.ptr(x_dst), N, L.ptr_array(pS + [brS]),
+                                                            L.ptr_array(pN + [brN]), nh, D, NEG_SLOPE, out.data_ptr(), R * H,
+                                                            L.ptr(aS), L.ptr(aN), 3 if K1_BF16Z else 3 | 256, L.stream())
             if rc == L.UAVGNN_EUNSUPPORTED:
                 fused = False
             else:
