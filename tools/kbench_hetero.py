@@ -92,14 +92,15 @@ def main():
         err = float((out - out2).abs().max()) / max(float(out2.abs().max()), 1e-30)
         erra = max(float((a_s - a_s2).abs().max()) if xs.shape[0] else 0.0, float((a_n - a_n2).abs().max()))
         Es, En = xs.shape[0], xn.shape[0]
-        for name, fn, sv in (("fused", fused, False), ("  phase S only", phase(1), False), ("  phase N only", phase(2), False),
+        for name, fn, sv in (("fused", fused, False), ("fused, fp32-MFMA score GEMM", phase(3 | 256), False),
+                             ("  phase S only", phase(1), False), ("  phase N only", phase(2), False),
                              ("  no phase (start-up only)", phase(0), False), ("per relation (2 launches)", split, False),
                              ("fused + save", fused, True), ("per relation + save", split, True)):
             args = (out, a_s.data_ptr(), a_n.data_ptr()) if sv else (out, None, None)
             ms = time_ms(lambda: fn(*args), a.reps)
             by = 16 * Es + 8 * En + N * (8 + 8 + 2048) + (16 * (Es + En) if sv else 0)
             fl = 3360 * Es + 2320 * En + 7168 * N
-            print(f"K1 fwd both relations {dist:5s} {name:26s} {ms * 1e3:8.2f} {by / ms / 1e6:9.1f} {by / ms / 1e6 / 80:6.2f} "
+            print(f"K1 fwd both relations {dist:5s} {name:28s} {ms * 1e3:8.2f} {by / ms / 1e6:9.1f} {by / ms / 1e6 / 80:6.2f} "
                   f"{fl / ms / 1e9:8.2f} {fl / ms / 1e9 / 1.573:6.2f}")
         print(f"    max rel diff fused vs per relation: out {err:.2e}  attn {erra:.2e}   (E_seen={Es}, E_near={En}, N={N})")
 
