@@ -1353,7 +1353,7 @@ def test_fused_hetero_k1_bf16_score_gemm_equals_the_fp32_mfma_build(monkeypatch)
             assert_close(a, b, 1e-5, f"{dist_name}: gradients through the saved attention weights")
 
 
-def test_fused_hetero_k1_raw_rows_vs_oracle():
+def test_fused_hetero_k1_raw_rows_vs_oracle(monkeypatch):
     """The [N, 2H] row block of the fused launch against the float64 oracle, relation by relation (before f_aggr)."""
     from uav_bs_ctrl_amd import ops
     from uav_bs_ctrl_amd.agents.gnn_agents import GATv2Conv
@@ -1372,10 +1372,21 @@ def test_fused_hetero_k1_raw_rows_vs_oracle():
         rels.append((xs, off, hb.relation_order(et), c))
     with th.no_grad():
         out = ops.hetero_gatv2(hb.agent_feat(), 4, rels)
+        monkeypatch.setattr(ops, "K1_BF16Z", False)
+        out_f32 = ops.hetero_gatv2(hb.agent_feat(), 4, rels)       # the fp32-MFMA build of the same kernel
+    errs = {}
     for i, (et, kx, ko, c) in enumerate((("seen", "x_gt", "seen_off", convs[0]), ("near", "x_ubs", "near_off", convs[1]))):
         p64 = {k: v.detach().cpu().double() for k, v in c.state_dict().items()}
         ref = R.gatv2_conv_seg(g[kx].double(), g["x_a"].double(), g[ko], p64, 4).reshape(320, -1)
         assert_close(out[:, 256 * i:256 * (i + 1)], ref, 1e-5, f"fused rows, relation {et}")
+        assert_close(out_f32[:, 256 * i:256 * (i + 1)], ref, 1e-5, f"fused rows (fp32-MFMA build), relation {et}")
+        scale = float(ref.abs().max())
+        errs[et] = (float((out[:, 256 * i:256 * (i + 1)].cpu().double() - ref).abs().max()) / scale,
+                    float((out_f32[:, 256 * i:256 * (i + 1)].cpu().double() - ref).abs().max()) / scale)
+    # "fp32 accuracy" of the bf16-matrix-core score GEMM, measured: its error against float64 is of the size of the fp32-MFMA
+    # build's on the same data (both ~1e-7 of max|row|)
+    for et, (e_bf16, e_f32) in errs.items():
+        assert e_bf16 <= 2.0 * e_f32 + 2e-7, (et, e_bf16, e_f32)
 
 
 def test_fused_adamw_clip_polyak_kernel_matches_torch_and_checkpoints_interchange():
