@@ -350,12 +350,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    # test hooks (tests/test_dp_gpu.py): all ranks on ONE device over gloo, so that the world-size-2 code path of this file
+    # runs on a one-GPU box (RCCL refuses two ranks on one device).  Never set by the driver: one rank per GPU over RCCL.
+    backend = os.environ.get("UAVGNN_BENCH_BACKEND", "nccl")
+    if os.environ.get("UAVGNN_BENCH_ONE_DEVICE") == "1":
+        local = 0
     th.cuda.set_device(local)
     device = th.device("cuda", local)
     use_dist = world > 1 or (a.force_dist and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from uav_bs_ctrl_amd import enable_tuned_gemms, ops
     from uav_bs_ctrl_amd.learner import MultiAgentQLearner, params_checksum
@@ -428,7 +436,8 @@ def main():
             "config": {"workload": f"{label}: {a.n} UBS x {a.M} GT, exp3 MADRQN (GATv2 obs-encoder + TarMAC), "
                                    f"B={a.B} env graphs/GPU, T={a.T}, D-{a.dist}, replay ratio 1: one step = {a.T} "
                                    f"act forwards + 1 update ({2 * a.T + 1} forwards + BPTT backward + AdamW)",
-                       "global_batch": world * a.B, "seq_len": a.T, "parallelism": f"dp{world}"},
+                       "global_batch": world * a.B, "seq_len": a.T, "parallelism": f"dp{world}",
+                       **({} if backend == "nccl" else {"collective_backend": backend + " (test hook, not RCCL)"})},
             "loss": loss,
             "params_checksum": [float(ck[0]), float(ck[1])],   # sum / sum of squares of the policy parameters after the timed steps
             "step_ms_device": [round(marks[i - 1].elapsed_time(marks[i]), 1) for i in range(1, len(marks))],
