@@ -392,7 +392,11 @@ def main():
             dist.barrier()
         th.cuda.synchronize()
 
-    ops.KERNEL_TIMER.reset(enabled=True)   # warm-up runs instrumented too, so the event pool exists before timing
+    # Inside the timed region only the GRADED kernel (K1 forward) carries HIP events: timing every launch costs the launch thread
+    # ~15 us per launch and makes the rollout phase host-bound (tools/launch_bound_probe.py: 21 -> 29 ms per 50 act forwards).
+    # The other kernels are timed in ONE extra, fully instrumented cycle after the timed region (`instrumented_cycle`).
+    GRADED = ("gatv2_hetero_fwd",)
+    ops.KERNEL_TIMER.reset(enabled=True, only=GRADED)   # warm-up runs instrumented the same way
     for _ in range(a.warmup):
         step()
     barrier()
@@ -401,7 +405,7 @@ def main():
     # counting as usual.
     gc.collect()
     gc.disable()
-    ops.KERNEL_TIMER.reset(enabled=True)
+    ops.KERNEL_TIMER.reset(enabled=True, only=GRADED)
     t0 = time.perf_counter()
     marks = []
     for _ in range(a.steps):
@@ -411,6 +415,13 @@ def main():
         marks.append(ev)
     barrier()
     elapsed = time.perf_counter() - t0
+    ktimes = ops.KERNEL_TIMER.summary()
+    ops.KERNEL_TIMER.reset(enabled=True)              # every span: one more cycle, on every rank (the update holds a collective)
+    t_i = time.perf_counter()
+    step()
+    barrier()
+    instr_s = time.perf_counter() - t_i
+    kfull = ops.KERNEL_TIMER.summary()
     gc.enable()
     ops.KERNEL_TIMER.enabled = False
     el = th.tensor([elapsed], device=device, dtype=th.float64)
@@ -443,7 +454,6 @@ def main():
             "step_ms_device": [round(marks[i - 1].elapsed_time(marks[i]), 1) for i in range(1, len(marks))],
         }
         # ---- roofline of the dominant message-passing kernel: K1 forward, BOTH relations (one fused launch) ----------
-        ktimes = ops.KERNEL_TIMER.summary()
         k = ktimes.get("gatv2_hetero_fwd")
         if k:
             # every K1 launch of the timed region (rollout launches over N_a destinations, the two time-batched encoder
@@ -496,7 +506,7 @@ def main():
                                         "bound by HBM (output-row writes)")}
         # ---- the GEMM-shaped kernels by time share (the GRU cell is the largest kernel of a dense cycle): MFMA roofs ----------
         sec = []
-        kc = ktimes.get("gru_cell_fwd")
+        kc = kfull.get("gru_cell_fwd")
         if kc and kc["work"]:
             fl = sum(2.0 * N * 3 * H * (K_in + H) for (N, K_in, H, _) in kc["work"])       # fp32-equivalent FLOP
             x3 = all(w[3] == "bf16x3" for w in kc["work"])
@@ -508,8 +518,8 @@ def main():
                         "achieved": 6.0 * tf if x3 else tf, "peak": BF16_PEAK_TFLOPS if x3 else FP32_PEAK_TFLOPS,
                         "unit": "TFLOP/s (bf16 MFMA: six products per fp32 product)" if x3 else "TFLOP/s",
                         "frac": (6.0 * tf / BF16_PEAK_TFLOPS) if x3 else tf / FP32_PEAK_TFLOPS,
-                        "share_of_step": kc["total_ms"] / (1e3 * elapsed)})
-        kg = ktimes.get("gemm_x3")
+                        "share_of_step": kc["total_ms"] / (1e3 * instr_s)})
+        kg = kfull.get("gemm_x3")
         if kg and kg["work"]:
             fl = sum(2.0 * M * N * K for (M, N, K) in kg["work"])
             tf = fl / (kg["total_ms"] * 1e-3) / 1e12
@@ -517,10 +527,14 @@ def main():
                         "bound": "mfma", "launches": kg["count"], "avg_launch_ms": kg["avg_ms"],
                         "fp32_equivalent_tflops": tf, "achieved": 6.0 * tf, "peak": BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s (bf16 MFMA: six products per fp32 product)", "frac": 6.0 * tf / BF16_PEAK_TFLOPS,
-                        "share_of_step": kg["total_ms"] / (1e3 * elapsed)})
+                        "share_of_step": kg["total_ms"] / (1e3 * instr_s)})
         if sec:
             res["roofline_secondary"] = sec
-        res["kernel_ms_per_launch"] = {n: round(v["avg_ms"], 4) for n, v in ktimes.items()}
+        res["kernel_ms_per_launch"] = {n: round(v["avg_ms"], 4) for n, v in kfull.items()}
+        res["instrumented_cycle"] = {"ms": 1e3 * instr_s,
+                                     "note": "one extra cycle AFTER the timed steps with HIP events around every C-ABI launch: source of "
+                                             "`roofline_secondary` and `kernel_ms_per_launch`.  The timed steps carry events around the "
+                                             "graded kernel (`roofline`) only - timing every launch makes the rollout host-bound"}
         res["arithmetic"] = ("fp32 in / out / accumulate everywhere.  K3b, K5 and all pointwise kernels: fp32 FMA.  The score GEMM of K1 "
                              "(csrc/gatv2_hetero.hip), the GRU cell (csrc/gru_x3.hip), the dense layers whose output tiles by 128 "
                              "columns (csrc/gemm_x3.hip) and the time-batched encoder weight gradient (csrc/gemm_tn_x3.hip): each "

@@ -315,6 +315,7 @@ int uavgnn_gru_cell_fwd(const float* inp, int ld_inp, int K_in, const float* h, 
  * 16-byte aligned) - call it whenever the weights may have changed; uavgnn_gru_cell_fwd_x3 has the contract of
  * uavgnn_gru_cell_fwd with `planes` in place of the two weight matrices. */
 int uavgnn_gru_cell_x3_supported(int K_in, int H);   /* K_in % 32 == 0 and H % 64 == 0 */
+void uavgnn_gru_x3_set_variant(int interleave);      /* A/B of tools/gru_probe.py: 1 (default) = staging interleaved with the MFMAs, 0 = staging as a block in front of them (bit-identical results) */
 long long uavgnn_gru_cell_x3_workspace_bytes(int K_in, int H);
 int uavgnn_gru_split_weights(const float* W_ih, int K_in, const float* W_hh, int H, void* planes, uavgnn_stream_t stream);
 int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, const float* h, int N, int H, const void* planes,
@@ -328,7 +329,7 @@ int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, const float* 
 #define UAVGNN_GEMM_ACCUMULATE 1
 #define UAVGNN_GEMM_RELU 2
 int uavgnn_gemm_x3_supported(int M, int N, int K);
-void uavgnn_gemm_x3_set_variant(int variant);   /* A/B of tools/gemm_x3_probe.py: 8 (default) = 256 x 128 tiles, eight waves, double-buffered LDS; 4 = 128 x 128 tiles, four waves */
+void uavgnn_gemm_x3_set_variant(int variant);   /* A/B of tools/gemm_x3_probe.py: 8 (default) = 256 x 128 tiles, eight waves, double-buffered LDS; 9 = the same with the staging interleaved with the MFMAs (faster per launch, not per power-limited cycle); 4 = 128 x 128 tiles, four waves */
 int uavgnn_split_bf16x3(const float* W, int ld, int R, int C, int transpose, void* planes, uavgnn_stream_t stream);
 int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const void* planes, int N, const float* bias, float* Y, int ldy,
                       int epilogue, uavgnn_stream_t stream);

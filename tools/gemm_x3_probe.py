@@ -43,14 +43,18 @@ for name, M, n_out, K, tr in cases:
     from uav_bs_ctrl_amd import _lib as L
     L.lib().uavgnn_gemm_x3_set_variant(4)
     t_x3_w4 = time_us(f_x3)
-    L.lib().uavgnn_gemm_x3_set_variant(8)
+    L.lib().uavgnn_gemm_x3_set_variant(9)     # eight waves, staging interleaved with the MFMAs
+    t_x3_il = time_us(f_x3)
+    y_il = f_x3()
+    L.lib().uavgnn_gemm_x3_set_variant(8)     # the default: eight waves, the staging of a slice as a block in front of its MFMAs
     t_x3, t_v = time_us(f_x3), time_us(f_v)
+    same = bool(th.equal(y_il, f_x3()))
     rows = slice(0, 2048)
     ref = a[rows].double() @ (W.double() if tr else W.double().t())
     scale = a[rows].double().abs() @ (W.double().abs() if tr else W.double().abs().t())
     e_x3 = ((f_x3()[rows].double() - ref).abs() / scale)
     e_v = ((f_v()[rows].double() - ref).abs() / scale)
     fl = 2.0 * M * n_out * K
-    print(f"{name}: [4-wave 128x128 tiles {t_x3_w4:8.1f} us] bf16x3 {t_x3:8.1f} us = {fl / t_x3 * 1e-6:6.1f} TFLOP/s | vendor {t_v:8.1f} us = {fl / t_v * 1e-6:6.1f} TFLOP/s | "
+    print(f"{name}: [4-wave 128x128 tiles {t_x3_w4:8.1f} us] [8-wave, interleaved staging {t_x3_il:8.1f} us, bit-identical {same}] bf16x3 {t_x3:8.1f} us = {fl / t_x3 * 1e-6:6.1f} TFLOP/s | vendor {t_v:8.1f} us = {fl / t_v * 1e-6:6.1f} TFLOP/s | "
           f"x{t_v / t_x3:.2f} | error / sum|a b|: bf16x3 max {e_x3.max().item():.1e} mean {e_x3.mean().item():.1e}, "
           f"vendor max {e_v.max().item():.1e} mean {e_v.mean().item():.1e}")

@@ -1,10 +1,14 @@
 // Stand-alone timing of the bf16x3 GRU cell (csrc/gru_x3.hip) at C3 size with parts of the kernel compiled out
-// (-DUAVGNN_X3_DBG=1: no LDS fragment reads / MFMA, 2: no global loads inside the slice loop, 3: no split / LDS writes).
+// (-DUAVGNN_X3_DBG=1: no global loads inside the slice loop, 2: no staging at all, 3: prologue + epilogue only;
+// -DUAVGNN_X3_DBG_LD=1 / 2: only the activation / only the weight-plane loads).  argv[1]: 1 = interleaved staging (default), 0 = blocks.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iuav_bs_ctrl_amd/csrc [-DUAVGNN_X3_DBG=n] tools/ubench/gru_x3_bench.hip -o ...
 #include "../../uav_bs_ctrl_amd/csrc/gru_x3.hip"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
-int main() {
+int main(int argc, char** argv) {
+  const int il = argc > 1 ? atoi(argv[1]) : 1;   // 1 = staging interleaved with the MFMAs (default of the library), 0 = staging in blocks
+  uavgnn_gru_x3_set_variant(il);
   const int N = 32768, K = 320, H = 256;
   float *inp, *h, *Wih, *Whh, *bih, *bhh, *out;
   void* planes;
@@ -21,12 +25,16 @@ int main() {
   for (int i = 0; i < 3; ++i) run();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  for (int i = 0; i < 20; ++i) run();
+  for (int i = 0; i < 200; ++i) run();
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
 #ifndef UAVGNN_X3_DBG
 #define UAVGNN_X3_DBG 0
 #endif
-  printf("gru_cell_fwd_x3 DBG=%d: %.1f us per launch\n", UAVGNN_X3_DBG, ms * 1000.f / 20);
+  std::vector<float> o(size_t(N) * H);
+  hipMemcpy(o.data(), out, 4ll * N * H, hipMemcpyDeviceToHost);
+  double cs = 0;
+  for (size_t i = 0; i < o.size(); ++i) cs += o[i] * double((i % 977) + 1);
+  printf("gru_cell_fwd_x3 DBG=%d interleave=%d: %.1f us per launch   checksum %.9e\n", UAVGNN_X3_DBG, il, ms * 1000.f / 200, cs);
   return 0;
 }

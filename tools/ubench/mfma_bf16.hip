@@ -128,6 +128,64 @@ __global__ __launch_bounds__(NW * 64) void kloop(float* out, int iters) {
   for (int c = 0; c < 3; ++c) for (int i = 0; i < 16; ++i) s += acc[c][i];
   out[blockIdx.x * NW * 64 + tid] = s + (vsink == 12345u ? 1.f : 0.f);
 }
+// kloop with MODE = 8 (+ LDS reads / barrier), but the staging VALU is INTERLEAVED with the MFMAs in program order
+// (sched_group_barrier: 1 MFMA, then VPM VALU, ...) instead of standing in a block in front of them: within a wave an
+// independent VALU instruction can issue in the shadow of an executing MFMA only if it FOLLOWS it in program order.
+template <int NW, int MODE, int VPM>
+__global__ __launch_bounds__(NW * 64) void kloop_il(float* out, int iters) {
+  __shared__ u32x4 lds[(MODE & 4) ? 5120 : 2048];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 2048; i += NW * 64) lds[i] = u32x4{0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  __syncthreads();
+  bf16x8 a[2][3], b[3][2][3];
+  const int l32 = lane & 31, lh = lane >> 5, sw = (l32 >> 2) & 3;
+  auto rd = [&](int row0, int kh) { return __builtin_bit_cast(bf16x8, lds[(row0 + l32) * 4 + ((2 * kh + lh) ^ sw)]); };
+  READ_ALL(0) READ_ALL(1)
+  f32x16 acc[3];
+  for (int c = 0; c < 3; ++c) for (int i = 0; i < 16; ++i) acc[c][i] = 0;
+  float vx[8];
+  for (int i = 0; i < 8; ++i) vx[i] = 1.0f + 0.001f * (tid + i);
+  unsigned vsink = 0;
+  for (int it = 0; it < iters; ++it) {
+    if (MODE & 1) READ_ALL(1)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      float x = vx[i], y = vx[i + 1];
+      for (int r = 0; r < 2; ++r) {
+        bf16x2 p = __builtin_convertvector(f32x2{x, y}, bf16x2);
+        unsigned h1 = __builtin_bit_cast(unsigned, p);
+        x -= __uint_as_float(h1 << 16); y -= __uint_as_float(h1 & 0xffff0000u);
+        p = __builtin_convertvector(f32x2{x, y}, bf16x2);
+        unsigned h2 = __builtin_bit_cast(unsigned, p);
+        x -= __uint_as_float(h2 << 16); y -= __uint_as_float(h2 & 0xffff0000u);
+        p = __builtin_convertvector(f32x2{x, y}, bf16x2);
+        vsink ^= h1 ^ h2 ^ __builtin_bit_cast(unsigned, p);
+        x = vx[i] * 1.0001f + r; y = vx[i + 1] * 0.9999f + r;
+      }
+      vx[i] = x; vx[i + 1] = y;
+    }
+#define T(kh, ia, ib) _Pragma("unroll") for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kh][ia], b[g][kh][ib], acc[g], 0, 0, 0);
+    T(0, 0, 2) T(0, 2, 0) T(0, 1, 1) T(0, 0, 1) T(0, 1, 0) T(0, 0, 0)
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE & 2) __syncthreads();
+    if (MODE & 1) READ_ALL(0)
+    __builtin_amdgcn_sched_barrier(0);
+    T(1, 0, 2) T(1, 2, 0) T(1, 1, 1) T(1, 0, 1) T(1, 1, 0) T(1, 0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+#undef T
+  }
+  float s = 0;
+  for (int c = 0; c < 3; ++c) for (int i = 0; i < 16; ++i) s += acc[c][i];
+  out[blockIdx.x * NW * 64 + tid] = s + (vsink == 12345u ? 1.f : 0.f);
+}
 template <typename F>
 float time_ms(F f) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -155,5 +213,8 @@ int main() {
   RUNL(8, 4, 256) RUNL(8, 5, 256) RUNL(8, 6, 256) RUNL(8, 7, 256)
   RUNL(4, 0, 512) RUNL(4, 1, 512) RUNL(4, 2, 512) RUNL(4, 3, 512)
   RUNL(8, 12, 256) RUNL(8, 15, 256) RUNL(4, 8, 512) RUNL(4, 11, 512)
+#define RUNI(NW, MODE, VPM, BLK) { float ms = time_ms([&] { hipLaunchKernelGGL((kloop_il<NW, MODE, VPM>), dim3(BLK), dim3(NW * 64), 0, 0, out, 2048); }); \
+    printf("loop of 36 MFMAs, %d waves / workgroup, %d workgroups%s%s%s, + ~90 staging VALU INTERLEAVED %d per MFMA of the first group: %.1f ns per MFMA per SIMD\n", NW, BLK, (MODE & 1) ? ", 24 LDS fragment reads" : "", (MODE & 2) ? ", 1 barrier" : "", (MODE & 4) ? ", 1 workgroup / CU" : "", VPM, ms * 1e6 / (2048.0 * 36 * ((MODE & 4) ? NW / 4.0 : (double(BLK) * NW / 4 / 256)))); }
+  RUNI(8, 12, 3, 256) RUNI(8, 12, 5, 256) RUNI(8, 12, 7, 256) RUNI(8, 15, 5, 256) RUNI(4, 8, 5, 512) RUNI(4, 11, 5, 512)
   return 0;
 }

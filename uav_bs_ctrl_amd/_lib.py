@@ -85,6 +85,7 @@ SIGNATURES = {
     "uavgnn_gru_cell_supported": (_c_int, [_c_int, _c_int]),
     "uavgnn_gru_cell_fwd": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_st]),
     "uavgnn_gru_cell_x3_supported": (_c_int, [_c_int, _c_int]),
+    "uavgnn_gru_x3_set_variant": (None, [_c_int]),
     "uavgnn_gru_cell_x3_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
     "uavgnn_gru_split_weights": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, ctypes.c_void_p, _c_st]),
     "uavgnn_gru_cell_fwd_x3": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_fp, _c_fp, _c_fp, _c_st]),

@@ -151,7 +151,7 @@ constexpr int PA = BM8 * 4, PB = BN * 4;               // 16-byte chunks per spl
 constexpr int BUF = 3 * PA + 3 * PB;                   // chunks per buffer (72 KB)
 }  // namespace w8
 
-template <bool ACC, bool RELU>
+template <bool ACC, bool RELU, bool IL>
 __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __restrict__ X, int ldx, int M, int K,
                                                               const unsigned short* __restrict__ Bp, int N,
                                                               const float* __restrict__ bias, float* __restrict__ Y, int ldy,
@@ -193,20 +193,33 @@ __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __res
   const int ns = K / BK;
   float4 ra[4];
   u32x4 rw[3];
-  auto gload = [&](int t) {
+  auto gload_a = [&](int t) {
     const unsigned k0 = static_cast<unsigned>(t) * BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(X + (xo[i] + k0));
+  };
+  auto gload_w = [&](int t) {
+    const unsigned k0 = static_cast<unsigned>(t) * BK;
 #pragma unroll
     for (int i = 0; i < 3; ++i) rw[i] = *reinterpret_cast<const u32x4*>(Bp + (bo[i] + k0));
   };
-  auto lstore = [&](int buf) {
+  auto gload = [&](int t) {
+    gload_a(t);
+    gload_w(t);
+  };
+  auto lstore_a = [&](int buf, int i) {
+    unsigned short* sa = reinterpret_cast<unsigned short*>(smem + buf * BUF) + sa_w;
+    stage4(sa + 64 * i * 32, PA * 8, ra[i]);
+  };
+  auto lstore_b = [&](int buf) {
     u32x4* sb = smem + buf * BUF;
-    unsigned short* sa = reinterpret_cast<unsigned short*>(sb) + sa_w;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) stage4(sa + 64 * i * 32, PA * 8, ra[i]);
 #pragma unroll
     for (int i = 0; i < 3; ++i) sb[sbw[i]] = rw[i];
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lstore_a(buf, i);
+    lstore_b(buf);
   };
   struct Half {
     bf16x8 a[2][3], b[2][3];   // [tile][plane]
@@ -234,24 +247,72 @@ __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __res
   const bool early = wave < 4;
   Half f0, f1;
   UAVGNN_X3_READ(f0, 0, 0)
-  for (int t = 0; t < ns; ++t) {
-    UAVGNN_X3_READ(f1, t & 1, 1)
-    if (early) {
-      lstore((t + 1) & 1);                 // slice t + 1 (the tail re-stages the last slice: unconditional, straight-line)
-      gload(min(t + 2, ns - 1));
+  if (IL) {
+    // The staging of slice t + 1 (split VALU, LDS stores) and the loads of slice t + 2 are INTERLEAVED with the first MFMA group
+    // in program order (sched_group_barrier): an independent VALU / LDS / memory instruction issues in the shadow of an
+    // executing MFMA only when it follows it in the instruction stream - as a block in front of the MFMAs its issue time adds to
+    // theirs (tools/ubench/mfma_bf16.hip).  The weight-plane loads go out right behind the LDS stores of their registers.
+    for (int t = 0; t < ns; ++t) {
+      UAVGNN_X3_READ(f1, t & 1, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      const Half& F = f0;
+      const int tn = min(t + 2, ns - 1);
+      lstore_b((t + 1) & 1);
+      gload_w(tn);
+      UAVGNN_X3_TERM(0, 2)
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lstore_a((t + 1) & 1, i);
+      UAVGNN_X3_TERM(2, 0) UAVGNN_X3_TERM(1, 1) UAVGNN_X3_TERM(0, 1) UAVGNN_X3_TERM(1, 0)
+#pragma unroll
+      for (int sg = 0; sg < 16; ++sg) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      gload_a(tn);
+      UAVGNN_X3_TERM(0, 0)
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      UAVGNN_X3_READ(f0, (t + 1) & 1, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      UAVGNN_X3_MFMA(f1)
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    UAVGNN_X3_MFMA(f0)
-    __builtin_amdgcn_sched_barrier(0);
-    if (!early) {
-      lstore((t + 1) & 1);
-      gload(min(t + 2, ns - 1));
+  } else {
+    for (int t = 0; t < ns; ++t) {
+      UAVGNN_X3_READ(f1, t & 1, 1)
+      if (early) {
+        lstore((t + 1) & 1);                 // slice t + 1 (the tail re-stages the last slice: unconditional, straight-line)
+        gload(min(t + 2, ns - 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      UAVGNN_X3_MFMA(f0)
+      __builtin_amdgcn_sched_barrier(0);
+      if (!early) {
+        lstore((t + 1) & 1);
+        gload(min(t + 2, ns - 1));
+      }
+      __syncthreads();
+      UAVGNN_X3_READ(f0, (t + 1) & 1, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      UAVGNN_X3_MFMA(f1)
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
-    UAVGNN_X3_READ(f0, (t + 1) & 1, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    UAVGNN_X3_MFMA(f1)
-    __builtin_amdgcn_sched_barrier(0);
   }
 #undef UAVGNN_X3_MFMA
 #undef UAVGNN_X3_TERM
@@ -282,7 +343,10 @@ __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __res
 
 using namespace uavgnn;
 
-static int g_gemm_x3_variant = 8;   // A/B switch of tools/gemm_x3_probe.py (uavgnn_gemm_x3_set_variant): 4 = 128 x 128 tiles, four waves
+static int g_gemm_x3_variant = 8;   // A/B switch of tools/gemm_x3_probe.py (uavgnn_gemm_x3_set_variant): 4 = 128 x 128 tiles, four waves;
+                                    // 8 = eight waves, staging in blocks (default); 9 = eight waves, staging interleaved with the
+                                    // MFMAs: 7-15 % faster launch by launch, but a C3 cycle runs at the package power limit and is
+                                    // 0.5-2 ms SLOWER with it (profiles/r03_staging_interleave.txt)
 extern "C" void uavgnn_gemm_x3_set_variant(int v) { g_gemm_x3_variant = v; }
 
 extern "C" int uavgnn_gemm_x3_supported(int M, int N, int K) {
@@ -313,16 +377,20 @@ extern "C" int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const vo
   const unsigned short* bp = static_cast<const unsigned short*>(planes);
   const bool acc = (epilogue & UAVGNN_GEMM_ACCUMULATE) != 0, relu = (epilogue & UAVGNN_GEMM_RELU) != 0;
   const int col_blocks = (N + BN - 1) / BN;
-  if (g_gemm_x3_variant == 8) {
+  if (g_gemm_x3_variant >= 8) {
     const int row_blocks = (M + w8::BM8 - 1) / w8::BM8;
     const dim3 grid(((row_blocks + 7) / 8) * 8 * col_blocks), block(w8::NT);
-#define UAVGNN_X3_GEMM(ACC, RELU)                                                                                        \
-  hipLaunchKernelGGL((gemm_nt_x3w8_kernel<ACC, RELU>), grid, block, 0, st, X, ldx, M, K, bp, N, bias, Y, ldy, row_blocks, \
+#define UAVGNN_X3_GEMM(ACC, RELU, IL)                                                                                        \
+  hipLaunchKernelGGL((gemm_nt_x3w8_kernel<ACC, RELU, IL>), grid, block, 0, st, X, ldx, M, K, bp, N, bias, Y, ldy, row_blocks, \
                      col_blocks)
-    if (acc && relu) UAVGNN_X3_GEMM(true, true);
-    else if (acc) UAVGNN_X3_GEMM(true, false);
-    else if (relu) UAVGNN_X3_GEMM(false, true);
-    else UAVGNN_X3_GEMM(false, false);
+#define UAVGNN_X3_GEMM_IL(IL)                         \
+  if (acc && relu) UAVGNN_X3_GEMM(true, true, IL);    \
+  else if (acc) UAVGNN_X3_GEMM(true, false, IL);      \
+  else if (relu) UAVGNN_X3_GEMM(false, true, IL);     \
+  else UAVGNN_X3_GEMM(false, false, IL);
+    if (g_gemm_x3_variant == 9) { UAVGNN_X3_GEMM_IL(true) }
+    else { UAVGNN_X3_GEMM_IL(false) }
+#undef UAVGNN_X3_GEMM_IL
 #undef UAVGNN_X3_GEMM
     return launch_status();
   }

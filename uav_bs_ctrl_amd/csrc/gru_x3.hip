@@ -26,6 +26,8 @@
 // MFMAs issue at half rate, profiles/r02_ubench_mfma_bf16.txt), the same with 32x32x16 MFMAs (215 us), loads two slices
 // ahead through a fully unrolled slice loop (-4 us), a start skew between co-resident workgroups (0), persistent workgroups
 // that load the next tile's first slice during the epilogue (207 us).
+#include <type_traits>
+
 #include "bf16x3.h"
 #include "common.h"
 
@@ -72,7 +74,7 @@ constexpr int PA = BM * 4, PB = 3 * BJ * 4;            // 16-byte chunks per spl
 constexpr int BUF = 3 * PA + 3 * PB;                   // chunks per buffer (60 KB)
 }  // namespace w8
 
-template <bool SAVE>
+template <bool SAVE, bool IL>
 __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
     const float* __restrict__ inp, int ld_inp, int K1, const float* __restrict__ h, int N, int H,
     const unsigned short* __restrict__ Wih_p, const float* __restrict__ b_ih, const unsigned short* __restrict__ Whh_p,
@@ -93,42 +95,68 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[s][i] = 0.f;
   const int l32 = lane & 31, lh = lane >> 5, sw = swz32(l32);
-
   // A loader: float4 q = tid + 512 i -> row tid / 8 + 64 i, k = 4 (tid % 8); rows past N are clamped (stores are masked)
   const int lr = tid >> 3, c4 = tid & 7;
-  int ar[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) ar[i] = min(m0 + lr + 64 * i, N - 1);
   const int sa_w = lr * 32 + (((c4 >> 1) ^ swz32(lr)) * 8) + (c4 & 1) * 4;   // in bf16 units inside an A plane
   // B loader: chunk q = tid + 512 i (i < 5, 2304 chunks): plane q / 768, row (q % 768) / 4 = gate * 64 + unit, chunk q % 4
-  int wr[5], wk[5], sbw[5];
+  // Per-lane BYTE offsets of both phases ([x || c] / W_ih, then h / W_hh) are computed once; a slice adds a scalar to the base
+  // pointer (global_load with an SGPR base + 32-bit VGPR offset: no per-slice address arithmetic on the VALU).
+  unsigned oa1[2], oa2[2], ow1[5], ow2[5];
+  int sbw[5];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned row = static_cast<unsigned>(min(m0 + lr + 64 * i, N - 1));
+    oa1[i] = 4u * (row * static_cast<unsigned>(ld_inp) + 4u * c4);
+    oa2[i] = 4u * (row * static_cast<unsigned>(H) + 4u * c4);
+  }
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int q = min(tid + NT * i, 3 * PB - 1), pl = q / PB, rem = q - pl * PB, row = rem >> 2, c = rem & 3;
-    wr[i] = pl * 3 * H + (row >> 6) * H + j0 + (row & 63);
-    wk[i] = 8 * c;
+    const unsigned wrow = static_cast<unsigned>(pl * 3 * H + (row >> 6) * H + j0 + (row & 63));
+    ow1[i] = 2u * (wrow * static_cast<unsigned>(K1) + 8u * c);
+    ow2[i] = 2u * (wrow * static_cast<unsigned>(H) + 8u * c);
     sbw[i] = 3 * PA + pl * PB + row * 4 + (c ^ swz32(row));
   }
   const int n1 = K1 / BK, ns = n1 + H / BK;
   float4 ra[2];
   u32x4 rw[5];
-  auto gload = [&](int t) {   // slice t (clamped by the caller): t < n1 reads [x || c] and W_ih, else h and W_hh
+  // slice t (clamped by the caller): t < n1 reads [x || c] and W_ih, else h and W_hh
+#ifndef UAVGNN_X3_DBG_LD
+#define UAVGNN_X3_DBG_LD 3   /* timing experiments: bit 0 = activation loads, bit 1 = weight-plane loads inside the slice loop */
+#endif
+  auto gload_a = [&](int t) {
     const bool p1 = t < n1;
-    const float* __restrict__ Asrc = p1 ? inp : h;
-    const unsigned short* __restrict__ Wp = p1 ? Wih_p : Whh_p;
-    const int lda = p1 ? ld_inp : H, K = p1 ? K1 : H, k0 = (p1 ? t : t - n1) * BK;
+    const char* __restrict__ Ab = reinterpret_cast<const char*>(p1 ? inp : h) + 4 * ((p1 ? t : t - n1) * BK);
+    if ((UAVGNN_X3_DBG_LD & 1) || t < 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(Asrc + static_cast<unsigned>(ar[i] * lda + k0 + 4 * c4));
-#pragma unroll
-    for (int i = 0; i < 5; ++i) rw[i] = *reinterpret_cast<const u32x4*>(Wp + static_cast<unsigned>(wr[i] * K + wk[i] + k0));
+      for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(Ab + (p1 ? oa1[i] : oa2[i]));
+    }
   };
-  auto lstore = [&](int buf) {
-    u32x4* sb = smem + buf * BUF;
-    unsigned short* sa = reinterpret_cast<unsigned short*>(sb) + sa_w;
+  auto gload_w = [&](int t) {
+    const bool p1 = t < n1;
+    const char* __restrict__ Wb = reinterpret_cast<const char*>(p1 ? Wih_p : Whh_p) + 2 * ((p1 ? t : t - n1) * BK);
+    if ((UAVGNN_X3_DBG_LD & 2) || t < 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) stage4(sa + 64 * i * 32, PA * 8, ra[i]);
+      for (int i = 0; i < 5; ++i) rw[i] = *reinterpret_cast<const u32x4*>(Wb + (p1 ? ow1[i] : ow2[i]));
+    }
+  };
+  auto gload = [&](int t) {
+    gload_a(t);
+    gload_w(t);
+  };
+  auto lstore_b = [&](int buf) {
+    u32x4* sb = smem + buf * BUF;
 #pragma unroll
     for (int i = 0; i < 5; ++i) sb[sbw[i]] = rw[i];   // i = 4, tid >= 256: the clamped chunk again - same data, same address
+  };
+  auto lstore_a = [&](int buf, int i) {
+    unsigned short* sa = reinterpret_cast<unsigned short*>(smem + buf * BUF) + sa_w;
+    stage4(sa + 64 * i * 32, PA * 8, ra[i]);
+  };
+  auto lstore = [&](int buf) {
+    lstore_a(buf, 0);
+    lstore_a(buf, 1);
+    lstore_b(buf);
   };
   // One K slice = two 16-wide halves of v_mfma_f32_32x32x16_bf16 (lane -> row lane % 32, 8 consecutive k at 8 (lane / 32) of
   // the half): per half and gate one 32 x 32 tile and six products; the three gates interleave so that dependent MFMAs are
@@ -174,32 +202,78 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
 #ifndef UAVGNN_X3_DBG
 #define UAVGNN_X3_DBG 0   /* timing experiments of tools/ubench/gru_x3_bench.hip: 1 = no global loads in the loop, 2 = no staging */
 #endif
-#define lstore(b) if (UAVGNN_X3_DBG < 2) lstore(b)
-#define gload(tt) if (UAVGNN_X3_DBG < 1) gload(tt)
-#define UAVGNN_X3_W8_STEP(NSET)                            \
+#define UAVGNN_X3_W8_STEP_BLK(NSET)                        \
   UAVGNN_X3_W8_READ(f1, t & 1, 1)                          \
   if (early) {                                             \
-    lstore((t + 1) & 1);                                   \
-    gload(min(t + 2, ns - 1));                             \
+    if (UAVGNN_X3_DBG < 2) lstore((t + 1) & 1);            \
+    if (UAVGNN_X3_DBG < 1) gload(min(t + 2, ns - 1));      \
   }                                                        \
   __builtin_amdgcn_sched_barrier(0);                       \
   UAVGNN_X3_W8_MFMA(f0, NSET)                              \
   __builtin_amdgcn_sched_barrier(0);                       \
   if (!early) {                                            \
-    lstore((t + 1) & 1);                                   \
-    gload(min(t + 2, ns - 1));                             \
+    if (UAVGNN_X3_DBG < 2) lstore((t + 1) & 1);            \
+    if (UAVGNN_X3_DBG < 1) gload(min(t + 2, ns - 1));      \
   }                                                        \
   __syncthreads();                                         \
   UAVGNN_X3_W8_READ(f0, (t + 1) & 1, 0)                    \
   __builtin_amdgcn_sched_barrier(0);                       \
   UAVGNN_X3_W8_MFMA(f1, NSET)                              \
   __builtin_amdgcn_sched_barrier(0);
+  // IL: the staging of slice t + 1 and the loads of slice t + 2 are INTERLEAVED with the first MFMA group in program order
+  // (sched_group_barrier; every wave stages there).  An independent VALU / LDS / memory instruction issues in the shadow of an
+  // executing MFMA only when it FOLLOWS it in the instruction stream; as a block in front of the MFMAs its issue time adds to
+  // theirs (tools/ubench/mfma_bf16.hip: 19.1 -> 15.8 ns per MFMA with ~90 staging VALU per 36 MFMAs).  The weight-plane loads
+  // go out right behind the LDS stores of their registers, the activation loads behind the splits.
+#define UAVGNN_X3_W8_STEP_IL(NSET_)                        \
+  {                                                        \
+    constexpr int NSET = NSET_;                            \
+    UAVGNN_X3_W8_READ(f1, t & 1, 1)                        \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    const Half& F = f0;                                    \
+    const int tn = min(t + 2, ns - 1);                     \
+    if (UAVGNN_X3_DBG < 2) lstore_b((t + 1) & 1);          \
+    if (UAVGNN_X3_DBG < 1) gload_w(tn);                    \
+    UAVGNN_X3_W8_TERM(0, 2)                                \
+    _Pragma("unroll") for (int sg = 0; sg < 3; ++sg) {     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);   \
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   \
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   \
+    }                                                      \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    if (UAVGNN_X3_DBG < 2) { lstore_a((t + 1) & 1, 0); lstore_a((t + 1) & 1, 1); } \
+    UAVGNN_X3_W8_TERM(2, 0) UAVGNN_X3_W8_TERM(1, 1) UAVGNN_X3_W8_TERM(0, 1) UAVGNN_X3_W8_TERM(1, 0) \
+    _Pragma("unroll") for (int sg = 0; sg < 12; ++sg) {    \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   \
+    }                                                      \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    if (UAVGNN_X3_DBG < 1) gload_a(tn);                    \
+    UAVGNN_X3_W8_TERM(0, 0)                                \
+    _Pragma("unroll") for (int sg = 0; sg < 3; ++sg) {     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   \
+    }                                                      \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  }                                                        \
+  __syncthreads();                                         \
+  UAVGNN_X3_W8_READ(f0, (t + 1) & 1, 0)                    \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  UAVGNN_X3_W8_MFMA(f1, NSET_)                             \
+  __builtin_amdgcn_sched_barrier(0);
   if (UAVGNN_X3_DBG == 3) t = ns;   /* timing experiment: prologue + epilogue only */
-  for (; t < n1; ++t) { UAVGNN_X3_W8_STEP(2) }
-  for (; t < ns; ++t) { UAVGNN_X3_W8_STEP(3) }
-#undef UAVGNN_X3_W8_STEP
-#undef lstore
-#undef gload
+  if (IL) {
+    for (; t < n1; ++t) { UAVGNN_X3_W8_STEP_IL(2) }
+    for (; t < ns; ++t) { UAVGNN_X3_W8_STEP_IL(3) }
+  } else {
+    for (; t < n1; ++t) { UAVGNN_X3_W8_STEP_BLK(2) }
+    for (; t < ns; ++t) { UAVGNN_X3_W8_STEP_BLK(3) }
+  }
+#undef UAVGNN_X3_W8_STEP_IL
+#undef UAVGNN_X3_W8_STEP_BLK
 #undef UAVGNN_X3_W8_MFMA
 #undef UAVGNN_X3_W8_READ
   __syncthreads();   // the last iteration's read of the stale buffer must not race the epilogue's tile
@@ -250,6 +324,9 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
 
 using namespace uavgnn;
 
+static int g_gru_x3_interleave = 1;   // A/B switch (uavgnn_gru_x3_set_variant): 0 = staging as a block in front of the MFMAs (round 2)
+extern "C" void uavgnn_gru_x3_set_variant(int interleave) { g_gru_x3_interleave = interleave; }
+
 extern "C" int uavgnn_gru_cell_x3_supported(int K_in, int H) {
   return (K_in >= BK && K_in % BK == 0 && H >= w8::BJ && H % w8::BJ == 0) ? 1 : 0;
 }
@@ -290,8 +367,13 @@ extern "C" int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, co
 #define UAVGNN_X3_LAUNCH(KERNEL, BJ_, NT_)                                                                              \
   hipLaunchKernelGGL(KERNEL, dim3(rb8 * (H / (BJ_))), dim3(NT_), 0, st, inp, ld_inp, K_in, h, N, H, p0, b_ih, p1, b_hh, \
                      h_out, pre_save, row_blocks)
-  if (pre_save != nullptr) UAVGNN_X3_LAUNCH(gru_cell_fwd_x3w8_kernel<true>, w8::BJ, w8::NT);
-  else UAVGNN_X3_LAUNCH(gru_cell_fwd_x3w8_kernel<false>, w8::BJ, w8::NT);
+  if (g_gru_x3_interleave) {
+    if (pre_save != nullptr) UAVGNN_X3_LAUNCH((gru_cell_fwd_x3w8_kernel<true, true>), w8::BJ, w8::NT);
+    else UAVGNN_X3_LAUNCH((gru_cell_fwd_x3w8_kernel<false, true>), w8::BJ, w8::NT);
+  } else {
+    if (pre_save != nullptr) UAVGNN_X3_LAUNCH((gru_cell_fwd_x3w8_kernel<true, false>), w8::BJ, w8::NT);
+    else UAVGNN_X3_LAUNCH((gru_cell_fwd_x3w8_kernel<false, false>), w8::BJ, w8::NT);
+  }
 #undef UAVGNN_X3_LAUNCH
   return launch_status();
 }

@@ -23,25 +23,31 @@ class _KernelTimer:
 
     def __init__(self):
         self.enabled = False
+        self.only = None
         self._spans = {}
 
-    def reset(self, enabled=True):
+    def reset(self, enabled=True, only=None):
+        """only: names of the spans to time (None = all).  A span costs two event creations + records on the launch
+        thread (~15 us) and two timestamp packets on the stream: timing EVERY launch of a cycle makes its rollout phase
+        host-bound (tools/launch_bound_probe.py), so a timed benchmark region instruments the kernel it grades only."""
         self._spans = {}
         self.enabled = enabled
+        self.only = None if only is None else frozenset(only)
 
     class _Span:
         def __init__(self, timer, name, work=None):
             self.t, self.name, self.work = timer, name, work
 
         def __enter__(self):
-            if self.t.enabled:
+            self.on = self.t.enabled and (self.t.only is None or self.name in self.t.only)
+            if self.on:
                 self.e0 = th.cuda.Event(enable_timing=True)
                 self.e1 = th.cuda.Event(enable_timing=True)
                 self.e0.record()
             return self
 
         def __exit__(self, *exc):
-            if self.t.enabled:
+            if self.on:
                 self.e1.record()
                 self.t._spans.setdefault(self.name, []).append((self.e0, self.e1, self.work))
             return False
@@ -425,8 +431,11 @@ _gemm_x3_variant_set = False
 
 def gemm_x3_supported(a, n_out, k) -> bool:
     global _gemm_x3_variant_set
-    if not _gemm_x3_variant_set and "UAVGNN_GEMM_X3_VARIANT" in os.environ:   # A/B: 4 = 128 x 128 tiles, four waves
-        L.lib().uavgnn_gemm_x3_set_variant(int(os.environ["UAVGNN_GEMM_X3_VARIANT"]))
+    if not _gemm_x3_variant_set:   # A/B switches (include/uavgnn.h): GEMM 9 / 8 / 4, GRU cell 1 / 0
+        if "UAVGNN_GEMM_X3_VARIANT" in os.environ:
+            L.lib().uavgnn_gemm_x3_set_variant(int(os.environ["UAVGNN_GEMM_X3_VARIANT"]))
+        if "UAVGNN_GRU_X3_VARIANT" in os.environ:
+            L.lib().uavgnn_gru_x3_set_variant(int(os.environ["UAVGNN_GRU_X3_VARIANT"]))
     _gemm_x3_variant_set = True
     return bool(GEMM_X3 and a.is_cuda and a.dtype == th.float32 and a.dim() == 2 and a.stride(1) == 1
                 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and n_out % 128 == 0 and a.shape[0] >= 4096
