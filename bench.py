@@ -264,6 +264,13 @@ def end_to_end(learner, a, device, mode="random", cycles=2):
     gen = th.Generator(device=device)
     gen.manual_seed(99)
     STATIC = os.environ.get("UAVGNN_E2E_STATIC", "1") == "1"   # per-step graphs without the host round trip for edge totals
+    # UAVGNN_E2E_GRAPH=1: the rollout step (device graph construction + policy forward + selection) as ONE hipGraph replay
+    # from fixed-address observation buffers (uav_bs_ctrl_amd/graphs.py).  At B = 4096 the eager step is GPU-bound and the
+    # replay buys nothing (measured round 3: 129.6 vs 128.8 ms per cycle); it pays at small B (profiles/r03_small_batch.txt).
+    ga = None
+    if os.environ.get("UAVGNN_E2E_GRAPH", "0") == "1":
+        from uav_bs_ctrl_amd.graphs import GraphedAct
+        ga = GraphedAct(learner, B, n, M, mp.r_comm)
 
     def positions():   # hotspot of M/5 groups of 5 GTs on a 200 m grid, UBSs on grid points (maps.py:96-111)
         grid = 200.0
@@ -286,9 +293,13 @@ def end_to_end(learner, a, device, mode="random", cycles=2):
         o = env.reset(ubs, gts, generator=gen)
         h = learner.init_hidden(B)
         for t in range(T):
-            g = from_padded_obs(o["gt"], o["ubs"], o["agent"], o["d_u2u"], r_comm=mp.r_comm, static=STATIC)
             rb.stage_obs(dict(gt=o["gt"], ubs=o["ubs"], agent=o["agent"], d_u2u=o["d_u2u"], h=h.view(B, n, -1)))
-            acts, h2 = learner.act(g, h, 1.0 if mode == "random" else 0.05)
+            eps = 1.0 if mode == "random" else 0.05
+            if ga is not None:
+                acts, h2 = ga(o["gt"], o["ubs"], o["agent"], o["d_u2u"], h, eps)
+            else:
+                g = from_padded_obs(o["gt"], o["ubs"], o["agent"], o["d_u2u"], r_comm=mp.r_comm, static=STATIC)
+                acts, h2 = learner.act(g, h, eps)
             if mode == "hotspot":
                 acts = th.zeros_like(acts)        # hover: the UBSs stay on the hotspot
             o, rew, done, _ = env.step(acts)      # overwrites the observation buffers in place: they are in the replay already
@@ -322,6 +333,8 @@ def end_to_end(learner, a, device, mode="random", cycles=2):
                 mode=mode, policy=("uniformly random actions (epsilon = 1)" if mode == "random" else
                                    "policy forward + selection run, simulator stepped with the hover action"),
                 includes="batched device simulator (f3) + device graph construction (f1) + tensor replay (f2) + act + update",
+                rollout_step=("one hipGraph replay (GraphedAct: graph construction + policy forward + selection)" if ga is not None
+                              else "eager launches"),
                 physics=f"DenseHotSpot-style map at {n} x {M}: 5 RBs, r_cov 100 m, r_sns 400 m, range 6 km, dt 40 s",
                 mean_gt_visibility=seen, mean_d_seen=seen * M, mean_gt_served=served)
 

@@ -20,6 +20,9 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWave * kWavesPerBlock;
+#ifndef UAVGNN_BWD_OCC
+#define UAVGNN_BWD_OCC 2
+#endif
 
 template <int FS>
 __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&x)[FS]);
@@ -187,7 +190,7 @@ template <int FS>
 __host__ __device__ constexpr int partial_len(int H) { return H * (FS + 8); }
 
 template <int FS, int NH, int D, bool CHUNK>
-__global__ __launch_bounds__(kThreads) void gatv2_bwd_kernel(
+__global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
     const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off,
     const int32_t* __restrict__ dst_order, int N,
     const float* __restrict__ W_s, const float* __restrict__ b_s, const float* __restrict__ W_d,
