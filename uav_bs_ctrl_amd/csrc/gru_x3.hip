@@ -19,7 +19,7 @@
 // x 64 hidden units; eight wavefronts of 32 agents x 32 units x 4 sets (64 accumulator registers) on
 // v_mfma_f32_32x32x16_bf16.  The LDS tiles are double-buffered with ONE barrier per slice, the fragment reads are software-
 // pipelined over the two 16-wide halves of a slice, the loads of slice t+2 are in flight while slice t computes.
-// Measured (tools/ubench/gru_x3_bench.hip, C3 size): 194 us; without any staging (fragment reads + MFMAs + barriers) 161 us;
+// Measured (tools/ubench/gru_x3_bench.hip, C3 size; round 2, staging in blocks - round 3's interleaved staging: 163-165 us): 194 us; without any staging (fragment reads + MFMAs + barriers) 161 us;
 // prologue + epilogue alone 36 us (one workgroup per CU: nothing overlaps them); the MFMAs alone would take 94 us
 // (tools/ubench/mfma_bf16.hip: 18.2 ns per 32x32x16 MFMA per SIMD with random operands).  Variants measured and dropped:
 // 128 x 32 tiles with four waves and 16x16x32 MFMAs (200 us: three independent accumulators between dependent 16x16x32
@@ -192,7 +192,9 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
   // their use - f1 = (slice t, second half) under the MFMAs of f0, f0 = (slice t + 1, first half) right after the barrier
   // under the MFMAs of f1.  Iteration t also stages slice t + 1 into the other buffer (its readers passed the barrier of
   // iteration t - 1) and starts the loads of slice t + 2; the tail re-stages / re-loads the last slice (unconditional).
-  // Waves w and w + 4 share a SIMD: the first four stage BEFORE their first MFMA group, the last four AFTER it.
+  // Two schedules of the staging (template parameter IL, uavgnn_gru_x3_set_variant; bit-identical results):
+  //   blocks      - waves w and w + 4 share a SIMD: the first four stage BEFORE their first MFMA group, the last four AFTER it;
+  //   interleaved - every wave stages INSIDE its first MFMA group (the default; see UAVGNN_X3_W8_STEP_IL).
   // sched_barrier pins the order (left alone, the compiler sinks the global loads below the MFMAs - prefetch distance zero -
   // and issues the LDS reads right before their MFMAs).
   const bool early = wave < 4;
