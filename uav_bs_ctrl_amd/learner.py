@@ -140,7 +140,14 @@ class MultiAgentQLearner:
         return agent_REGISTRY["gnn"](self.obs_shape, self.n_actions, self.args)   # learner.py:62-67 ('gnn' arm)
 
     def init_hidden(self, batch_size: int = 1) -> th.Tensor:
-        return self.policy_net.init_hidden().expand(self.n_agents * batch_size, -1).to(self.device)
+        """[n_agents * batch_size, H] on the learner's device (learner.py:82-83).  The agent's one-row initial state (on
+        the CPU, as the reference returns it) is moved to the device FIRST and expanded there: expanding on the host
+        materialises B * n * H floats in pageable memory and copies them synchronously - 33 MB and ~10 ms of a blocked
+        launch thread per rollout at C3 size (tools/prof_act_host.py)."""
+        h0 = self.policy_net.init_hidden()
+        if h0.device != self.device:
+            h0 = h0.to(self.device, non_blocking=True)
+        return h0.expand(self.n_agents * batch_size, -1).contiguous()
 
     # ---- rollout --------------------------------------------------------------------------------------------------
     @th.no_grad()
