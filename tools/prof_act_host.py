@@ -26,3 +26,24 @@ th.cuda.synchronize()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
 print(s.getvalue()[:6000])
+
+
+def update():
+    obs = [g.fresh() for g in batch["obs"]]
+    fb = dict(batch, obs=obs, obs_all=batch["obs_all"].fresh(), obs_all_next=batch["obs_all_next"].fresh())
+    return learner.update(fb)
+
+
+for _ in range(2):
+    update()
+th.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(3):
+    update()
+pr.disable()
+th.cuda.synchronize()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22)
+print("---- update (3 calls) ----")
+print(s.getvalue()[:5000])
