@@ -1813,3 +1813,31 @@ def test_bf16x3_split_is_exact(transpose):
     assert th.equal(total.float(), ref)
     a = ref.abs().double()
     assert bool((p[1].double().abs() <= a * 2.0 ** -8).all()) and bool((p[2].double().abs() <= a * 2.0 ** -16).all())
+
+
+def test_frozen_weights_scope_reuses_planes_and_changes_nothing():
+    """ops.frozen_weights() (the learner's loss forward + backward): weight planes of the bf16x3 kernels are split once per
+    scope instead of once per call - same bits out; outside the scope a `.data` write to a weight is seen by the very next call."""
+    from uav_bs_ctrl_amd import ops
+    th.manual_seed(3)
+    N, K, H = 4096, 320, 256
+    cell = th.nn.GRUCell(K, H).cuda()
+    inp, h = th.randn(N, K, device="cuda"), th.randn(N, H, device="cuda")
+    x, W = th.randn(N, 512, device="cuda"), th.randn(256, 512, device="cuda") * 0.05
+    with th.no_grad():
+        y0, g0 = ops.gru_cell(inp, h, cell), ops.gemm_x3(x, W)
+        with ops.frozen_weights():
+            y1, g1 = ops.gru_cell(inp, h, cell), ops.gemm_x3(x, W)
+            y2, g2 = ops.gru_cell(inp, h, cell), ops.gemm_x3(x, W)
+            assert len(ops._PLANES) == 2                       # one entry per weight set, not per call
+            with ops.frozen_weights():                         # nested scopes share the outer cache
+                ops.gru_cell(inp, h, cell)
+                assert len(ops._PLANES) == 2
+        assert ops._PLANES is None
+        assert th.equal(y0, y1) and th.equal(y1, y2) and th.equal(g0, g1) and th.equal(g1, g2)
+        cell.weight_ih.data.mul_(0.5)
+        W.data.mul_(2.0)
+        y3, g3 = ops.gru_cell(inp, h, cell), ops.gemm_x3(x, W)
+        ref = cell.double()(inp.double(), h.double())
+        assert float((y3.double() - ref).abs().max()) <= 1e-5
+        assert float((g3 - 2.0 * g0).abs().max()) == 0.0        # a power-of-two scale commutes with every rounding

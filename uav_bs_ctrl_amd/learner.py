@@ -257,12 +257,13 @@ class MultiAgentQLearner:
         ops.GRAD_SINK = sink = ops.WeightGradSink() if self.device.type == "cuda" else None
         loss = None
         try:
-            for b in chunks:
-                loss_b, agent_out, _ = self.loss(b)
-                if len(chunks) > 1:
-                    loss_b = loss_b / len(chunks)
-                loss_b.backward()
-                loss = loss_b.detach() if loss is None else loss + loss_b.detach()
+            with ops.frozen_weights():      # nothing changes a parameter until apply(): weight planes are split once
+                for b in chunks:
+                    loss_b, agent_out, _ = self.loss(b)
+                    if len(chunks) > 1:
+                        loss_b = loss_b / len(chunks)
+                    loss_b.backward()
+                    loss = loss_b.detach() if loss is None else loss + loss_b.detach()
             if sink is not None:
                 sink.flush()
         finally:

@@ -317,6 +317,39 @@ def gru_cell_supported(inp, h) -> bool:
 
 GRU_X3 = os.environ.get("UAVGNN_GRU_X3", "1") != "0"   # the cell's GEMMs as bf16x3 splits on the bf16 matrix cores (csrc/gru_x3.hip)
 
+# bf16 planes of weight matrices, reused ONLY inside a `frozen_weights()` scope.  A drop-in module's weights may change behind
+# any cache (`.data` writes bump no version counter), so by default every call splits its weights again (3-5 us, one launch).
+# The learner's loss forward + backward is one call during which nobody can touch the parameters: 101 recurrent steps and 51
+# backward steps share their planes there (~250 launches, ~1.1 ms of a C3 cycle).
+_PLANES = None
+
+
+class frozen_weights:
+    """Scope in which the caller guarantees that no parameter changes: weight planes are built once per (storage, layout)."""
+
+    def __enter__(self):
+        global _PLANES
+        self.prev, _PLANES = _PLANES, ({} if _PLANES is None else _PLANES)
+        return self
+
+    def __exit__(self, *exc):
+        global _PLANES
+        _PLANES = self.prev
+        return False
+
+
+def _cached_planes(key, nbytes, device, build):
+    """planes tensor for `key`; `build(planes)` launches the split when the scope has not seen the key yet."""
+    if _PLANES is not None:
+        hit = _PLANES.get(key)
+        if hit is not None:
+            return hit
+    planes = th.empty(nbytes, dtype=th.uint8, device=device)
+    build(planes)
+    if _PLANES is not None:
+        _PLANES[key] = planes
+    return planes
+
 
 def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save):
     """h' (and the [N, 4H] pre-activation sets when `save`) of the fused GRU cell."""
@@ -325,11 +358,14 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save):
     pre = th.empty((N, 4 * H), dtype=th.float32, device=h.device) if save else None
     if GRU_X3 and L.lib().uavgnn_gru_cell_x3_supported(inp.shape[1], H):
         lib, K_in = L.lib(), inp.shape[1]
-        planes = th.empty(lib.uavgnn_gru_cell_x3_workspace_bytes(K_in, H), dtype=th.uint8, device=h.device)
         with KERNEL_TIMER.span("gru_cell_fwd", (N, K_in, H, "bf16x3")):
-            # the planes are rebuilt on every call: nothing observable tells when a drop-in module's weights changed
-            rc = lib.uavgnn_gru_split_weights(W_ih.data_ptr(), K_in, W_hh.data_ptr(), H, planes.data_ptr(), L.stream())
-            L.check(rc, "uavgnn_gru_split_weights")
+            # the planes are rebuilt on every call outside a frozen_weights() scope: nothing observable tells when a drop-in
+            # module's weights changed
+            planes = _cached_planes(("gru", W_ih.data_ptr(), W_hh.data_ptr(), K_in, H),
+                                    lib.uavgnn_gru_cell_x3_workspace_bytes(K_in, H), h.device,
+                                    lambda p: L.check(lib.uavgnn_gru_split_weights(W_ih.data_ptr(), K_in, W_hh.data_ptr(), H,
+                                                                                   p.data_ptr(), L.stream()),
+                                                      "uavgnn_gru_split_weights"))
             rc = lib.uavgnn_gru_cell_fwd_x3(inp.data_ptr(), inp.stride(0), K_in, h.data_ptr(), N, H, planes.data_ptr(),
                                             b_ih.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), L.ptr(pre), L.stream())
         L.check(rc, "uavgnn_gru_cell_fwd_x3")
@@ -445,18 +481,18 @@ def gemm_x3_supported(a, n_out, k) -> bool:
 def gemm_x3(a, W, transpose_w=False, bias=None, out=None, accumulate=False, relu=False):
     """out = a @ W.T (transpose_w=False, W [n_out, k]) or a @ W (transpose_w=True, W [k, n_out]) (+ bias) (+ out) (relu).
     `W` may be a strided view with unit inner stride; its bf16 planes are rebuilt on every call (3-5 us: nothing observable
-    tells when a drop-in module's weights changed).  Caller checks gemm_x3_supported()."""
+    tells when a drop-in module's weights changed) unless the caller opened a frozen_weights() scope.  Caller checks gemm_x3_supported()."""
     lib = L.lib()
     M, K = a.shape
     R, C = W.shape
     n_out = C if transpose_w else R
     assert (R if transpose_w else C) == K and W.stride(1) == 1
-    planes = th.empty(6 * R * C, dtype=th.uint8, device=a.device)
     if out is None:
         out = th.empty((M, n_out), dtype=th.float32, device=a.device)
     with KERNEL_TIMER.span("gemm_x3", (M, n_out, K)):
-        rc = lib.uavgnn_split_bf16x3(W.data_ptr(), W.stride(0), R, C, int(transpose_w), planes.data_ptr(), L.stream())
-        L.check(rc, "uavgnn_split_bf16x3")
+        planes = _cached_planes(("mat", W.data_ptr(), W.stride(0), R, C, bool(transpose_w)), 6 * R * C, a.device,
+                                lambda p: L.check(lib.uavgnn_split_bf16x3(W.data_ptr(), W.stride(0), R, C, int(transpose_w),
+                                                                          p.data_ptr(), L.stream()), "uavgnn_split_bf16x3"))
         rc = lib.uavgnn_gemm_nt_x3(a.data_ptr(), a.stride(0), M, K, planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(),
                                    out.stride(0), (1 if accumulate else 0) | (2 if relu else 0), L.stream())
     L.check(rc, "uavgnn_gemm_nt_x3")
