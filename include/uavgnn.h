@@ -313,7 +313,8 @@ int uavgnn_gru_cell_fwd(const float* inp, int ld_inp, int K_in, const float* h, 
  * profiles/r02_ubench_gemm_bf16x3.txt; fp32 MFMA issues at 1/16 of the bf16 MFMA rate on gfx950).
  * uavgnn_gru_split_weights writes the bf16 planes of W_ih then W_hh ([3][3H][K_in] | [3][3H][H], ..._workspace_bytes bytes,
  * 16-byte aligned) - call it whenever the weights may have changed; uavgnn_gru_cell_fwd_x3 has the contract of
- * uavgnn_gru_cell_fwd with `planes` in place of the two weight matrices. */
+ * uavgnn_gru_cell_fwd with `planes` in place of the two weight matrices; 4 N max(ld_inp, H) must stay below 2^32 (32-bit byte
+ * offsets inside the kernel: 3.3 M rows at K_in = 320), UAVGNN_EUNSUPPORTED otherwise. */
 int uavgnn_gru_cell_x3_supported(int K_in, int H);   /* K_in % 32 == 0 and H % 64 == 0 */
 void uavgnn_gru_x3_set_variant(int interleave);      /* A/B of tools/gru_probe.py: 1 (default) = staging interleaved with the MFMAs, 0 = staging as a block in front of them (bit-identical results) */
 long long uavgnn_gru_cell_x3_workspace_bytes(int K_in, int H);

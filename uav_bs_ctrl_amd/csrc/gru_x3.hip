@@ -361,6 +361,9 @@ extern "C" int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, co
       ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(planes) |
         reinterpret_cast<uintptr_t>(h_out)) & 15))
     return UAVGNN_EUNSUPPORTED;
+  // the kernel addresses its operands by 32-bit BYTE offsets from the base pointers (global_load with an SGPR base)
+  if (4LL * N * (ld_inp > H ? ld_inp : H) >= (1LL << 32) || 18LL * H * (K_in > H ? K_in : H) >= (1LL << 32))
+    return UAVGNN_EUNSUPPORTED;
   if (N == 0) return 0;
   const unsigned short* p0 = static_cast<const unsigned short*>(planes);
   const unsigned short* p1 = p0 + 9LL * H * K_in;

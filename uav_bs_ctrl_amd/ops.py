@@ -356,7 +356,8 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save):
     N, H = h.shape
     h2 = th.empty_like(h)
     pre = th.empty((N, 4 * H), dtype=th.float32, device=h.device) if save else None
-    if GRU_X3 and L.lib().uavgnn_gru_cell_x3_supported(inp.shape[1], H):
+    if (GRU_X3 and L.lib().uavgnn_gru_cell_x3_supported(inp.shape[1], H)
+            and 4 * N * max(inp.stride(0), H) < 2 ** 32):        # 32-bit byte offsets inside the kernel (3.3 M rows at K_in = 320)
         lib, K_in = L.lib(), inp.shape[1]
         with KERNEL_TIMER.span("gru_cell_fwd", (N, K_in, H, "bf16x3")):
             # the planes are rebuilt on every call outside a frozen_weights() scope: nothing observable tells when a drop-in
