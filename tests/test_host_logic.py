@@ -334,3 +334,44 @@ def test_checkpoint_carries_the_lr_scheduler_like_the_reference(tmp_path):
 def test_heterobatch_to_same_device_keeps_the_object():
     g = from_obs_dicts(_obs(np.random.default_rng(0), 3, 5), np.zeros((3, 3)), 1.0)
     assert g.to("cpu") is g and g.to(th.device("cpu")) is g
+
+
+def test_weight_plane_cache_lives_only_inside_a_frozen_weights_scope():
+    """ops._cached_planes (host logic of the bf16x3 wrappers): outside ops.frozen_weights() every call builds its planes again
+    (a drop-in module's weights may change behind any cache); inside, once per key, nested scopes share the outer cache and
+    the cache is gone when the outermost scope exits - also when it exits by an exception."""
+    from uav_bs_ctrl_amd import ops
+    built = []
+    build = lambda p: built.append(p.numel())  # noqa: E731
+    ops._cached_planes(("k", 1), 16, "cpu", build)
+    ops._cached_planes(("k", 1), 16, "cpu", build)
+    assert built == [16, 16] and ops._PLANES is None
+    with ops.frozen_weights():
+        a = ops._cached_planes(("k", 1), 16, "cpu", build)
+        b = ops._cached_planes(("k", 1), 16, "cpu", build)
+        with ops.frozen_weights():
+            c = ops._cached_planes(("k", 1), 16, "cpu", build)
+            ops._cached_planes(("k", 2), 32, "cpu", build)
+        assert a is b and b is c and built == [16, 16, 16, 32] and len(ops._PLANES) == 2
+    assert ops._PLANES is None
+    try:
+        with ops.frozen_weights():
+            ops._cached_planes(("k", 3), 8, "cpu", build)
+            raise RuntimeError("boom")
+    except RuntimeError:
+        pass
+    assert ops._PLANES is None and built[-1] == 8
+
+
+def test_kernel_timer_filter_selects_spans_by_name():
+    """ops.KERNEL_TIMER.reset(only=...) (bench.py times only the graded kernel inside its timed region): a span outside the
+    filter, or any span of a disabled timer, must not touch the HIP event API at all."""
+    from uav_bs_ctrl_amd import ops
+    t = ops._KernelTimer()
+    t.reset(enabled=True, only=("graded",))
+    with t.span("other") as s:
+        assert s.on is False                 # no event was created (th.cuda.Event would fail on this CPU-only box anyway)
+    t.reset(enabled=False)
+    with t.span("graded") as s:
+        assert s.on is False
+    assert t._spans == {}
