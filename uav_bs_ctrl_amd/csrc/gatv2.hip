@@ -13,6 +13,8 @@
 // Backward produces parameter gradients only (observations are leaves), accumulates them in registers per wave
 // (lane <-> channel), folds the 4 waves of a workgroup in fixed order through LDS and leaves one partial row per
 // workgroup; a second launch sums the rows in fixed order (deterministic, no float atomics).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace uavgnn {
@@ -195,7 +197,8 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
     const int32_t* __restrict__ dst_order, int N,
     const float* __restrict__ W_s, const float* __restrict__ b_s, const float* __restrict__ W_d,
     const float* __restrict__ b_d, const float* __restrict__ attn, float slope, const float* __restrict__ out,
-    const float* __restrict__ d_out, int ld_out, const float* __restrict__ a_save, float* __restrict__ partial) {
+    const float* __restrict__ d_out, int ld_out, const float* __restrict__ a_save, float* __restrict__ partial,
+    int onepass_max_deg) {
   // Per destination v (one wavefront), head k, channel n = (k,d), in-edges u with attention a_uk:
   //   g = d_out * [out > 0];  G[k] = sum_d g[n] W_s[n,:];  de_uk = a_uk (G[k].x_u - T[k]),  T[k] = sum_u a_uk G[k].x_u
   // With lrelu'(z) = c_lin + c_abs sgn(z), c_lin = (1+s)/2, c_abs = (1-s)/2 (SURVEY A.3 i) everything that is linear in
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
   __shared__ float sG[kWavesPerBlock][H];
   __shared__ float sGk[kWavesPerBlock][KF];
   __shared__ float sPS[kWavesPerBlock][2 * KF];   // P[k][f] | Sb[k][f]
-  __shared__ float sE[kWavesPerBlock][kWave * ES];
+  __shared__ float sE[kWavesPerBlock][2 * kWave * ES];   // up to 128 staged edges (two 64-edge chunks)
   __shared__ float sRed[P];
 
   const int tid = threadIdx.x;
@@ -301,30 +304,6 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
       if (part == 0) gk[kf] = gp;
     }
     wave_sync();
-    // T[k] = sum_u a_uk (G[k].x_u): one wave reduction per head
-    float T[NH];
-    {
-      float t[NH];
-#pragma unroll
-      for (int k = 0; k < NH; ++k) t[k] = 0.f;
-      for (int base = 0; base < deg; base += kWave) {
-        if (base + lane < deg) {
-          const int u = e0 + base + lane;
-          float x[FS];
-          load_row<FS>(x_src + static_cast<size_t>(u) * FS, x);
-#pragma unroll
-          for (int k = 0; k < NH; ++k) {
-            float dot = 0.f;
-#pragma unroll
-            for (int f = 0; f < FS; ++f) dot = fmaf(gk[k * FS + f], x[f], dot);
-            t[k] = fmaf(a_save[static_cast<size_t>(u) * NH + k], dot, t[k]);
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < NH; ++k) T[k] = wave_sum(t[k]);
-    }
-
     float S1[J], S2[J][FS];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -333,40 +312,12 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
       for (int f = 0; f < FS; ++f) S2[j][f] = 0.f;
     }
     float accP = 0.f, accSb = 0.f;   // lanes < KF: P[pk][pf], Sb[pk][pf]
-
-    for (int base = 0; base < deg; base += kWave) {
-      {  // stage x_u, de_uk, a_uk of up to 64 edges in LDS (lane <-> edge)
-        const bool valid = base + lane < deg;
-        const int u = e0 + base + lane;
-        float x[FS], de[NH], a[NH];
-        if (valid) {
-          load_row<FS>(x_src + static_cast<size_t>(u) * FS, x);
-#pragma unroll
-          for (int k = 0; k < NH; ++k) {
-            float dot = 0.f;
-#pragma unroll
-            for (int f = 0; f < FS; ++f) dot = fmaf(gk[k * FS + f], x[f], dot);
-            a[k] = a_save[static_cast<size_t>(u) * NH + k];
-            de[k] = a[k] * (dot - T[k]);
-          }
-        } else {
-#pragma unroll
-          for (int f = 0; f < FS; ++f) x[f] = 0.f;
-#pragma unroll
-          for (int k = 0; k < NH; ++k) de[k] = a[k] = 0.f;
-        }
-#pragma unroll
-        for (int f = 0; f < FS; ++f) ew[lane * ES + f] = x[f];
-#pragma unroll
-        for (int k = 0; k < NH; ++k) {
-          ew[lane * ES + FS + k] = de[k];
-          ew[lane * ES + FS + NH + k] = a[k];
-        }
-      }
-      wave_sync();
-      const int cnt = min(kWave, deg - base);
+    // the per-(edge, channel) sums over `cnt` staged edges starting at staged slot `s0` (lane <-> channel, edge data is a
+    // broadcast LDS read)
+    auto run_edges = [&](const int s0, const int cnt) {
 #pragma unroll 4
-      for (int i = 0; i < cnt; ++i) {  // lane <-> channel, edge data is a broadcast LDS read
+      for (int ii = 0; ii < cnt; ++ii) {
+        const int i = s0 + ii;
         float xe[FS];
 #pragma unroll
         for (int f = 0; f < FS; ++f) xe[f] = ew[i * ES + f];
@@ -385,7 +336,118 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
         accP = fmaf(ew[i * ES + FS + pk], xpf, accP);
         accSb = fmaf(ew[i * ES + FS + NH + pk], xpf, accSb);
       }
+    };
+    // T[k] = sum_u a_uk (G[k].x_u): one wave reduction per head
+    float T[NH];
+    if (deg <= onepass_max_deg) {
+      // Up to 128 in-edges (every BASELINE configuration): ONE pass over the edge data.  x_u, a_uk and G[k].x_u of all edges
+      // are staged in LDS while T accumulates (same summation order as the two-pass path: chunk 0, then chunk 1, then the
+      // wave reduction - bit-identical), then every lane turns the staged dots of its edges into de_uk = a_uk (dot - T[k]) in
+      // place.  The second pass of the general path below re-loads x_u and a_uk and recomputes the dots.
+      float t[NH];
+#pragma unroll
+      for (int k = 0; k < NH; ++k) t[k] = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const int slot = ch * kWave + lane;
+        if (ch * kWave < deg) {
+          float x[FS], a[NH], dot[NH];
+          if (slot < deg) {
+            const int u = e0 + slot;
+            load_row<FS>(x_src + static_cast<size_t>(u) * FS, x);
+#pragma unroll
+            for (int k = 0; k < NH; ++k) {
+              float d = 0.f;
+#pragma unroll
+              for (int f = 0; f < FS; ++f) d = fmaf(gk[k * FS + f], x[f], d);
+              dot[k] = d;
+              a[k] = a_save[static_cast<size_t>(u) * NH + k];
+              t[k] = fmaf(a[k], d, t[k]);
+            }
+          } else {
+#pragma unroll
+            for (int f = 0; f < FS; ++f) x[f] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NH; ++k) dot[k] = a[k] = 0.f;
+          }
+#pragma unroll
+          for (int f = 0; f < FS; ++f) ew[slot * ES + f] = x[f];
+#pragma unroll
+          for (int k = 0; k < NH; ++k) {
+            ew[slot * ES + FS + k] = dot[k];
+            ew[slot * ES + FS + NH + k] = a[k];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NH; ++k) T[k] = wave_sum(t[k]);
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const int slot = ch * kWave + lane;
+        if (ch * kWave < deg) {
+#pragma unroll
+          for (int k = 0; k < NH; ++k)      // the lane's own slots: written above by this lane, no synchronisation needed
+            ew[slot * ES + FS + k] = ew[slot * ES + FS + NH + k] * (ew[slot * ES + FS + k] - T[k]);
+        }
+      }
       wave_sync();
+      run_edges(0, deg);
+      wave_sync();
+    } else {
+      {
+        float t[NH];
+#pragma unroll
+        for (int k = 0; k < NH; ++k) t[k] = 0.f;
+        for (int base = 0; base < deg; base += kWave) {
+          if (base + lane < deg) {
+            const int u = e0 + base + lane;
+            float x[FS];
+            load_row<FS>(x_src + static_cast<size_t>(u) * FS, x);
+#pragma unroll
+            for (int k = 0; k < NH; ++k) {
+              float dot = 0.f;
+#pragma unroll
+              for (int f = 0; f < FS; ++f) dot = fmaf(gk[k * FS + f], x[f], dot);
+              t[k] = fmaf(a_save[static_cast<size_t>(u) * NH + k], dot, t[k]);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NH; ++k) T[k] = wave_sum(t[k]);
+      }
+      for (int base = 0; base < deg; base += kWave) {
+        {  // stage x_u, de_uk, a_uk of up to 64 edges in LDS (lane <-> edge)
+          const bool valid = base + lane < deg;
+          const int u = e0 + base + lane;
+          float x[FS], de[NH], a[NH];
+          if (valid) {
+            load_row<FS>(x_src + static_cast<size_t>(u) * FS, x);
+#pragma unroll
+            for (int k = 0; k < NH; ++k) {
+              float dot = 0.f;
+#pragma unroll
+              for (int f = 0; f < FS; ++f) dot = fmaf(gk[k * FS + f], x[f], dot);
+              a[k] = a_save[static_cast<size_t>(u) * NH + k];
+              de[k] = a[k] * (dot - T[k]);
+            }
+          } else {
+#pragma unroll
+            for (int f = 0; f < FS; ++f) x[f] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NH; ++k) de[k] = a[k] = 0.f;
+          }
+#pragma unroll
+          for (int f = 0; f < FS; ++f) ew[lane * ES + f] = x[f];
+#pragma unroll
+          for (int k = 0; k < NH; ++k) {
+            ew[lane * ES + FS + k] = de[k];
+            ew[lane * ES + FS + NH + k] = a[k];
+          }
+        }
+        wave_sync();
+        run_edges(0, min(kWave, deg - base));
+        wave_sync();
+      }
     }
     if (lane < KF) {
       ps[lane] = accP;
@@ -834,12 +896,14 @@ int launch_bwd(const float* x_src, const float* x_dst, const int32_t* seg_off, c
   constexpr int H = NH * D;
   constexpr int P = partial_len<FS>(H);
   const int grid = bwd_blocks(N);
+  // A/B switch: UAVGNN_BWD_ONEPASS=0 sends every destination through the general two-pass path (same bits out)
+  static const int onepass = (getenv("UAVGNN_BWD_ONEPASS") && getenv("UAVGNN_BWD_ONEPASS")[0] == '0') ? 0 : 2 * kWave;
   if (sparse_hint)
     hipLaunchKernelGGL((gatv2_bwd_kernel<FS, NH, D, true>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off,
-                       dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws);
+                       dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws, onepass);
   else
     hipLaunchKernelGGL((gatv2_bwd_kernel<FS, NH, D, false>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off,
-                       dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws);
+                       dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws, onepass);
   int rc = launch_status();
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + kWave - 1) / kWave), dim3(1024), 0, st, ws, grid, P, gp);
