@@ -11,7 +11,8 @@ import os
 import torch as th  # imported first on purpose: libuavgnn must bind to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libuavgnn.so")
+# UAVGNN_LIB: another build of the same library (kernel A/Bs of the probes: a variant compiled with different -D switches)
+LIB_PATH = os.environ.get("UAVGNN_LIB") or os.path.join(_HERE, "csrc", "libuavgnn.so")
 
 _c_fp = ctypes.c_void_p   # const float* / float*
 _c_ip = ctypes.c_void_p   # const int32_t*

@@ -22,6 +22,9 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWave * kWavesPerBlock;
+#ifndef UAVGNN_BWD_UNROLL
+#define UAVGNN_BWD_UNROLL 4
+#endif
 #ifndef UAVGNN_BWD_OCC
 #define UAVGNN_BWD_OCC 2
 #endif
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
     // the per-(edge, channel) sums over `cnt` staged edges starting at staged slot `s0` (lane <-> channel, edge data is a
     // broadcast LDS read)
     auto run_edges = [&](const int s0, const int cnt) {
-#pragma unroll 4
+#pragma unroll UAVGNN_BWD_UNROLL
       for (int ii = 0; ii < cnt; ++ii) {
         const int i = s0 + ii;
         float xe[FS];
