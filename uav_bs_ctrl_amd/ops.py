@@ -356,6 +356,7 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save):
     N, H = h.shape
     h2 = th.empty_like(h)
     pre = th.empty((N, 4 * H), dtype=th.float32, device=h.device) if save else None
+    _apply_variant_env()
     if (GRU_X3 and L.lib().uavgnn_gru_cell_x3_supported(inp.shape[1], H)
             and 4 * N * max(inp.stride(0), H) < 2 ** 32):        # 32-bit byte offsets inside the kernel (3.3 M rows at K_in = 320)
         lib, K_in = L.lib(), inp.shape[1]
@@ -466,14 +467,19 @@ GEMM_X3 = os.environ.get("UAVGNN_GEMM_X3", "1") != "0"   # False: vendor fp32 GE
 _gemm_x3_variant_set = False
 
 
-def gemm_x3_supported(a, n_out, k) -> bool:
+def _apply_variant_env():
+    """A/B switches of the probes from the environment, once (include/uavgnn.h): GEMM 9 / 8 / 4, GRU cell 1 / 0."""
     global _gemm_x3_variant_set
-    if not _gemm_x3_variant_set:   # A/B switches (include/uavgnn.h): GEMM 9 / 8 / 4, GRU cell 1 / 0
+    if not _gemm_x3_variant_set:
         if "UAVGNN_GEMM_X3_VARIANT" in os.environ:
             L.lib().uavgnn_gemm_x3_set_variant(int(os.environ["UAVGNN_GEMM_X3_VARIANT"]))
         if "UAVGNN_GRU_X3_VARIANT" in os.environ:
             L.lib().uavgnn_gru_x3_set_variant(int(os.environ["UAVGNN_GRU_X3_VARIANT"]))
     _gemm_x3_variant_set = True
+
+
+def gemm_x3_supported(a, n_out, k) -> bool:
+    _apply_variant_env()
     return bool(GEMM_X3 and a.is_cuda and a.dtype == th.float32 and a.dim() == 2 and a.stride(1) == 1
                 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and n_out % 128 == 0 and a.shape[0] >= 4096
                 and a.shape[0] * a.stride(0) < 2 ** 31 and L.lib().uavgnn_gemm_x3_supported(a.shape[0], n_out, k))
