@@ -321,6 +321,12 @@ long long uavgnn_gru_cell_x3_workspace_bytes(int K_in, int H);
 int uavgnn_gru_split_weights(const float* W_ih, int K_in, const float* W_hh, int H, void* planes, uavgnn_stream_t stream);
 int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, const float* h, int N, int H, const void* planes,
                            const float* b_ih, const float* b_hh, float* h_out, float* pre_save, uavgnn_stream_t stream);
+/* The same call with the cell's input given as TWO pieces [inp (K1 columns) || inp2 (K2 columns)] - the TarMAC step's
+ * th.cat([x, c]) (gnn_agents.py:268-270) without the concatenated copy; K1, K2 multiples of 32 (K2 = 0: one piece), `planes`
+ * built for K_in = K1 + K2. */
+int uavgnn_gru_cell_fwd_x3_cat(const float* inp, int ld_inp, int K1, const float* inp2, int ld_inp2, int K2, const float* h,
+                               int N, int H, const void* planes, const float* b_ih, const float* b_hh, float* h_out,
+                               float* pre_save, uavgnn_stream_t stream);
 /* Dense layers on the bf16 matrix cores (csrc/gemm_x3.hip; reference: the nn.Linear layers of
  * algos/madrqn/agents/gnn_agents.py - f_aggr :101-102, :106, TarMAC projections :227-236 - and the input-gradient GEMMs of
  * loss.backward(), learner.py:157): Y[M, N] = X[M, K] B[N, K]^T (+ bias[N]) (+ Y) (then ReLU), fp32 in / out, each fp32 product

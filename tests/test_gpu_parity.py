@@ -7,7 +7,7 @@ import pytest
 import torch as th
 
 from oracle import restatement as R
-from tests.gpu_util import agent_from_params, default_init_params, synth_graph, to_batch
+from tests.gpu_util import agent_from_params, default_init_params, make_args, synth_graph, to_batch
 from tests.util import assert_close, grad_close, load_golden, load_learner_golden
 
 pytestmark = pytest.mark.gpu
@@ -1841,3 +1841,44 @@ def test_frozen_weights_scope_reuses_planes_and_changes_nothing():
         ref = cell.double()(inp.double(), h.double())
         assert float((y3.double() - ref).abs().max()) <= 1e-5
         assert float((g3 - 2.0 * g0).abs().max()) == 0.0        # a power-of-two scale commutes with every rounding
+
+
+def test_two_piece_gru_input_equals_the_concatenated_input():
+    """uavgnn_gru_cell_fwd_x3_cat: the cell's input given as [x || c] from two buffers (no-grad TarMAC steps skip the
+    concatenating copy) must produce the bits of the one-buffer call - same kernel, same slices, different base pointers."""
+    from uav_bs_ctrl_amd import ops
+    th.manual_seed(11)
+    N, H, M = 5000, 256, 64          # not a multiple of the 128-row tile: the clamped tail rows are covered
+    cell = th.nn.GRUCell(H + M, H).cuda()
+    x, c, h = th.randn(N, H, device="cuda"), th.randn(N, M, device="cuda"), th.randn(N, H, device="cuda")
+    with th.no_grad():
+        assert ops.gru_cell_two_piece_supported(x, c, h)
+        cat = th.cat((x, c), 1)
+        y_cat, _ = ops._gru_cell_launch(cat, h, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, save=False)
+        y_two, _ = ops._gru_cell_launch(x, h, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, save=False, inp2=c)
+        assert th.equal(y_cat, y_two)
+        ref = cell.double()(cat.double(), h.double())
+        assert float((y_two.double() - ref).abs().max()) <= 1e-5
+        # strided pieces (views into wider buffers) take the same path
+        wide_x, wide_c = th.randn(N, H + 64, device="cuda"), th.randn(N, M + 32, device="cuda")
+        xv, cv = wide_x[:, :H], wide_c[:, :M]
+        assert ops.gru_cell_two_piece_supported(xv, cv, h)
+        y_v, _ = ops._gru_cell_launch(xv, h, cell.float().weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, save=False, inp2=cv)
+        y_r, _ = ops._gru_cell_launch(th.cat((xv, cv), 1), h, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, save=False)
+        assert th.equal(y_v, y_r)
+
+
+def test_no_grad_tarmac_step_without_the_concatenated_copy_equals_the_training_forward():
+    """agent forward under no_grad (two-piece cell input, K3b writes c alone) vs the same forward with grad enabled (the
+    [x || c] buffer is built and kept for the backward): same logits and hidden state, bit for bit."""
+    cfg = dict(enc="gnn", c="tarmac", n_heads=4, key_size=16, msg_size=64, n_rounds=1, dueling=False, hidden_size=256)
+    B, n, M = 160, 8, 20
+    from uav_bs_ctrl_amd import GnnAgent
+    th.manual_seed(5)
+    agent = GnnAgent(dict(agent=2, ubs=2, gt=4), 9, make_args(cfg)).cuda()
+    g = to_batch(synth_graph(B, n, M, "ragged", seed=3))
+    h = 0.3 * th.randn(B * n, 256, device="cuda")
+    with th.no_grad():
+        q0, h0 = agent(g, h)
+    q1, h1 = agent(g.fresh(), h.clone().requires_grad_(True))
+    assert th.equal(q0, q1.detach()) and th.equal(h0, h1.detach())

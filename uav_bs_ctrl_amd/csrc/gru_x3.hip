@@ -76,7 +76,8 @@ constexpr int BUF = 3 * PA + 3 * PB;                   // chunks per buffer (60 
 
 template <bool SAVE, bool IL>
 __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
-    const float* __restrict__ inp, int ld_inp, int K1, const float* __restrict__ h, int N, int H,
+    const float* __restrict__ inp, int ld_inp, int K1, const float* __restrict__ inp2, int ld_inp2, int K2,
+    const float* __restrict__ h, int N, int H,
     const unsigned short* __restrict__ Wih_p, const float* __restrict__ b_ih, const unsigned short* __restrict__ Whh_p,
     const float* __restrict__ b_hh, float* __restrict__ h_out, float* __restrict__ pre, int row_blocks) {
   using namespace w8;
@@ -99,50 +100,72 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
   const int lr = tid >> 3, c4 = tid & 7;
   const int sa_w = lr * 32 + (((c4 >> 1) ^ swz32(lr)) * 8) + (c4 & 1) * 4;   // in bf16 units inside an A plane
   // B loader: chunk q = tid + 512 i (i < 5, 2304 chunks): plane q / 768, row (q % 768) / 4 = gate * 64 + unit, chunk q % 4
-  // Per-lane BYTE offsets of both phases ([x || c] / W_ih, then h / W_hh) are computed once; a slice adds a scalar to the base
-  // pointer (global_load with an SGPR base + 32-bit VGPR offset: no per-slice address arithmetic on the VALU).
-  unsigned oa1[2], oa2[2], ow1[5], ow2[5];
+  // Loads walk the K slices through a CURSOR: scalar base pointers of the activation piece / weight-plane set in use, advanced
+  // by one slice per load, plus per-lane BYTE offsets of that piece (global_load with an SGPR base + 32-bit VGPR offset: no
+  // per-slice address arithmetic on the VALU).  At a piece boundary - [inp (K1 columns) || inp2 (K2 columns)] against W_ih, then
+  // h against W_hh; inp2 is the TarMAC step's c without the concatenated [x || c] copy, K2 = 0: one piece - a wave-uniform
+  // branch re-bases the cursor and recomputes the lane offsets (twice per kernel).
+  unsigned rowa[2], wrow[5];
   int sbw[5];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const unsigned row = static_cast<unsigned>(min(m0 + lr + 64 * i, N - 1));
-    oa1[i] = 4u * (row * static_cast<unsigned>(ld_inp) + 4u * c4);
-    oa2[i] = 4u * (row * static_cast<unsigned>(H) + 4u * c4);
-  }
+  for (int i = 0; i < 2; ++i) rowa[i] = static_cast<unsigned>(min(m0 + lr + 64 * i, N - 1));
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int q = min(tid + NT * i, 3 * PB - 1), pl = q / PB, rem = q - pl * PB, row = rem >> 2, c = rem & 3;
-    const unsigned wrow = static_cast<unsigned>(pl * 3 * H + (row >> 6) * H + j0 + (row & 63));
-    ow1[i] = 2u * (wrow * static_cast<unsigned>(K1) + 8u * c);
-    ow2[i] = 2u * (wrow * static_cast<unsigned>(H) + 8u * c);
+    wrow[i] = static_cast<unsigned>(pl * 3 * H + (row >> 6) * H + j0 + (row & 63));
     sbw[i] = 3 * PA + pl * PB + row * 4 + (c ^ swz32(row));
   }
-  const int n1 = K1 / BK, ns = n1 + H / BK;
+  // byte offset of the lane's 8-bf16 chunk inside a weight slice: chunk q % 4 (= tid % 4, except for the clamped i = 4 of tid >= 256)
+  const unsigned wc8 = 16u * (tid & 3), wc8_last = 16u * (min(tid + NT * 4, 3 * PB - 1) & 3);
+  const int n1 = K1 / BK, n12 = n1 + K2 / BK, ns = n12 + H / BK;   // slices of inp, of [inp || inp2], of everything
   float4 ra[2];
   u32x4 rw[5];
-  // slice t (clamped by the caller): t < n1 reads [x || c] and W_ih, else h and W_hh
+  unsigned oa[2], ow[5];
+  const char* __restrict__ Ab = reinterpret_cast<const char*>(inp);
+  const char* __restrict__ Wb = reinterpret_cast<const char*>(Wih_p);
+  int lt = 0;                                                // the slice the next load fetches
+  auto set_a = [&](const float* base, int ld) {
+    Ab = reinterpret_cast<const char*>(base);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) oa[i] = 4u * (rowa[i] * static_cast<unsigned>(ld) + 4u * c4);
+  };
+  auto set_w = [&](const unsigned short* base, int K) {
+    Wb = reinterpret_cast<const char*>(base);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) ow[i] = 2u * wrow[i] * static_cast<unsigned>(K) + (i == 4 ? wc8_last : wc8);
+  };
+  set_a(inp, ld_inp);
+  set_w(Wih_p, K1 + K2);
 #ifndef UAVGNN_X3_DBG_LD
 #define UAVGNN_X3_DBG_LD 3   /* timing experiments: bit 0 = activation loads, bit 1 = weight-plane loads inside the slice loop */
 #endif
-  auto gload_a = [&](int t) {
-    const bool p1 = t < n1;
-    const char* __restrict__ Ab = reinterpret_cast<const char*>(p1 ? inp : h) + 4 * ((p1 ? t : t - n1) * BK);
-    if ((UAVGNN_X3_DBG_LD & 1) || t < 2) {
+  auto gload_a = [&]() {
+    if ((UAVGNN_X3_DBG_LD & 1) || lt < 2) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(Ab + (p1 ? oa1[i] : oa2[i]));
+      for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(Ab + oa[i]);
     }
   };
-  auto gload_w = [&](int t) {
-    const bool p1 = t < n1;
-    const char* __restrict__ Wb = reinterpret_cast<const char*>(p1 ? Wih_p : Whh_p) + 2 * ((p1 ? t : t - n1) * BK);
-    if ((UAVGNN_X3_DBG_LD & 2) || t < 2) {
+  auto gload_w = [&]() {
+    if ((UAVGNN_X3_DBG_LD & 2) || lt < 2) {
 #pragma unroll
-      for (int i = 0; i < 5; ++i) rw[i] = *reinterpret_cast<const u32x4*>(Wb + (p1 ? ow1[i] : ow2[i]));
+      for (int i = 0; i < 5; ++i) rw[i] = *reinterpret_cast<const u32x4*>(Wb + ow[i]);
     }
   };
-  auto gload = [&](int t) {
-    gload_a(t);
-    gload_w(t);
+  auto advance = [&]() {      // after both loads of slice lt were issued; past the last slice the cursor stays on it
+    if (lt + 1 >= ns) return;
+    ++lt;
+    Ab += 4 * BK;
+    Wb += 2 * BK;
+    if (lt == n1 && n12 > n1) set_a(inp2, ld_inp2);
+    if (lt == n12) {
+      set_a(h, H);
+      set_w(Whh_p, H);
+    }
+  };
+  auto gload = [&]() {
+    gload_a();
+    gload_w();
+    advance();
   };
   auto lstore_b = [&](int buf) {
     u32x4* sb = smem + buf * BUF;
@@ -184,9 +207,9 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
     UAVGNN_X3_FOR_TERMS(UAVGNN_X3_W8_TERM)         \
   }
 
-  gload(0);
+  gload();
   lstore(0);
-  gload(min(1, ns - 1));
+  gload();
   __syncthreads();
   // Software pipeline over the halves: the fragment reads of a half are issued one MFMA group (18 MFMAs = 576 cycles) before
   // their use - f1 = (slice t, second half) under the MFMAs of f0, f0 = (slice t + 1, first half) right after the barrier
@@ -208,14 +231,14 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
   UAVGNN_X3_W8_READ(f1, t & 1, 1)                          \
   if (early) {                                             \
     if (UAVGNN_X3_DBG < 2) lstore((t + 1) & 1);            \
-    if (UAVGNN_X3_DBG < 1) gload(min(t + 2, ns - 1));      \
+    if (UAVGNN_X3_DBG < 1) gload();                        \
   }                                                        \
   __builtin_amdgcn_sched_barrier(0);                       \
   UAVGNN_X3_W8_MFMA(f0, NSET)                              \
   __builtin_amdgcn_sched_barrier(0);                       \
   if (!early) {                                            \
     if (UAVGNN_X3_DBG < 2) lstore((t + 1) & 1);            \
-    if (UAVGNN_X3_DBG < 1) gload(min(t + 2, ns - 1));      \
+    if (UAVGNN_X3_DBG < 1) gload();                        \
   }                                                        \
   __syncthreads();                                         \
   UAVGNN_X3_W8_READ(f0, (t + 1) & 1, 0)                    \
@@ -233,9 +256,8 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
     UAVGNN_X3_W8_READ(f1, t & 1, 1)                        \
     __builtin_amdgcn_sched_barrier(0);                     \
     const Half& F = f0;                                    \
-    const int tn = min(t + 2, ns - 1);                     \
     if (UAVGNN_X3_DBG < 2) lstore_b((t + 1) & 1);          \
-    if (UAVGNN_X3_DBG < 1) gload_w(tn);                    \
+    if (UAVGNN_X3_DBG < 1) gload_w();                      \
     UAVGNN_X3_W8_TERM(0, 2)                                \
     _Pragma("unroll") for (int sg = 0; sg < 3; ++sg) {     \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
@@ -252,7 +274,7 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
       __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   \
     }                                                      \
     __builtin_amdgcn_sched_barrier(0);                     \
-    if (UAVGNN_X3_DBG < 1) gload_a(tn);                    \
+    if (UAVGNN_X3_DBG < 1) gload_a();                      \
     UAVGNN_X3_W8_TERM(0, 0)                                \
     _Pragma("unroll") for (int sg = 0; sg < 3; ++sg) {     \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
@@ -260,6 +282,7 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   \
     }                                                      \
     __builtin_amdgcn_sched_barrier(0);                     \
+    if (UAVGNN_X3_DBG < 1) advance();                      \
   }                                                        \
   __syncthreads();                                         \
   UAVGNN_X3_W8_READ(f0, (t + 1) & 1, 0)                    \
@@ -268,10 +291,10 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
   __builtin_amdgcn_sched_barrier(0);
   if (UAVGNN_X3_DBG == 3) t = ns;   /* timing experiment: prologue + epilogue only */
   if (IL) {
-    for (; t < n1; ++t) { UAVGNN_X3_W8_STEP_IL(2) }
+    for (; t < n12; ++t) { UAVGNN_X3_W8_STEP_IL(2) }
     for (; t < ns; ++t) { UAVGNN_X3_W8_STEP_IL(3) }
   } else {
-    for (; t < n1; ++t) { UAVGNN_X3_W8_STEP_BLK(2) }
+    for (; t < n12; ++t) { UAVGNN_X3_W8_STEP_BLK(2) }
     for (; t < ns; ++t) { UAVGNN_X3_W8_STEP_BLK(3) }
   }
 #undef UAVGNN_X3_W8_STEP_IL
@@ -353,25 +376,31 @@ extern "C" int uavgnn_gru_split_weights(const float* W_ih, int K_in, const float
   return launch_status();
 }
 
-extern "C" int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, const float* h, int N, int H,
-                                      const void* planes, const float* b_ih, const float* b_hh, float* h_out,
-                                      float* pre_save, uavgnn_stream_t stream) {
-  if (N < 0 || !inp || !h || !planes || !b_ih || !b_hh || !h_out || ld_inp < K_in) return UAVGNN_EINVAL;
-  if (!uavgnn_gru_cell_x3_supported(K_in, H) || (ld_inp & 3) ||
-      ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(planes) |
-        reinterpret_cast<uintptr_t>(h_out)) & 15))
+extern "C" int uavgnn_gru_cell_fwd_x3_cat(const float* inp, int ld_inp, int K1, const float* inp2, int ld_inp2, int K2,
+                                          const float* h, int N, int H, const void* planes, const float* b_ih,
+                                          const float* b_hh, float* h_out, float* pre_save, uavgnn_stream_t stream) {
+  const int K_in = K1 + K2;
+  if (N < 0 || !inp || !h || !planes || !b_ih || !b_hh || !h_out || ld_inp < K1 || K2 < 0 || (K2 > 0 && (!inp2 || ld_inp2 < K2)))
+    return UAVGNN_EINVAL;
+  if (K2 == 0) {
+    inp2 = inp;
+    ld_inp2 = ld_inp;
+  }
+  if (!uavgnn_gru_cell_x3_supported(K_in, H) || K1 < BK || (K1 % BK) || (K2 % BK) || (ld_inp & 3) || (ld_inp2 & 3) ||
+      ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(inp2) | reinterpret_cast<uintptr_t>(h) |
+        reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(h_out)) & 15))
     return UAVGNN_EUNSUPPORTED;
   // the kernel addresses its operands by 32-bit BYTE offsets from the base pointers (global_load with an SGPR base)
-  if (4LL * N * (ld_inp > H ? ld_inp : H) >= (1LL << 32) || 18LL * H * (K_in > H ? K_in : H) >= (1LL << 32))
-    return UAVGNN_EUNSUPPORTED;
+  const long long ld_max = ld_inp > ld_inp2 ? (ld_inp > H ? ld_inp : H) : (ld_inp2 > H ? ld_inp2 : H);
+  if (4LL * N * ld_max >= (1LL << 32) || 18LL * H * (K_in > H ? K_in : H) >= (1LL << 32)) return UAVGNN_EUNSUPPORTED;
   if (N == 0) return 0;
   const unsigned short* p0 = static_cast<const unsigned short*>(planes);
   const unsigned short* p1 = p0 + 9LL * H * K_in;
   const int row_blocks = (N + BM - 1) / BM, rb8 = ((row_blocks + 7) / 8) * 8;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define UAVGNN_X3_LAUNCH(KERNEL, BJ_, NT_)                                                                              \
-  hipLaunchKernelGGL(KERNEL, dim3(rb8 * (H / (BJ_))), dim3(NT_), 0, st, inp, ld_inp, K_in, h, N, H, p0, b_ih, p1, b_hh, \
-                     h_out, pre_save, row_blocks)
+#define UAVGNN_X3_LAUNCH(KERNEL, BJ_, NT_)                                                                                  \
+  hipLaunchKernelGGL(KERNEL, dim3(rb8 * (H / (BJ_))), dim3(NT_), 0, st, inp, ld_inp, K1, inp2, ld_inp2, K2, h, N, H, p0, b_ih, \
+                     p1, b_hh, h_out, pre_save, row_blocks)
   if (g_gru_x3_interleave) {
     if (pre_save != nullptr) UAVGNN_X3_LAUNCH((gru_cell_fwd_x3w8_kernel<true, true>), w8::BJ, w8::NT);
     else UAVGNN_X3_LAUNCH((gru_cell_fwd_x3w8_kernel<false, true>), w8::BJ, w8::NT);
@@ -381,4 +410,10 @@ extern "C" int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, co
   }
 #undef UAVGNN_X3_LAUNCH
   return launch_status();
+}
+
+extern "C" int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, const float* h, int N, int H,
+                                      const void* planes, const float* b_ih, const float* b_hh, float* h_out,
+                                      float* pre_save, uavgnn_stream_t stream) {
+  return uavgnn_gru_cell_fwd_x3_cat(inp, ld_inp, K_in, nullptr, 0, 0, h, N, H, planes, b_ih, b_hh, h_out, pre_save, stream);
 }

@@ -351,15 +351,27 @@ def _cached_planes(key, nbytes, device, build):
     return planes
 
 
-def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save):
-    """h' (and the [N, 4H] pre-activation sets when `save`) of the fused GRU cell."""
+def gru_cell_two_piece_supported(x, c, h) -> bool:
+    """The bf16x3 cell takes its input as [x || c] from two buffers (no concatenated copy) when both pieces are multiples of
+    32 columns wide, 16-byte aligned with row strides of whole float4s."""
+    K1, K2, H = x.shape[1], c.shape[1], h.shape[1]
+    return bool(GRU_X3 and K1 >= 32 and K1 % 32 == 0 and K2 % 32 == 0 and x.stride(1) == 1 and c.stride(1) == 1
+                and x.stride(0) % 4 == 0 and c.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and c.data_ptr() % 16 == 0
+                and L.lib().uavgnn_gru_cell_x3_supported(K1 + K2, H)
+                and 4 * x.shape[0] * max(x.stride(0), c.stride(0), H) < 2 ** 32)
+
+
+def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save, inp2=None):
+    """h' (and the [N, 4H] pre-activation sets when `save`) of the fused GRU cell.  inp2: second piece of the input
+    ([inp || inp2] is what W_ih multiplies; the caller checked gru_cell_two_piece_supported)."""
     N, H = h.shape
     h2 = th.empty_like(h)
     pre = th.empty((N, 4 * H), dtype=th.float32, device=h.device) if save else None
     _apply_variant_env()
-    if (GRU_X3 and L.lib().uavgnn_gru_cell_x3_supported(inp.shape[1], H)
-            and 4 * N * max(inp.stride(0), H) < 2 ** 32):        # 32-bit byte offsets inside the kernel (3.3 M rows at K_in = 320)
-        lib, K_in = L.lib(), inp.shape[1]
+    if inp2 is not None or (GRU_X3 and L.lib().uavgnn_gru_cell_x3_supported(inp.shape[1], H)
+                            and 4 * N * max(inp.stride(0), H) < 2 ** 32):   # 32-bit byte offsets inside the kernel (3.3 M rows at K_in = 320)
+        lib, K1, K2 = L.lib(), inp.shape[1], (0 if inp2 is None else inp2.shape[1])
+        K_in = K1 + K2
         with KERNEL_TIMER.span("gru_cell_fwd", (N, K_in, H, "bf16x3")):
             # the planes are rebuilt on every call outside a frozen_weights() scope: nothing observable tells when a drop-in
             # module's weights changed
@@ -368,9 +380,10 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save):
                                     lambda p: L.check(lib.uavgnn_gru_split_weights(W_ih.data_ptr(), K_in, W_hh.data_ptr(), H,
                                                                                    p.data_ptr(), L.stream()),
                                                       "uavgnn_gru_split_weights"))
-            rc = lib.uavgnn_gru_cell_fwd_x3(inp.data_ptr(), inp.stride(0), K_in, h.data_ptr(), N, H, planes.data_ptr(),
-                                            b_ih.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), L.ptr(pre), L.stream())
-        L.check(rc, "uavgnn_gru_cell_fwd_x3")
+            rc = lib.uavgnn_gru_cell_fwd_x3_cat(inp.data_ptr(), inp.stride(0), K1, L.ptr(inp2),
+                                                0 if inp2 is None else inp2.stride(0), K2, h.data_ptr(), N, H, planes.data_ptr(),
+                                                b_ih.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), L.ptr(pre), L.stream())
+        L.check(rc, "uavgnn_gru_cell_fwd_x3_cat")
         return h2, pre
     with KERNEL_TIMER.span("gru_cell_fwd", (N, inp.shape[1], H, "f32")):
         rc = L.lib().uavgnn_gru_cell_fwd(inp.data_ptr(), inp.stride(0), inp.shape[1], h.data_ptr(), N, H, W_ih.data_ptr(),
@@ -771,24 +784,39 @@ class _TarmacStep(th.autograd.Function):
         else:
             proj = th.addmm(bp, x, Wp[:, :H].t())
             proj.addmm_(h, Wp[:, H:].t())                                 # [N, M + 2K]: value | signature | query
-        inp = th.empty((N, H + M), dtype=th.float32, device=x.device)     # [x || c], both halves filled by K3b
         E = talk_src.shape[0]
         a_save = th.empty(max(E, 1), dtype=th.float32, device=x.device)
         ld = M + 2 * K
-        _launch_talk_fwd(env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld, K, M,
-                         talk_off, talk_src, N, 1.0 / K, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(), x.data_ptr(),
-                         x.stride(0), H)
-        fused = gru_cell_supported(inp, h) and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (W_ih, W_hh))
-        if fused:      # K4 in one launch: gi / gh never reach HBM; training forwards keep the [N, 4H] pre-activation sets
-            h2, pre = _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save=bool(train))
-            gi = gh = pre if pre is not None else h2           # placeholders keep save_for_backward's arity
+        aligned = all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (W_ih, W_hh))
+        c_only = None
+        if not train and aligned and h.shape[0] >= GRU_FUSED_MIN_ROWS and GRU_FUSED:
+            c_only = th.empty((N, M), dtype=th.float32, device=x.device)
+            if not gru_cell_two_piece_supported(x, c_only, h):
+                c_only = None
+        if c_only is not None:
+            # no-grad call (rollout, target network): nothing keeps [x || c] for a backward, so K3b writes c alone and the cell
+            # reads its input from the two buffers - the 2 x 4 H bytes per agent of the concatenating copy disappear
+            _launch_talk_fwd(env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld, K, M,
+                             talk_off, talk_src, N, 1.0 / K, c_only.data_ptr(), M, a_save.data_ptr(), None, 0, 0)
+            h2, _ = _gru_cell_launch(x, h, W_ih, b_ih, W_hh, b_hh, save=False, inp2=c_only)
+            inp, fused = c_only, True
+            gi = gh = h2                                           # placeholders keep save_for_backward's arity
         else:
-            gi = th.addmm(b_ih, inp, W_ih.t())
-            gh = th.addmm(b_hh, h, W_hh.t())
-            h2 = th.empty_like(h)
-            with KERNEL_TIMER.span("gru_gates_fwd"):
-                rc = L.lib().uavgnn_gru_gates_fwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), N, H, h2.data_ptr(), L.stream())
-            L.check(rc, "uavgnn_gru_gates_fwd")
+            inp = th.empty((N, H + M), dtype=th.float32, device=x.device)     # [x || c], both halves filled by K3b
+            _launch_talk_fwd(env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld, K, M,
+                             talk_off, talk_src, N, 1.0 / K, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(), x.data_ptr(),
+                             x.stride(0), H)
+            fused = gru_cell_supported(inp, h) and aligned
+            if fused:      # K4 in one launch: gi / gh never reach HBM; training forwards keep the [N, 4H] pre-activation sets
+                h2, pre = _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save=bool(train))
+                gi = gh = pre if pre is not None else h2           # placeholders keep save_for_backward's arity
+            else:
+                gi = th.addmm(b_ih, inp, W_ih.t())
+                gh = th.addmm(b_hh, h, W_hh.t())
+                h2 = th.empty_like(h)
+                with KERNEL_TIMER.span("gru_gates_fwd"):
+                    rc = L.lib().uavgnn_gru_gates_fwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), N, H, h2.data_ptr(), L.stream())
+                L.check(rc, "uavgnn_gru_gates_fwd")
         q = th.addmm(b_out, h2, W_out.t())
         ctx.dims = (M, K)
         ctx.split, ctx.env, ctx.dx_out, ctx.fused_gru = split, env, dx_out, fused
