@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""K1 forward (fused launch) run twice into poisoned outputs + once through the fp32-MFMA build: reports elements that differ
+between the two runs (non-determinism / unwritten rows) and against the fp32 build (values).  Debug aid.
+
+    python tools/k1_check.py [--dist dense|env] [--B 1024] [--n 4] [--M 40] [--save]
+"""
+import argparse
+import os
+import sys
+
+import torch as th
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import synth_batch_gpu  # noqa: E402
+from uav_bs_ctrl_amd import _lib as L  # noqa: E402
+from uav_bs_ctrl_amd.agents.gnn_agents import GATv2Conv  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--dist", default="dense")
+ap.add_argument("--B", type=int, default=1024)
+ap.add_argument("--n", type=int, default=4)
+ap.add_argument("--M", type=int, default=40)
+ap.add_argument("--save", action="store_true")
+ap.add_argument("--no-order", action="store_true")
+a = ap.parse_args()
+dev = th.device("cuda")
+gen = th.Generator(device=dev)
+gen.manual_seed(0)
+th.manual_seed(0)
+hb = synth_batch_gpu(a.B, a.n, a.M, a.dist, dev, gen)
+xs, so = hb.relation_segments("seen")
+xn, no = hb.relation_segments("near")
+order = None if a.no_order else hb.relation_order("seen")
+x_a = hb.agent_feat()
+N = x_a.shape[0]
+ps = []
+for FS in (4, 2):
+    c = GATv2Conv((FS, 2), 64, 4).to(dev)
+    ps.append([t.detach().contiguous() for t in (c.fc_src.weight, c.fc_src.bias, c.fc_dst.weight, c.fc_dst.bias, c.attn,
+                                                 c.res_fc.weight, c.res_fc.bias)])
+lib, st = L.lib(), L.stream()
+
+
+def run(phases):
+    out = th.full((N, 512), float("nan"), device=dev)
+    a_s = th.full((max(xs.shape[0], 1), 4), float("nan"), device=dev)
+    a_n = th.full((max(xn.shape[0], 1), 4), float("nan"), device=dev)
+    rc = lib.uavgnn_gatv2_hetero_fwd_phases(xs.data_ptr(), xs.shape[0], so.data_ptr(), L.ptr(order), xn.data_ptr(), xn.shape[0],
+                                            no.data_ptr(), x_a.data_ptr(), N, L.ptr_array(ps[0]), L.ptr_array(ps[1]), 4, 64, 0.2,
+                                            out.data_ptr(), 512, a_s.data_ptr() if a.save else None,
+                                            a_n.data_ptr() if a.save else None, phases, st)
+    assert rc == 0
+    th.cuda.synchronize()
+    return out, a_s, a_n
+
+
+def report(what, x, y, tol):
+    bad = ~((x - y).abs() <= tol * (1 + y.abs()))   # NaN counts as bad
+    print(f"{what}: {int(bad.sum())} of {bad.numel()} differ", end="")
+    if bad.any() and x.dim() == 2 and x.shape[1] == 512:
+        rows = bad.any(1).nonzero().flatten()
+        cols = bad.any(0).nonzero().flatten()
+        print(f"; rows {rows[:12].tolist()} ({len(rows)}), rows % 16 {th.bincount(rows % 16, minlength=16).tolist()}, "
+              f"cols {int(cols.min())}..{int(cols.max())} ({len(cols)}), NaN {int(th.isnan(x).sum())}", end="")
+    print()
+
+
+o1, s1, n1 = run(3)
+for rep in range(5):
+    o2, s2, n2 = run(3)
+    report(f"run {rep + 2} vs run 1", o2, o1, 0.0)
+of, sf, nf = run(3 | 256)
+report("bf16 build vs fp32-MFMA build", o1, of, 1e-5)
+for o in (o1, o2):
+    bad = ~((o - of).abs() <= 1e-5 * (1 + of.abs()))
+    if bad.any():
+        r = int(bad.any(1).nonzero()[0])
+        cs = bad[r].nonzero().flatten().tolist()
+        print("row", r, "cols", cs)
+        for c in cs[:8]:
+            w = float(o[r, c])
+            near = ((of - w).abs() < 1e-6 * (1 + abs(w))).nonzero()[:6].tolist()
+            print(f"  col {c}: got {w:.8e} want {float(of[r, c]):.8e}; the fp32 build has that value at {near}")
+if a.save:
+    report("saved near weights", n1, nf, 1e-5)
+    report("saved seen weights", s1, sf, 1e-5)
+print("N", N, "E_seen", xs.shape[0], "E_near", xn.shape[0])

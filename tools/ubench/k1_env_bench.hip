@@ -1,10 +1,14 @@
 // Stand-alone timing of the fused K1 forward (csrc/gatv2_hetero.hip) at C3 size on SURVEY's degree distributions, without
 // Python: back-to-back launches between two events, whole kernel and phase ablations, + a checksum of the output so that
 // variants can be compared for equality.  argv[1]: dist (env | dense | zero), argv[2]: B (default 4096).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iuav_bs_ctrl_amd/csrc [-D...] tools/ubench/k1_env_bench.hip -o tools/ubench/bin/k1_env_bench
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iuav_bs_ctrl_amd/csrc [-DK1_OLD] [-D...] tools/ubench/k1_env_bench.hip -o tools/ubench/bin/k1_env_bench[_pair]
 #define K1_ABLATE 1
 #define K1_STANDALONE 1
+#if defined(K1_OLD)   // the rounds 1-3 kernel (pairs of destinations per row tile in phase N): -DK1_OLD [-DK1_BF16Z=0]
+#include "../../uav_bs_ctrl_amd/csrc/gatv2_hetero_pair.inc"
+#else
 #include "../../uav_bs_ctrl_amd/csrc/gatv2_hetero.hip"
+#endif
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -116,13 +120,13 @@ int main(int argc, char** argv) {
     printf("streaming write of %.1f MB, %4d blocks: plain %6.2f us (%.2f TB/s)  nontemporal %6.2f us (%.2f TB/s)\n", n4 * 16 / 1e6, g,
            t0, n4 * 16 / t0 / 1e6, t1, n4 * 16 / t1 / 1e6);
   }
-  for (int ph : {3, 2, 1, 0, 2 | 32, 2 | 64, 2 | 32 | 64}) {
+  for (int ph : {3, 2, 2 | 2048, 1, 0, 2 | 32, 2 | 64, 2 | 128, 2 | 32 | 64 | 128}) {
     auto run = [&] {
       int rc = uavgnn_gatv2_hetero_fwd_phases(d_xg, Es, d_so, d_ord, d_xu, En, d_no, d_xa, N, ps, pn, 4, 64, 0.2f, out, 2 * H,
                                               nullptr, nullptr, ph, nullptr);
       if (rc) { printf("rc %d\n", rc); exit(1); }
     };
-    hipMemset(out, 0, size_t(N) * 2 * H * 4);
+    hipMemset(out, getenv("K1_POISON") ? 0xff : 0, size_t(N) * 2 * H * 4);   // K1_POISON: unwritten elements stay NaN
     for (int i = 0; i < 3; ++i) run();
     hipEventRecord(e0);
     for (int i = 0; i < reps; ++i) run();
@@ -131,11 +135,47 @@ int main(int argc, char** argv) {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     hipMemcpy(host.data(), out, host.size() * 4, hipMemcpyDeviceToHost);
+    if (getenv("K1_POISON")) {
+      size_t bad = 0, first = 0;
+      for (size_t i = 0; i < host.size(); ++i) if (host[i] != host[i]) { if (!bad) first = i; ++bad; }
+      printf("phases %3d: %zu unwritten elements (first: row %zu col %zu)\n", ph, bad, first / (2 * H), first % (2 * H));
+    }
     double cs = 0, ca = 0;
     for (size_t i = 0; i < host.size(); ++i) { cs += host[i] * double((i % 977) + 1); ca += fabs(host[i]); }
+    if (const char* dp = getenv("K1_DUMP")) {   // raw output of the first listed phase set, for element-wise comparison of two builds
+      if (ph == 3) { FILE* f = fopen(dp, "wb"); fwrite(host.data(), 4, host.size(), f); fclose(f); }
+    }
     const double us = ms * 1e3 / reps;
     printf("phases %3d: %8.2f us  %7.1f GB/s alg (%.3f of 8 TB/s)   checksum %.9e  abs %.9e\n", ph, us, bytes / us / 1e3,
            bytes / us / 1e3 / 8000.0, cs, ca);
   }
+#if !defined(K1_OLD)
+  {  // time line of the wavefronts of ONE launch (phases bit 10): 100 MHz stamps at entry, after the workgroup prologue, after the
+     // phase-N operand loads, after the residual-only rows / the score tiles / the `near` rows of the first block were issued,
+     // after the wave's stores have drained, after phase S
+    const int waves = 256 * 8;
+    unsigned long long* d_dbg;
+    hipMalloc(&d_dbg, size_t(waves) * 8 * 8);
+    std::vector<unsigned long long> st(size_t(waves) * 8);
+    for (int ph : {3, 2}) {
+      for (int rep = 0; rep < 3; ++rep) {
+        hipMemset(d_dbg, 0, size_t(waves) * 64);
+        uavgnn_gatv2_hetero_fwd_phases(d_xg, Es, d_so, d_ord, d_xu, En, d_no, d_xa, N, ps, pn, 4, 64, 0.2f, out, 2 * H,
+                                       reinterpret_cast<float*>(d_dbg), nullptr, ph | 1024, nullptr);
+        hipDeviceSynchronize();
+      }
+      hipMemcpy(st.data(), d_dbg, st.size() * 8, hipMemcpyDeviceToHost);
+      unsigned long long t0 = ~0ull;
+      for (int w = 0; w < waves; ++w) if (st[size_t(w) * 8]) t0 = std::min(t0, st[size_t(w) * 8]);
+      printf("time line, phases %d (us after the first wavefront's entry; min / mean / max over %d wavefronts):\n", ph, waves);
+      const char* names[8] = {"entry", "prologue done", "N operands loaded", "seen rows issued", "tiles + softmax done", "near rows issued", "stores drained", "phase S done"};
+      for (int k = 0; k < 8; ++k) {
+        double mn = 1e30, mx = 0, sum = 0; int cnt = 0;
+        for (int w = 0; w < waves; ++w) { const unsigned long long v = st[size_t(w) * 8 + k]; if (!v) continue; const double us = (v - t0) * 0.01; mn = std::min(mn, us); mx = std::max(mx, us); sum += us; ++cnt; }
+        if (cnt) printf("  %-22s %6.2f / %6.2f / %6.2f   (%d)\n", names[k], mn, sum / cnt, mx, cnt);
+      }
+    }
+  }
+#endif
   return 0;
 }

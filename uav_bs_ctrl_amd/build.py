@@ -29,7 +29,8 @@ def sources():
 
 
 def headers():
-    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    return (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc"))
+            + glob.glob(os.path.join(ROOT, "include", "*.h")))
 
 
 def _obj(src: str) -> str:

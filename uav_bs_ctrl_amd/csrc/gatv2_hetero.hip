@@ -3,44 +3,53 @@
 // F = 2; 4 heads x 64 channels; math SURVEY Appendix A.1/A.3) write the two halves of one [N, 2H] row (the th.cat of
 // gnn_agents.py:106 never exists), with one constant-load prologue and one pass over the destination meta data.
 //
-// Every persistent wavefront runs two phases:
+// Round 4 layout (rounds 1-3: csrc/gatv2_hetero_pair.inc, still the fp32-MFMA build behind `phases` bit 8).  One workgroup of
+// eight wavefronts per CU; every persistent wavefront runs two phases:
 //
-//  S  the `seen` relation of the destinations that HAVE in-edges, one destination at a time on 16-edge row tiles - the
-//     formulation of gatv2_mfma.hip (Z^T = W_s X^T + c[v] on the matrix cores, |z| half of the leaky ReLU as one
-//     |.|-modifier FMA per channel, permlane head reduction, log2-domain online softmax, input-space aggregation) with
-//     three changes: lane <-> FOUR CONSECUTIVE channels in the per-destination prologue / epilogue (one 16-byte LDS
-//     write, five 16-byte LDS reads and one 16-byte row store instead of 4 + 32 + 4 dword operations), the first row tile
-//     of the NEXT destination is requested while the last tile of the current one computes (no exposed HBM latency at
-//     a destination boundary), and destinations without in-edges are left to phase N.  With a hand-out order (sorted
-//     by decreasing degree) the phase ends at the first isolated destination - 94 % of the agents of a random-policy
-//     rollout never enter it.
+//  S  the `seen` relation of the destinations that HAVE in-edges, one destination at a time on 16-edge row tiles
+//     (Z^T = W_s X^T + c[v] on the matrix cores, |z| half of the leaky ReLU as one |.|-modifier FMA per channel, permlane
+//     head reduction, log2-domain online softmax, input-space aggregation, lane <-> four channels epilogue).  With a
+//     hand-out order (sorted by decreasing degree) the phase ends at the first isolated destination - 94 % of the agents
+//     of a random-policy rollout never enter it.
 //
-//  N  the `near` relation of ALL destinations, TWO destinations per row tile, plus the residual-only `seen` half of the
-//     isolated ones.  A `near` edge has two source features, so the K = 4 contraction of the MFMA holds
-//     [x_u ; x_v]: A = [W_s | W_d] rows, B = (x_u0, x_u1, x_v0, x_v1) per column, C = b_s + b_d - the destination term
-//     needs no per-destination C operand, so the 16 columns of a tile may belong to different destinations: columns
-//     0-7 carry the in-edges of destination 2p, columns 8-15 those of 2p+1 (degrees above 8 take further passes with
-//     the online softmax).  The segment softmax is an all-reduce over 8 lanes (two quad permutes + row_half_mirror),
-//     nothing crosses a 16-lane row, no LDS in the tile loop.  n - 1 = 7 neighbours -> 7/8 of the columns do work,
-//     where one destination per tile wastes 9/16 and the lane <-> channel kernel (gatv2_small.hip) spends ~350 VALU
-//     instructions per destination.
+//  N  the `near` relation of ALL destinations + the residual-only `seen` half of the isolated ones, on BLOCKS OF 16
+//     DESTINATIONS.  MFMA column j = destination j of the block; one score tile per EDGE SLOT u (the u-th in-edge of every
+//     destination; the destination term rides in the contraction: A = [W_s | W_d] rows, B = (x_u0, x_u1, x_v0, x_v1)), so
+//       * lane (j, k) ends up with the scores of ALL in-edges of destination j for head k in registers: the segment
+//         softmax and the input-space aggregation are lane-local (no cross-lane step, no padding: n - 1 = 7 neighbours
+//         are 7 tiles, not 8 columns of 16), for 16 destinations x 4 heads at once;
+//       * destination meta data is a plain vector load (lane j <-> destination j): no hand-over through v_readlane;
+//       * the per-destination epilogue - ReLU(W_s agg_k + has b_s + W_r x_v + b_r) for 256 channels, and ReLU(W_r x_v +
+//         b_r) of `seen` for isolated destinations - is ONE MORE MATRIX-CORE PRODUCT per 16 channels x 16 destinations:
+//         K groups = (agg_k0, agg_k1, x_v0, x_v1) as exact bf16 triples, biases in the free K slots against (has, 1);
+//         the lane <-> channel FMAs of rounds 1-3 (44 VALU per destination) become 2 MFMAs + 8 v_max per destination;
+//       * the D layout (lane = 4 channels of ONE destination) is turned into full rows through a per-wave LDS buffer:
+//         16 destinations x 512 B per pass, written with ds_write_b128, read back row-contiguously and stored as 512-B
+//         segments (two destinations per store instruction).
 //
-// Arithmetic: fp32 in / out / accumulate.  The score GEMM runs on the bf16 matrix cores as six exact bf16 products per fp32
-// product (K1_BF16Z, below): results equal the per-relation fp32-MFMA kernels' to fp32 rounding (1e-9 relative on the output
-// checksum), not bit for bit.
+// All bf16 A operands (score tiles of both phases, both epilogue products: 4 x 16 KB) are built ONCE PER WORKGROUP into
+// LDS by all 512 threads (rounds 1-3: every wavefront split its own, ~650 VALU per wave - a quarter of a rollout launch's
+// instructions); the per-wave prologue of a phase is 16 ds_read_b128 + 16 for the attention vector.
+//
+// Arithmetic: fp32 in / out / accumulate.  Score GEMM and epilogue product run on the bf16 matrix cores as six exact bf16
+// products per fp32 product (bf16x3.h: every product exact in the fp32 accumulator, the three dropped ones <= 2^-23 of
+// the product): results equal the fp32-MFMA build's to fp32 rounding, not bit for bit.
 // Instantiated for D = 64 (H = 256: every BASELINE configuration); other shapes use the per-relation kernels.
 #include "common.h"
 
 namespace uavgnn {
+
+int gatv2_hetero_launch_f32(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order, const float* x_ubs,
+                            const int32_t* near_off, const float* x_dst, int N, const float* const* seen_params,
+                            const float* const* near_params, float slope, float* out, int ld_out, float* attn_save_seen,
+                            float* attn_save_near, int phases, hipStream_t st);
+
 namespace {
 
-#ifndef K1_BF16Z
-#define K1_BF16Z 1    // 1: the score GEMM z = W x + c on v_mfma_f32_16x16x32_bf16 with exact three-way operand splits; 0: fp32 MFMA
-#endif
 #ifndef K1_ABLATE
-#define K1_ABLATE 0   // 1 (tools/ubench/k1_env_bench.hip only): `phases` bit 5 skips the score tile of phase N, bit 6 its row stores
+#define K1_ABLATE 0   // 1 (tools/ubench/k1_env_bench.hip only): `phases` bit 5 skips the score tiles of phase N, bit 6 its row stores, bit 7 its epilogue products
 #endif
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 8;
 constexpr int kThreads = kWave * kWavesPerBlock;
 constexpr int NH = 4;
 constexpr int D = 64;
@@ -48,6 +57,8 @@ constexpr int H = NH * D;          // 256
 constexpr int CT = H / 16;         // 16 channel tiles
 constexpr int TPH = D / 16;        // channel tiles per head
 constexpr int FS_S = 4, FS_N = 2;
+constexpr int UB = 8;              // edge slots per pass of phase N
+constexpr int kBounceLd = 132;     // floats per destination row of the per-wave row buffer (128 + 4: 8 consecutive lanes of a ds_write_b128 on distinct 16-B slots)
 constexpr float kLog2e = 1.4426950408889634f;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -56,10 +67,11 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
 }
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
 constexpr int kRowRor = 0x120;        // row_ror:n
-constexpr int kQuadXor1 = 0xB1;       // quad_perm:[1,0,3,2]
-constexpr int kQuadXor2 = 0x4E;       // quad_perm:[2,3,0,1]
-constexpr int kHalfMirror = 0x141;    // row_half_mirror: lane i <-> 7 - i inside every 8 lanes
 
 __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<kRowRor + 8>(v);
@@ -75,17 +87,11 @@ __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, dpp_mov<kRowRor + 1>(v));
   return v;
 }
-// all-reduce over the 8 lanes of a half row (the in-edge slots of ONE destination in phase N)
-__device__ __forceinline__ float half8_sum(float v) {
-  v += dpp_mov<kQuadXor1>(v);
-  v += dpp_mov<kQuadXor2>(v);
-  v += dpp_mov<kHalfMirror>(v);
-  return v;
-}
-__device__ __forceinline__ float half8_max(float v) {
-  v = fmaxf(v, dpp_mov<kQuadXor1>(v));
-  v = fmaxf(v, dpp_mov<kQuadXor2>(v));
-  v = fmaxf(v, dpp_mov<kHalfMirror>(v));
+__device__ __forceinline__ int row16_max_i(int v) {
+  v = max(v, dpp_mov_i<kRowRor + 8>(v));
+  v = max(v, dpp_mov_i<kRowRor + 4>(v));
+  v = max(v, dpp_mov_i<kRowRor + 2>(v));
+  v = max(v, dpp_mov_i<kRowRor + 1>(v));
   return v;
 }
 
@@ -99,6 +105,31 @@ __device__ __forceinline__ float reduce_heads(float pe0, float pe1, float pe2, f
   return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
 
+// 16-byte row-piece store under a wave-uniform 64-bit lane mask: EXEC is narrowed by scalar instructions around ONE
+// global_store (address = wave-uniform base in an SGPR pair + per-lane byte offset in one VGPR).  No branch (hipcc puts an
+// s_cbranch_execz around every `if (lane predicate) store`), no address VGPR pair per store (eight of them spill).
+//   * s_and_b64 writes SCC: declared, or the compiler keeps a compare result live across the statement (found the hard way);
+//   * no hazard recognizer runs inside inline asm: the s_nop covers "SALU writes SGPR -> VMEM reads it" (5 wait states);
+//   * the compiler does not know these are stores: every s_waitcnt vmcnt(n) it places later waits for them as well, so loads
+//     that are in flight are consumed BEFORE the stores of a block are issued (K1_TOUCH).
+// Measured alternatives: raw buffer stores with out-of-range offsets for the masked lanes (compiler-visible, exact counts,
+// fastest: 810 vs 870 us on the time-batched launch) returned WRONG DATA under store back-pressure on this hardware - the first
+// dword of the last four lanes of every 16-lane group of one store of a burst of eight arrived as the NEXT store's address
+// operand, in ~0.003 % of the rows, timing dependent (tools/k1_check.py finds it in seconds); plain predicated C++ stores
+// (per-lane predicate, address pairs) spill and run 10 % slower.
+__device__ __forceinline__ void store_piece(float* base, unsigned lane_off, f32x4 v, unsigned long long lanes) {
+  asm volatile(
+      "s_mov_b64 vcc, exec\n\t"
+      "s_and_b64 exec, exec, %3\n\t"
+      "s_nop 4\n\t"
+      "global_store_dwordx4 %0, %1, %2\n\t"
+      "s_mov_b64 exec, vcc"
+      :
+      : "v"(lane_off), "v"(v), "s"(base), "s"(lanes)
+      : "vcc", "scc");
+}
+#define K1_TOUCH(x) asm volatile("" ::"v"(x))
+
 __device__ __forceinline__ float rl(float v, int lane) {
   return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
 }
@@ -108,22 +139,11 @@ struct RelParams {   // one GATv2Conv: fc_src, fc_dst, attn, res_fc (DGL layout,
   const float* b_r;
 };
 
-// The MFMA + |z| FMA block shared by both phases: 16 channel tiles of one row tile -> log2-domain score of
-// (column j, head g) in every lane, up to a per-(destination, head) constant that cancels in the softmax.
-// The instruction order is PINNED (sched_barrier): MFMA ct+1 is issued, then the four |z| FMAs of tile ct run in its
-// shadow.  Left to itself hipcc hoists / sinks the FMAs around the MFMAs and the tile takes ~10 % longer
-// (tools/ubench/tile_sched.hip: 510 vs 455-463 ns per tile per SIMD at two waves per SIMD).
-#if K1_BF16Z
-// ---- the score GEMM on the bf16 matrix cores -------------------------------------------------------------------------
-// fp32 MFMA on gfx950 issues at the fp32 VECTOR rate and does not overlap the VALU work of the same SIMD (measured additive:
-// profiles/r03_k1_env_ablation.txt, tools/ubench/tile_sched.hip), so the 16 fp32 MFMAs of a row tile cost as much as its
-// ~105 VALU instructions.  The K = 4 contraction is therefore laid out over the K = 32 of ONE v_mfma_f32_16x16x32_bf16 per
-// channel tile: K group g (8 slots, = lane group g on both operands) holds the six bf16 x bf16 products of feature g -
-//     A = (w1 w1 | w2 w2 | w1 w3 | 0 0)      B = (x1 x2 | x1 x2 | x3 x1 | 0 0)      w = w1 + w2 + w3, x = x1 + x2 + x3 exactly
-// (bf16x3.h: every product exact in the fp32 accumulator, the three dropped ones <= 2^-23 |w x|: one fp32 rounding).  A lane
-// owns ONE feature of its edge (the value it already loads as the fp32 B operand), so the B operand is one three-way split per
-// tile (9 VALU); the A operands are split once per wavefront (64 VGPRs instead of 16).  The destination term stays the fp32 C
-// operand.  tools/ubench/tile_sched.hip: 354 ns per tile per SIMD against 454 for the fp32 MFMA tile (2 waves per SIMD).
+// ---- fp32 products on the bf16 matrix cores --------------------------------------------------------------------------
+// The K = 4 contraction of a tile is laid out over the K = 32 of ONE v_mfma_f32_16x16x32_bf16: K group g (8 slots, = lane
+// group g on both operands) holds the six bf16 x bf16 products of feature g -
+//     A = (w1 w1 | w2 w2 | w1 w3 | c c')      B = (x1 x2 | x1 x2 | x3 x1 | d d')      w = w1 + w2 + w3, x = x1 + x2 + x3 exactly
+// and the last word of a group carries bias terms against 1 (or against a 0 / 1 flag).
 typedef __bf16 k1_bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 k1_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float k1_f32x2 __attribute__((ext_vector_type(2)));
@@ -141,48 +161,41 @@ __device__ __forceinline__ K1Split k1_split(float x) {
   s.h3 = __builtin_bit_cast(unsigned, p);
   return s;
 }
-__device__ __forceinline__ k1_u32x4 k1_a_operand(float w) {   // (w1 w1 | w2 w2 | w1 w3 | 0 0)
-  const K1Split s = k1_split(w);
-  return k1_u32x4{s.h1, s.h2, (s.h1 & 0xffffu) | (s.h3 & 0xffff0000u), 0u};
+// A operand of one (row, K group): weight w, and in the last word the bias triple's first two terms (pair) or its third
+__device__ __forceinline__ k1_u32x4 k1_a_operand(float w, float bias, int bias_part) {   // bias_part: 0 none, 1 (b1 b2), 2 (b3 0)
+  const K1Split s = k1_split(w), b = k1_split(bias);
+  const unsigned last = bias_part == 1 ? ((b.h1 & 0xffffu) | (b.h2 & 0xffff0000u)) : bias_part == 2 ? (b.h3 & 0xffffu) : 0u;
+  return k1_u32x4{s.h1, s.h2, (s.h1 & 0xffffu) | (s.h3 & 0xffff0000u), last};
 }
-__device__ __forceinline__ k1_bf16x8 k1_b_operand(float x) {   // (x1 x2 | x1 x2 | x3 x1 | 0 0)
+__device__ __forceinline__ k1_bf16x8 k1_b_operand(float x, unsigned last_word) {   // (x1 x2 | x1 x2 | x3 x1 | last)
   const K1Split s = k1_split(x);
   const unsigned x12 = (s.h1 & 0xffffu) | (s.h2 & 0xffff0000u);
-  return __builtin_bit_cast(k1_bf16x8, k1_u32x4{x12, x12, (s.h3 & 0xffffu) | (s.h1 & 0xffff0000u), 0u});
+  return __builtin_bit_cast(k1_bf16x8, k1_u32x4{x12, x12, (s.h3 & 0xffffu) | (s.h1 & 0xffff0000u), last_word});
 }
-#define K1_WA_T k1_u32x4
-#define K1_WA_INIT(w) k1_a_operand(w)
+// acc += |z| a as ONE v_fma_f32 with the |.| source modifier.  Left alone, hipcc's SLP vectorizer pairs the accumulators into
+// v_pk_fma_f32 - which has no |.| modifier - and spends a v_and_b32 per element on the absolute value (82 instead of 64 VALU
+// instructions per row tile); the empty asm makes the accumulator opaque to it.  (The FMA itself must stay a compiler-visible
+// instruction: written as inline asm it escapes the hazard recognizer and reads matrix-core results too early - measured as
+// 3e-5 relative errors.)
+__device__ __forceinline__ void k1_fma_abs(float& acc, float z, float a) {
+  acc = fmaf(a, fabsf(z), acc);
+  asm("" : "+v"(acc));
+}
 #define K1_MFMA(WA_ct, XBOP, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k1_bf16x8, WA_ct), XBOP, C, 0, 0, 0)
-#define K1_XB_OP(xb) k1_b_operand(xb)
-// phase N: the channel bias b_s + b_d rides in the free K slots (A: b1 b2 | b3 0 in the last word of lane groups 0 / 1, B: 1 1
-// | 1 0 there), so the C operand is the inline constant 0 and no register holds it
-__device__ __forceinline__ k1_u32x4 k1_a_operand_bias(float w, float bias, int g) {
-  k1_u32x4 a = k1_a_operand(w);
-  const K1Split b = k1_split(bias);
-  a[3] = g == 0 ? ((b.h1 & 0xffffu) | (b.h2 & 0xffff0000u)) : g == 1 ? (b.h3 & 0xffffu) : 0u;
-  return a;
-}
-__device__ __forceinline__ k1_bf16x8 k1_b_operand_one(float x, unsigned one_word) {
-  const K1Split s = k1_split(x);
-  const unsigned x12 = (s.h1 & 0xffffu) | (s.h2 & 0xffff0000u);
-  return __builtin_bit_cast(k1_bf16x8, k1_u32x4{x12, x12, (s.h3 & 0xffffu) | (s.h1 & 0xffff0000u), one_word});
-}
-#else
-#define K1_WA_T float
-#define K1_WA_INIT(w) (w)
-#define K1_MFMA(WA_ct, XBOP, C) __builtin_amdgcn_mfma_f32_16x16x4f32(WA_ct, XBOP, C, 0, 0, 0)
-#define K1_XB_OP(xb) (xb)
-#endif
-#define UAVGNN_TILE_SCORE(WA, ATT, CINIT, WLIN, XB, E_OUT) UAVGNN_TILE_SCORE_(WA, ATT, CINIT, WLIN, XB, K1_XB_OP(XB), E_OUT)
-#define K1_INDEX(A) A
-#define UAVGNN_TILE_SCORE_(WA, ATT, CINIT, WLIN, XB, XBOP, E_OUT)                                       \
+
+// The MFMA + |z| FMA block shared by both phases: 16 channel tiles of one row tile -> log2-domain score of
+// (column j, head g) in every lane, up to a per-(destination, head) constant that cancels in the softmax.
+// The instruction order is PINNED (sched_barrier): MFMA ct+1 is issued, then the four |z| FMAs of tile ct run in its
+// shadow.  Left to itself hipcc hoists / sinks the FMAs around the MFMAs and the tile takes ~10 % longer
+// (tools/ubench/tile_sched.hip).
+#define UAVGNN_TILE_SCORE(WA, ATT, CINIT, WLIN, XB, XBOP, E_OUT)                                        \
   {                                                                                                     \
     float pe[NH][2];                                                                                    \
     _Pragma("unroll") for (int k = 0; k < NH; ++k) {                                                    \
       pe[k][0] = WLIN[k] * (XB);                                                                        \
       pe[k][1] = 0.f;                                                                                   \
     }                                                                                                   \
-    const auto xb_op = XBOP;                                                                            \
+    const k1_bf16x8 xb_op = XBOP;                                                                       \
     f32x4 z_cur = K1_MFMA(WA[0], xb_op, CINIT(0));                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                 \
@@ -192,95 +205,363 @@ __device__ __forceinline__ k1_bf16x8 k1_b_operand_one(float x, unsigned one_word
         __builtin_amdgcn_sched_barrier(0);                                                              \
       }                                                                                                 \
       const int k = ct / TPH;                                                                           \
-      pe[k][0] = fmaf(ATT[ct][0], fabsf(z_cur[0]), pe[k][0]);                                           \
-      pe[k][1] = fmaf(ATT[ct][1], fabsf(z_cur[1]), pe[k][1]);                                           \
-      pe[k][0] = fmaf(ATT[ct][2], fabsf(z_cur[2]), pe[k][0]);                                           \
-      pe[k][1] = fmaf(ATT[ct][3], fabsf(z_cur[3]), pe[k][1]);                                           \
+      k1_fma_abs(pe[k][0], z_cur[0], ATT[ct][0]);                                                       \
+      k1_fma_abs(pe[k][1], z_cur[1], ATT[ct][1]);                                                       \
+      k1_fma_abs(pe[k][0], z_cur[2], ATT[ct][2]);                                                       \
+      k1_fma_abs(pe[k][1], z_cur[3], ATT[ct][3]);                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                                \
       z_cur = z_nxt;                                                                                    \
     }                                                                                                   \
     E_OUT = reduce_heads(pe[0][0] + pe[0][1], pe[1][0] + pe[1][1], pe[2][0] + pe[2][1], pe[3][0] + pe[3][1]); \
   }
 
+enum { kSetSeen = 0, kSetNear = 1, kSetEpiNear = 2, kSetEpiSeen = 3 };
+
+// SAVE: the attention weights of both relations are written for the backward pass (training forwards); the inference
+// instantiation does not carry them through the block.
+template <bool SAVE>
 __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     const float* __restrict__ x_gt, const int32_t* __restrict__ seen_off, const int32_t* __restrict__ seen_order,
     const float* __restrict__ x_ubs, const int32_t* __restrict__ near_off, const float* __restrict__ x_dst, int N,
     int E_seen, RelParams ps, RelParams pn, float slope, float* __restrict__ out, int ld_out, float* __restrict__ a_save_s,
-    float* __restrict__ a_save_n, int phases) {
+    float* __restrict__ a_save_n_arg, int phases) {
+  float* const a_save_n = SAVE ? a_save_n_arg : nullptr;
+  // prepared bf16 A operands, [set][channel tile][lane]: 64 KB
+  __shared__ __attribute__((aligned(16))) k1_u32x4 sA[4][CT * kWave];
+  // operands of phase S's lane <-> channel prologue / epilogue (read once per destination)
   __shared__ __attribute__((aligned(16))) float sWs[H * FS_S];     // fc_src.weight of `seen`, row-major [H, 4]
-  __shared__ __attribute__((aligned(16))) float sWn[H * FS_N];     // fc_src.weight of `near`, row-major [H, 2]
-  __shared__ __attribute__((aligned(16))) float sAs[H], sAn[H];     // attention vectors
-  __shared__ __attribute__((aligned(16))) float sWdn[H * 2];        // fc_dst.weight of `near` (A operand rows of phase N)
-  __shared__ __attribute__((aligned(16))) float sBCn[H];            // b_s + b_d of `near` (the constant C operand)
-  // the remaining small operands, staged once per workgroup instead of fetched by every wavefront:
-  __shared__ __attribute__((aligned(16))) float sWds[H * 2], sWrs[H * 2], sWrn[H * 2];   // seen fc_dst / res_fc, near res_fc
-  __shared__ __attribute__((aligned(16))) float sBss[H], sBds[H], sBrs[H], sBsn[H], sBrn[H];   // biases (b_r: 0 when absent)
-  __shared__ float sWa[2][NH * 4];                                  // wa[k][f] = sum_d attn[k,d] W_s[k,d,f] per relation
-  __shared__ __attribute__((aligned(16))) float sC[kWavesPerBlock][H];
+  __shared__ __attribute__((aligned(16))) float sWds[H * 2], sWrs[H * 2];   // seen fc_dst / res_fc
+  __shared__ __attribute__((aligned(16))) float sBss[H], sBds[H], sBrs[H];   // seen biases (b_r: 0 when absent)
+  __shared__ __attribute__((aligned(16))) float sAs[H], sAn[H];     // attention vectors x log2(e) (1 - slope) / 2
+  __shared__ float sWa[2][NH * 4];                                  // log2(e) (1 + slope) / 2 x sum_d attn[k,d] W_s[k,d,f] per relation
+  __shared__ __attribute__((aligned(16))) float sC[kWavesPerBlock][H];   // phase S: destination term; phase N: aggregate hand-over
+  __shared__ __attribute__((aligned(16))) float sRow[kWavesPerBlock][16 * kBounceLd];   // phase N: output rows of one pass
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 15;          // MFMA column (edge slot) / A row
-  const int g = lane >> 4;          // lane group: K index of the A / B operands, head after the reduction
-
-  for (int i = tid; i < H * FS_S / 4; i += kThreads)
-    reinterpret_cast<float4*>(sWs)[i] = reinterpret_cast<const float4*>(ps.W_s)[i];
-  for (int i = tid; i < H * FS_N / 4; i += kThreads) {
-    reinterpret_cast<float4*>(sWn)[i] = reinterpret_cast<const float4*>(pn.W_s)[i];
-    reinterpret_cast<float4*>(sWdn)[i] = reinterpret_cast<const float4*>(pn.W_d)[i];
-    reinterpret_cast<float4*>(sWds)[i] = reinterpret_cast<const float4*>(ps.W_d)[i];
-    reinterpret_cast<float4*>(sWrs)[i] = reinterpret_cast<const float4*>(ps.W_r)[i];
-    reinterpret_cast<float4*>(sWrn)[i] = reinterpret_cast<const float4*>(pn.W_r)[i];
-  }
-  for (int i = tid; i < H; i += kThreads) {
-    sAs[i] = ps.attn[i];
-    sAn[i] = pn.attn[i];
-    sBCn[i] = pn.b_s[i] + pn.b_d[i];
-    sBss[i] = ps.b_s[i];
-    sBds[i] = ps.b_d[i];
-    sBsn[i] = pn.b_s[i];
-    sBrs[i] = ps.b_r != nullptr ? ps.b_r[i] : 0.f;
-    sBrn[i] = pn.b_r != nullptr ? pn.b_r[i] : 0.f;
-  }
-  __syncthreads();
-  {  // wa[rel][k][f]: 2 x 16 outputs, 16 partial sums each; 256 threads = 16 rows of 16 lanes, two rounds
-    const int kf = tid >> 4, part = tid & 15;
-    const int k = kf >> 2, f = kf & 3;
-    float a0 = 0.f, a1 = 0.f;
-    for (int d = part; d < D; d += 16) {
-      a0 = fmaf(sAs[k * D + d], sWs[(k * D + d) * FS_S + f], a0);
-      if (f < FS_N) a1 = fmaf(sAn[k * D + d], sWn[(k * D + d) * FS_N + f], a1);
-    }
-    a0 = row16_sum(a0);
-    a1 = row16_sum(a1);
-    if (part == 0) {
-      sWa[0][kf] = a0;
-      sWa[1][kf] = a1;
-    }
-  }
-  __syncthreads();
+  const int j = lane & 15;          // MFMA column (edge slot / destination of the block) / A row
+  const int g = lane >> 4;          // lane group: K group of the A / B operands, head after the reduction
 
   const float c_abs = kLog2e * 0.5f * (1.f - slope), c_lin = kLog2e * 0.5f * (1.f + slope);
-  float* __restrict__ cw = sC[wave];
   const int stride = gridDim.x * kWavesPerBlock;
   const int it0 = blockIdx.x * kWavesPerBlock + wave;
+  const int nblk = (N + 15) >> 4;   // blocks of 16 destinations (phase N)
+#if K1_ABLATE   // `phases` bit 10: per-wavefront time stamps (100 MHz s_memrealtime) into the buffer passed as attn_save_seen
+  unsigned long long* const dbg = (phases & 1024) ? reinterpret_cast<unsigned long long*>(a_save_s) : nullptr;
+  if (phases & 1024) a_save_s = nullptr;
+#define K1_STAMP(i) if (dbg != nullptr && lane == 0) dbg[static_cast<size_t>(it0) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define K1_STAMP(i)
+#endif
+  K1_STAMP(0)
+
+  // Inputs of this wavefront's FIRST block of phase N are requested before the workgroup prologue (their two dependent
+  // round trips overlap the staging below): destination meta data - lane j <-> destination j, a plain vector load -, then
+  // the first-pass edge features.  Clamped, never predicated (see phase S).
+  struct Meta { int n0, n1, s0, s1; float2 xv; };
+  auto load_meta = [&](const int blk) {
+    const int vc = min(blk * 16 + j, N - 1);
+    Meta m;
+    m.n0 = near_off[vc];
+    m.n1 = near_off[vc + 1];
+    m.s0 = seen_off[vc];
+    m.s1 = seen_off[vc + 1];
+    m.xv = *reinterpret_cast<const float2*>(x_dst + 2 * vc);
+    return m;
+  };
+  float2 xq[UB];   // first-pass inputs of the next block: slot u of destination j (masked slots read edge row 0)
+  auto load_edges = [&](const Meta& m, const int blk, const int base) {
+    const int dg = (blk * 16 + j < N) ? m.n1 - m.n0 : 0;
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      xq[u] = *reinterpret_cast<const float2*>(x_ubs + static_cast<size_t>(base + u < dg ? m.n0 + base + u : 0) * FS_N);
+  };
+  Meta mnext = load_meta(min(it0, nblk - 1));
+
+  // ---- workgroup prologue: constants and prepared A operands into LDS ------------------------------------------------
+  // Branch-free, every global load issued before anything waits (ONE round trip; a version with `if (tid < ...)` blocks and
+  // null-pointer branches around the loads cost ten dependent round trips = 4 us of a 20-us launch).
+  const float* const brs_p = ps.b_r != nullptr ? ps.b_r : ps.b_s;   // res_fc.bias may be absent: any valid address, scaled by 0
+  const float* const brn_p = pn.b_r != nullptr ? pn.b_r : pn.b_s;
+  const float brs_on = ps.b_r != nullptr ? 1.f : 0.f, brn_on = pn.b_r != nullptr ? 1.f : 0.f;
+  const int t256 = tid & 255, t128 = tid & 127;
+  const float4 l_ws = reinterpret_cast<const float4*>(ps.W_s)[t256];
+  const float4 l_wd = reinterpret_cast<const float4*>(ps.W_d)[t128], l_wr = reinterpret_cast<const float4*>(ps.W_r)[t128];
+  const float l_as = ps.attn[t256], l_an = pn.attn[t256], l_bs = ps.b_s[t256], l_bd = ps.b_d[t256], l_br = brs_p[t256];
+  // wa[rel][k][f]: 2 x 16 outputs, 16 partial sums of 4 terms each; 512 threads = 32 rows of 16 lanes
+  const int wa_kf = tid >> 4, wa_part = tid & 15;
+  const int wa_rel = wa_kf >> 4, wa_k = (wa_kf >> 2) & 3, wa_f = wa_kf & 3;
+  float l_wa_a[4], l_wa_w[4];
+  {
+    const float* at = wa_rel ? pn.attn : ps.attn;
+    const float* ws = wa_rel ? pn.W_s : ps.W_s;
+    const int F = wa_rel ? FS_N : FS_S, f = min(wa_f, F - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = wa_k * D + wa_part + 16 * i;
+      l_wa_a[i] = at[d];
+      l_wa_w[i] = ws[d * F + f];
+    }
+  }
+  float l_w[8], l_b[8];   // 4 sets x 1024 entries over 512 threads: weight and bias of entry q * 512 + tid
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int idx = (q & 1) * kThreads + tid;
+    const int row = (idx >> 6) * 16 + (idx & 15), gg = (idx >> 4) & 3;
+    if ((q >> 1) == kSetSeen) {
+      l_w[q] = ps.W_s[row * FS_S + gg];
+      l_b[q] = 0.f;
+    } else if ((q >> 1) == kSetNear) {   // A = [W_s | W_d], the channel bias b_s + b_d in the free slots of K groups 0 / 1
+      l_w[q] = *(gg < 2 ? pn.W_s + row * FS_N + gg : pn.W_d + row * 2 + gg - 2);
+      l_b[q] = pn.b_s[row] + pn.b_d[row];
+    } else if ((q >> 1) == kSetEpiNear) {   // A = [W_s | W_r]; b_s against `has` in K groups 0 / 1, b_r against 1 in groups 2 / 3
+      l_w[q] = *(gg < 2 ? pn.W_s + row * FS_N + gg : pn.W_r + row * 2 + gg - 2);
+      l_b[q] = *(gg < 2 ? pn.b_s + row : brn_p + row) * (gg < 2 ? 1.f : brn_on);
+    } else {   // residual-only `seen` row: A = [0 | W_r], b_r against 1 in groups 2 / 3
+      l_w[q] = ps.W_r[row * 2 + (gg & 1)] * (gg < 2 ? 0.f : 1.f);
+      l_b[q] = brs_p[row] * (gg < 2 ? 0.f : brs_on);
+    }
+  }
+  load_edges(mnext, min(it0, nblk - 1), 0);   // needs the meta data requested first: the one dependent round trip
+  // unconditional stores (two / four threads write the same value to the same word): no branch, no pessimistic wait
+  reinterpret_cast<float4*>(sWs)[t256] = l_ws;
+  reinterpret_cast<float4*>(sWds)[t128] = l_wd;
+  reinterpret_cast<float4*>(sWrs)[t128] = l_wr;
+  sAs[t256] = c_abs * l_as;
+  sAn[t256] = c_abs * l_an;
+  sBss[t256] = l_bs;
+  sBds[t256] = l_bd;
+  sBrs[t256] = l_br * brs_on;
+  {
+    float a0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a0 = fmaf(l_wa_a[i], l_wa_w[i], a0);
+    a0 = row16_sum(a0);
+    if (wa_part == 0) sWa[wa_rel][wa_kf & 15] = (wa_f < (wa_rel ? FS_N : FS_S)) ? c_lin * a0 : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int idx = (q & 1) * kThreads + tid;
+    const int gg = (idx >> 4) & 3;
+    const int set = q >> 1;
+    const int part = set == kSetSeen ? 0 : set == kSetNear ? (gg == 0 ? 1 : gg == 1 ? 2 : 0)
+                   : set == kSetEpiNear ? ((gg & 1) ? 2 : 1) : (gg < 2 ? 0 : (gg & 1) ? 2 : 1);
+    sA[set][idx] = k1_a_operand(l_w[q], l_b[q], part);
+  }
+  __syncthreads();
+  K1_STAMP(1)
+
+  float* __restrict__ cw = sC[wave];
+  const f32x4 czero = {0.f, 0.f, 0.f, 0.f};
+
+  // ====== phase N: `near` + residual-only `seen` rows on blocks of 16 destinations (column j <-> destination) ========
+  // Runs BEFORE phase S: it writes 2 KB per destination, and its row stores drain while phase S computes.
+  if ((phases & 2) && it0 < nblk) {
+    const unsigned one_tile = g == 0 ? 0x3F803F80u : g == 1 ? 0x00003F80u : 0u;   // bf16 1.0 against the bias slots of the A operand
+    float* __restrict__ rw = sRow[wave];
+    const int half = lane >> 5, c16 = lane & 31;   // row stores: destination 2i + half of the block, 16-byte chunk c16 of the pass
+    const unsigned row_off = static_cast<unsigned>(half * ld_out + 4 * c16) * 4u;   // byte offset of the lane's piece from the row pair's base
+#if K1_ABLATE
+    if ((phases & 512) && wave < 4) __builtin_amdgcn_s_setprio(2);
+#endif
+
+    K1_STAMP(2)
+    // The two wavefronts that share a SIMD (waves w and w + 4 of the workgroup) run the store-bound part (residual-only `seen`
+    // rows: LDS + memory pipeline) and the issue-bound part (score tiles: VALU + matrix cores) of a block in OPPOSITE order,
+    // so that one of them always has instructions to issue (in lock step - both storing, then both computing - the phase took
+    // 11.8 us of a rollout launch for 5.5 us of issue time).
+    const bool tiles_first = (wave & 4) != 0;
+    for (int blk = it0; blk < nblk; blk += stride) {
+      const Meta mt = mnext;
+      const int v0 = blk << 4;
+      const bool valid_v = v0 + j < N;
+      const int deg = valid_v ? mt.n1 - mt.n0 : 0;
+      const bool iso = valid_v && mt.s1 == mt.s0;
+      float2 (&xu)[UB] = xq;
+      const int nb = min(blk + stride, nblk - 1);
+      mnext = load_meta(nb);   // meta data of the next block: in flight while this one computes
+      const int maxdeg = __builtin_amdgcn_readfirstlane(row16_max_i(deg));
+      const float xvg = (g & 1) ? mt.xv.y : mt.xv.x;   // only read by lane groups 2, 3
+      const unsigned vmask = static_cast<unsigned>(__builtin_amdgcn_ballot_w64(valid_v)) & 0xffffu;
+      const unsigned imask = static_cast<unsigned>(__builtin_amdgcn_ballot_w64(iso)) & 0xffffu;
+#if K1_ABLATE   // `phases` bit 11: every block stores to the first rows (no HBM drain: what the store INSTRUCTIONS cost)
+      float* const row0 = out + static_cast<size_t>((phases & 2048) ? (blockIdx.x & 7) * 16 : v0) * ld_out;
+#else
+      float* const row0 = out + static_cast<size_t>(v0) * ld_out;   // wave-uniform
+#endif
+
+      // ---- epilogue products + row stores: 8 channel tiles (512 B per destination) per pass ------------------------
+      // D[channel][destination]: lane (j, g) holds channels 16 ct + 4 g .. + 3 of destination j = one 16-byte piece of its
+      // row; the pieces go through the per-wave LDS buffer and leave as 512-byte row segments, two destinations per
+      // store instruction (lane half <-> destination: the predicate of a store is a 64-bit EXEC mask built by scalar
+      // instructions from the 16-bit destination mask; no branch, so the number of stores in flight is static and the
+      // prefetches behind them are waited for with counted s_waitcnt).  Storing from the transposed product D[destination]
+      // [channel] without LDS - 64-byte pieces per 16 lanes - was measured: four times the store instructions, 12 cycles
+      // each in the memory pipeline, slower.
+      auto emit = [&](const int set, const int col0, const unsigned mask, const k1_bf16x8* bop, const bool per_head) {
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const int ct = hp * 8 + c;
+            const k1_u32x4 a = sA[set][ct * kWave + lane];
+            f32x4 d = K1_MFMA(a, bop[per_head ? ct / TPH : 0], czero);
+#if K1_ABLATE
+            if (phases & 128) d = czero;
+#endif
+            d[0] = fmaxf(d[0], 0.f);
+            d[1] = fmaxf(d[1], 0.f);
+            d[2] = fmaxf(d[2], 0.f);
+            d[3] = fmaxf(d[3], 0.f);
+            *reinterpret_cast<f32x4*>(rw + j * kBounceLd + c * 16 + 4 * g) = d;
+          }
+          wave_sync_lds();
+#if K1_ABLATE
+          if (!(phases & 64))
+#endif
+          {
+            f32x4 vals[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vals[i] = *reinterpret_cast<const f32x4*>(rw + (2 * i + half) * kBounceLd + 4 * c16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const unsigned long long m64 = (((mask >> (2 * i)) & 1u) ? 0x00000000ffffffffull : 0ull) |
+                                             (((mask >> (2 * i + 1)) & 1u) ? 0xffffffff00000000ull : 0ull);
+              store_piece(row0 + static_cast<size_t>(2 * i) * ld_out + col0 + hp * 128, row_off, vals[i], m64);
+            }
+          }
+          wave_sync_lds();   // the row buffer is rewritten by the next pass
+        }
+      };
+
+#pragma unroll
+      for (int u = 0; u < UB; ++u) K1_TOUCH(xu[u].x);   // in flight since the previous block (or the prologue): landed before the first store
+      float m = -INFINITY, den = 0.f, s0 = 0.f, s1 = 0.f;
+      float pw[UB];
+      for (int step = 0; step < 2; ++step) {
+        if ((step == 0) != tiles_first) {
+          // the residual-only `seen` rows of the isolated destinations need x_v only
+          if (imask != 0u) {
+            const k1_bf16x8 bx = k1_b_operand(g < 2 ? 0.f : xvg, (g & 1) ? 0x00003F80u : 0x3F803F80u);
+            emit(kSetEpiSeen, 0, imask, &bx, false);
+          }
+          if (blk == it0) { K1_STAMP(3) }
+          continue;
+        }
+        // A operands and attention vector of the score tiles: (re)read from LDS per block - 32 ds_read_b128 - instead of held
+        // across the row-store parts of the block, whose LDS round trips want the registers (the opaque lane index keeps the
+        // compiler from hoisting the reads out of the block loop)
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));
+        k1_u32x4 Wa[CT];
+        float att[CT][4], wlin[NH];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          Wa[ct] = sA[kSetNear][ct * kWave + lane_v];
+          const float4 a4 = *reinterpret_cast<const float4*>(sAn + ct * 16 + 4 * (lane_v >> 4));
+          att[ct][0] = a4.x; att[ct][1] = a4.y; att[ct][2] = a4.z; att[ct][3] = a4.w;
+        }
+#pragma unroll
+        for (int k = 0; k < NH; ++k) wlin[k] = (g < 2) ? sWa[1][k * 4 + (lane_v >> 4)] : 0.f;
+        for (int base = 0; base < maxdeg; base += UB) {
+          if (base > 0) {   // degrees above 8: further passes through the online softmax
+            load_edges(mt, blk, base);
+          }
+          float e[UB];
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            e[u] = 0.f;
+            if (base + u < maxdeg) {   // wave-uniform
+              const float xB = (g == 0) ? xu[u].x : (g == 1) ? xu[u].y : xvg;
+#if K1_ABLATE
+              if (phases & 32) e[u] = xB; else
+#endif
+#define K1_CINIT_N(ct) czero
+              UAVGNN_TILE_SCORE(Wa, att, K1_CINIT_N, wlin, xB, k1_b_operand(xB, one_tile), e[u])
+            }
+          }
+          // ---- lane-local segment softmax over the slots of this pass (lane (j, k): destination j, head k) -----------
+          float mx = -INFINITY;
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            e[u] = (base + u < deg) ? e[u] : -INFINITY;
+            mx = fmaxf(mx, e[u]);
+          }
+          const float mn = fmaxf(m, mx);
+          const float mref = (mn == -INFINITY) ? 0.f : mn;      // destination without in-edges so far: every weight is exp2(-inf) = 0
+          const float sc = __builtin_amdgcn_exp2f(m - mref);     // exp2(-inf) = 0 on the first pass
+          den *= sc;
+          s0 *= sc;
+          s1 *= sc;
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            pw[u] = __builtin_amdgcn_exp2f(e[u] - mref);
+            den += pw[u];
+            s0 = fmaf(pw[u], xu[u].x, s0);
+            s1 = fmaf(pw[u], xu[u].y, s1);
+          }
+          m = mn;
+          if (a_save_n != nullptr && maxdeg > UB) {   // raw scores now, weights once the maximum and the sum are final
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+              if (base + u < deg) a_save_n[static_cast<size_t>(mt.n0 + base + u) * NH + g] = e[u];
+          }
+        }
+        if (blk == it0) { K1_STAMP(4) }
+      }
+      const float inv = den > 0.f ? __builtin_amdgcn_rcpf(den) : 0.f;      // isolated destination: aggregate = 0
+      if (a_save_n != nullptr) {
+        if (maxdeg <= UB) {
+#pragma unroll
+          for (int u = 0; u < UB; ++u)
+            if (u < deg) a_save_n[static_cast<size_t>(mt.n0 + u) * NH + g] = pw[u] * inv;
+        } else {
+          for (int u = 0; u < deg; ++u) {
+            float* ap = a_save_n + static_cast<size_t>(mt.n0 + u) * NH + g;
+            *ap = __builtin_amdgcn_exp2f(*ap - m) * inv;
+          }
+        }
+      }
+      // ---- hand the aggregates of head k over to the lanes that feed K group g of the epilogue product ---------------
+      cw[j * 8 + g] = s0 * inv;
+      cw[j * 8 + 4 + g] = s1 * inv;
+      wave_sync_lds();
+      const f32x4 ag = *reinterpret_cast<const f32x4*>(cw + j * 8 + (g & 1) * 4);   // feature g of heads 0..3 (groups 0, 1)
+      const unsigned has_w = deg > 0 ? 0xffffffffu : 0u;
+      const unsigned one_epi = (g & 1 ? 0x00003F80u : 0x3F803F80u) & (g < 2 ? has_w : 0xffffffffu);
+      k1_bf16x8 bop[NH];
+#pragma unroll
+      for (int k = 0; k < NH; ++k) bop[k] = k1_b_operand(g < 2 ? ag[k] : xvg, one_epi);
+      wave_sync_lds();   // cw is rewritten by the next block
+      emit(kSetEpiNear, H, vmask, bop, true);
+      if (blk == it0) { K1_STAMP(5) }
+      load_edges(mnext, nb, 0);   // first-pass inputs of the next block
+    }
+#if K1_ABLATE
+    if (dbg != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    K1_STAMP(6)
+#endif
+#if K1_ABLATE
+    if (phases & 512) __builtin_amdgcn_s_setprio(0);
+#endif
+  }
 
   // =========================== phase S: `seen` on the destinations that have in-edges ===============================
   if (it0 < N && (phases & 1) && E_seen > 0) {
-    K1_WA_T Wa[CT];
+    k1_u32x4 Wa[CT];
     float att[CT][4], wlin[NH];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      Wa[ct] = K1_WA_INIT(sWs[(ct * 16 + j) * FS_S + g]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) att[ct][r] = c_abs * sAs[ct * 16 + 4 * g + r];
+      Wa[ct] = sA[kSetSeen][ct * kWave + lane];
+      const float4 a4 = *reinterpret_cast<const float4*>(sAs + ct * 16 + 4 * g);
+      att[ct][0] = a4.x; att[ct][1] = a4.y; att[ct][2] = a4.z; att[ct][3] = a4.w;
     }
 #pragma unroll
-    for (int k = 0; k < NH; ++k) wlin[k] = c_lin * sWa[0][k * 4 + g];
+    for (int k = 0; k < NH; ++k) wlin[k] = sWa[0][k * 4 + g];
     // The per-destination constants of the prologue / epilogue (lane <-> channels 4*lane .. 4*lane+3: fc_dst, res_fc rows,
-    // biases) are READ FROM LDS where they are used, once per destination: the bf16 A operands take 64 VGPRs (K1_BF16Z) and
-    // 28 more registers held across the tile loop would spill.
+    // biases) are READ FROM LDS where they are used, once per destination: the bf16 A operands take 64 VGPRs and 28 more
+    // registers held across the tile loop would spill.
     // inputs of the row tile that is processed next (possibly the first tile of the next destination)
     float4 xr;
     float xBn;
@@ -321,7 +602,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
         }
         float e;
 #define K1_CINIT_S(ct) cinit[ct]
-        UAVGNN_TILE_SCORE(Wa, att, K1_CINIT_S, wlin, xB, e)
+        UAVGNN_TILE_SCORE(Wa, att, K1_CINIT_S, wlin, xB, k1_b_operand(xB, 0u), e)
         if (valid) {
           if (a_save_s != nullptr) a_save_s[static_cast<size_t>(ce0 + base + j) * NH + g] = e;
           const float mn = fmaxf(m, e);
@@ -376,8 +657,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
 
     // Destination meta data 64 hand-out positions at a time by VECTOR loads (lane <-> position) + v_readlane.  Scalar
     // loads would share the lgkm counter with the LDS traffic of process(): its first s_waitcnt lgkmcnt(0) would wait for
-    // the look-ahead s_loads of the NEXT destination (an L2 round trip per destination - what the per-relation kernel
-    // pays: ~1.5k cycles per destination).
+    // the look-ahead s_loads of the NEXT destination (an L2 round trip per destination).
     bool done = false;
     for (int kb = 0; !done && it0 + kb * stride < N; kb += kWave) {
       const int my_it = it0 + (kb + lane) * stride;
@@ -409,198 +689,6 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
       }
     }
   }
-
-  // ================= phase N: `near`, two destinations per row tile, + residual-only `seen` rows ====================
-  if (phases & 2) {
-    K1_WA_T Wa[CT];
-    float att[CT][4], wlin[NH];
-#if K1_BF16Z
-    const unsigned one_word = g == 0 ? 0x3F803F80u : g == 1 ? 0x00003F80u : 0u;   // bf16 1.0 against the bias slots of the A operand
-    const f32x4 czero = {0.f, 0.f, 0.f, 0.f};
-#define K1_CINIT_N(ct) czero
-#define K1_XBOP_N(xb) k1_b_operand_one(xb, one_word)
-#else
-    f32x4 cconst[CT];
-#define K1_CINIT_N(ct) cconst[ct]
-#define K1_XBOP_N(xb) (xb)
-#endif
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const int row = ct * 16 + j;
-      const float wv = (g < 2) ? sWn[row * FS_N + g] : sWdn[row * 2 + (g - 2)];
-#if K1_BF16Z
-      Wa[ct] = k1_a_operand_bias(wv, sBCn[row], g);
-#else
-      Wa[ct] = wv;
-#endif
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ch = ct * 16 + 4 * g + r;
-        att[ct][r] = c_abs * sAn[ch];
-#if !K1_BF16Z
-        cconst[ct][r] = sBCn[ch];
-#endif
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NH; ++k) wlin[k] = (g < 2) ? c_lin * sWa[1][k * 4 + g] : 0.f;
-    // epilogue constants, lane <-> channels 4*lane .. 4*lane+3
-#define K1_EPI_CONSTS                                                                                                              \
-      float ws[4][2], bsn[4], wrn[4][2], brn[4], wrs[4][2], brs[4];                                                                \
-      {                                                                                                                            \
-        const float4 bs4 = reinterpret_cast<const float4*>(sBsn)[lane];                                                            \
-        const float4 ws_lo = reinterpret_cast<const float4*>(sWn)[2 * lane], ws_hi = reinterpret_cast<const float4*>(sWn)[2 * lane + 1];   \
-        const float4 wn_lo = reinterpret_cast<const float4*>(sWrn)[2 * lane], wn_hi = reinterpret_cast<const float4*>(sWrn)[2 * lane + 1]; \
-        const float4 wq_lo = reinterpret_cast<const float4*>(sWrs)[2 * lane], wq_hi = reinterpret_cast<const float4*>(sWrs)[2 * lane + 1]; \
-        const float4 bn4 = reinterpret_cast<const float4*>(sBrn)[lane], bq4 = reinterpret_cast<const float4*>(sBrs)[lane];          \
-        bsn[0] = bs4.x; bsn[1] = bs4.y; bsn[2] = bs4.z; bsn[3] = bs4.w;                                                            \
-        ws[0][0] = ws_lo.x; ws[0][1] = ws_lo.y; ws[1][0] = ws_lo.z; ws[1][1] = ws_lo.w;                                            \
-        ws[2][0] = ws_hi.x; ws[2][1] = ws_hi.y; ws[3][0] = ws_hi.z; ws[3][1] = ws_hi.w;                                            \
-        wrn[0][0] = wn_lo.x; wrn[0][1] = wn_lo.y; wrn[1][0] = wn_lo.z; wrn[1][1] = wn_lo.w;                                        \
-        wrn[2][0] = wn_hi.x; wrn[2][1] = wn_hi.y; wrn[3][0] = wn_hi.z; wrn[3][1] = wn_hi.w;                                        \
-        wrs[0][0] = wq_lo.x; wrs[0][1] = wq_lo.y; wrs[1][0] = wq_lo.z; wrs[1][1] = wq_lo.w;                                        \
-        wrs[2][0] = wq_hi.x; wrs[2][1] = wq_hi.y; wrs[3][0] = wq_hi.z; wrs[3][1] = wq_hi.w;                                        \
-        brn[0] = bn4.x; brn[1] = bn4.y; brn[2] = bn4.z; brn[3] = bn4.w;                                                            \
-        brs[0] = bq4.x; brs[1] = bq4.y; brs[2] = bq4.z; brs[3] = bq4.w;                                                            \
-      }
-    K1_EPI_CONSTS
-    const int half = j >> 3, slot = j & 7;
-    const int P = (N + 1) >> 1;     // destination pairs (2p, 2p+1)
-
-    // pair meta data 64 at a time by vector loads (lane <-> pair), handed over by v_readlane: no scalar-load chain
-    for (int kb = 0; it0 + kb * stride < P; kb += kWave) {
-      const int my_p = it0 + (kb + lane) * stride;
-      const bool mine = my_p < P;
-      const int vA = 2 * my_p;
-      const bool hasB = mine && (vA + 1 < N);
-      const int m_n0 = mine ? near_off[vA] : 0;
-      const int m_n1 = mine ? near_off[vA + 1] : 0;
-      const int m_n2 = hasB ? near_off[vA + 2] : m_n1;
-      const int m_s0 = mine ? seen_off[vA] : 0;
-      const int m_s1 = mine ? seen_off[vA + 1] : 0;
-      const int m_s2 = hasB ? seen_off[vA + 2] : m_s1;
-      const float2 m_xa = mine ? *reinterpret_cast<const float2*>(x_dst + 2 * vA) : make_float2(0.f, 0.f);
-      const float2 m_xb = hasB ? *reinterpret_cast<const float2*>(x_dst + 2 * vA + 2) : make_float2(0.f, 0.f);
-      // bit 0 / 1: destination A / B has no `seen` in-edge (its residual-only row is written here); bit 2: B exists
-      const int m_flags = (m_s1 == m_s0 ? 1 : 0) | ((hasB && m_s2 == m_s1) ? 2 : 0) | (hasB ? 4 : 0);
-      const int cnt = min(kWave, (P - it0 - kb * stride + stride - 1) / stride);
-      // first-pass inputs of the NEXT pair are requested before the current pair computes
-      int q_n0 = __builtin_amdgcn_readlane(m_n0, 0), q_n1 = __builtin_amdgcn_readlane(m_n1, 0);
-      int q_n2 = __builtin_amdgcn_readlane(m_n2, 0);
-      float2 xq;   // clamped, never predicated loads (see phase S); masked slots read edge row 0
-      {
-        const int e0 = half ? q_n1 : q_n0, dg = half ? q_n2 - q_n1 : q_n1 - q_n0;
-        xq = *reinterpret_cast<const float2*>(x_ubs + static_cast<size_t>(slot < dg ? e0 + slot : 0) * FS_N);
-      }
-      for (int ii = 0; ii < cnt; ++ii) {
-        const int p = it0 + (kb + ii) * stride;
-        const int n0 = q_n0, n1 = q_n1, n2 = q_n2;
-        float2 xu = xq;
-        if (ii + 1 < cnt) {
-          q_n0 = __builtin_amdgcn_readlane(m_n0, ii + 1);
-          q_n1 = __builtin_amdgcn_readlane(m_n1, ii + 1);
-          q_n2 = __builtin_amdgcn_readlane(m_n2, ii + 1);
-          const int e0 = half ? q_n1 : q_n0, dg = half ? q_n2 - q_n1 : q_n1 - q_n0;
-          xq = *reinterpret_cast<const float2*>(x_ubs + static_cast<size_t>(slot < dg ? e0 + slot : 0) * FS_N);
-        }
-        const int flags = __builtin_amdgcn_readlane(m_flags, ii);
-        const float xa0 = rl(m_xa.x, ii), xa1 = rl(m_xa.y, ii), xb0 = rl(m_xb.x, ii), xb1 = rl(m_xb.y, ii);
-        const int degA = n1 - n0, degB = n2 - n1;
-        const int my_e0 = half ? n1 : n0, my_deg = half ? degB : degA;
-        const float xv_g = (g == 2) ? (half ? xb0 : xa0) : (half ? xb1 : xa1);   // only read by lane groups 2, 3
-
-        float m = -INFINITY, den = 0.f, s0 = 0.f, s1 = 0.f;
-        const int dmax = max(degA, degB);
-        for (int base = 0; base < dmax; base += 8) {
-          const bool valid = base + slot < my_deg;
-          const float2 xc = xu;
-          if (base + 8 < dmax)       // degrees above 8: further passes
-            xu = *reinterpret_cast<const float2*>(
-                x_ubs + static_cast<size_t>(base + 8 + slot < my_deg ? my_e0 + base + 8 + slot : 0) * FS_N);
-          const float xB = (g == 0) ? xc.x : (g == 1) ? xc.y : xv_g;
-          float e;
-#if K1_ABLATE
-          if (phases & 32) e = xB; else
-#endif
-          UAVGNN_TILE_SCORE_(Wa, att, K1_CINIT_N, wlin, xB, K1_XBOP_N(xB), e)
-          if (valid) {
-            if (a_save_n != nullptr) a_save_n[static_cast<size_t>(my_e0 + base + slot) * NH + g] = e;
-            const float mn = fmaxf(m, e);
-            const float sc = __builtin_amdgcn_exp2f(m - mn);
-            const float pw = __builtin_amdgcn_exp2f(e - mn);
-            den = fmaf(den, sc, pw);
-            s0 = fmaf(s0, sc, pw * xc.x);
-            s1 = fmaf(s1, sc, pw * xc.y);
-            m = mn;
-          }
-        }
-        // ---- segment softmax: all-reduce over the 8 slots of each destination ---------------------------------
-        const float mx = half8_max(m);
-        const float scl = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mx);
-        const float dsum = half8_sum(den * scl);
-        const float inv = dsum > 0.f ? __builtin_amdgcn_rcpf(dsum) : 0.f;      // isolated destination: aggregate = 0
-        const float t0 = half8_sum(s0 * scl) * inv, t1 = half8_sum(s1 * scl) * inv;
-        if (a_save_n != nullptr) {
-          for (int base = 0; base < my_deg; base += 8) {
-            if (base + slot < my_deg) {
-              float* ap = a_save_n + static_cast<size_t>(my_e0 + base + slot) * NH + g;
-              *ap = __builtin_amdgcn_exp2f(*ap - mx) * inv;
-            }
-          }
-        }
-        // head g's aggregated inputs of BOTH destinations in every lane of the row
-        const float o0 = dpp_mov<kRowRor + 8>(t0), o1 = dpp_mov<kRowRor + 8>(t1);
-        const float sA0 = half ? o0 : t0, sA1 = half ? o1 : t1, sB0 = half ? t0 : o0, sB1 = half ? t1 : o1;
-        // ---- epilogue: lane <-> 4 consecutive channels of head g ----------------------------------------------
-        float* rowA = out + static_cast<size_t>(2 * p) * ld_out;
-        {
-          float4 o;
-          float* op = reinterpret_cast<float*>(&o);
-          const float has = degA > 0 ? 1.f : 0.f;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float agg = has * fmaf(ws[r][1], sA1, fmaf(ws[r][0], sA0, bsn[r]));
-            op[r] = fmaxf(agg + fmaf(wrn[r][1], xa1, fmaf(wrn[r][0], xa0, brn[r])), 0.f);
-          }
-#if K1_ABLATE
-          if (!(phases & 64) || o.x == 123.456f)
-#endif
-          *reinterpret_cast<float4*>(rowA + H + 4 * lane) = o;
-          if (flags & 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) op[r] = fmaxf(fmaf(wrs[r][1], xa1, fmaf(wrs[r][0], xa0, brs[r])), 0.f);
-#if K1_ABLATE
-            if (!(phases & 64) || o.x == 123.456f)
-#endif
-            *reinterpret_cast<float4*>(rowA + 4 * lane) = o;
-          }
-        }
-        if (flags & 4) {
-          float* rowB = rowA + ld_out;
-          float4 o;
-          float* op = reinterpret_cast<float*>(&o);
-          const float has = degB > 0 ? 1.f : 0.f;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float agg = has * fmaf(ws[r][1], sB1, fmaf(ws[r][0], sB0, bsn[r]));
-            op[r] = fmaxf(agg + fmaf(wrn[r][1], xb1, fmaf(wrn[r][0], xb0, brn[r])), 0.f);
-          }
-#if K1_ABLATE
-          if (!(phases & 64) || o.x == 123.456f)
-#endif
-          *reinterpret_cast<float4*>(rowB + H + 4 * lane) = o;
-          if (flags & 2) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) op[r] = fmaxf(fmaf(wrs[r][1], xb1, fmaf(wrs[r][0], xb0, brs[r])), 0.f);
-#if K1_ABLATE
-            if (!(phases & 64) || o.x == 123.456f)
-#endif
-            *reinterpret_cast<float4*>(rowB + 4 * lane) = o;
-          }
-        }
-      }
-    }
-  }
 }
 
 }  // namespace
@@ -608,41 +696,12 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
 
 using namespace uavgnn;
 
-// The file is compiled twice: as itself (score GEMM on the bf16 matrix cores) and through gatv2_hetero_f32.hip
-// (-> K1_BF16Z = 0, K1_F32_TU: the fp32-MFMA score GEMM of rounds 1-2, reachable as phases bit 8 = the A/B and strict-fp32 leg).
-namespace uavgnn {
-#if defined(K1_F32_TU)
-int gatv2_hetero_launch_f32(
-#else
-int gatv2_hetero_launch_f32(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order, const float* x_ubs,
-                            const int32_t* near_off, const float* x_dst, int N, const float* const* seen_params,
-                            const float* const* near_params, float slope, float* out, int ld_out, float* attn_save_seen,
-                            float* attn_save_near, int phases, hipStream_t st);
-static int gatv2_hetero_launch(
-#endif
-    const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order, const float* x_ubs,
-    const int32_t* near_off, const float* x_dst, int N, const float* const* seen_params, const float* const* near_params,
-    float slope, float* out, int ld_out, float* attn_save_seen, float* attn_save_near, int phases, hipStream_t st) {
-  RelParams ps{seen_params[0], seen_params[1], seen_params[2], seen_params[3], seen_params[4], seen_params[5], seen_params[6]};
-  RelParams pn{near_params[0], near_params[1], near_params[2], near_params[3], near_params[4], near_params[5], near_params[6]};
-  int grid = capped_grid(N, kWavesPerBlock, 512);   // persistent: 2 workgroups per CU
-#if K1_ABLATE
-  if (const char* gs = getenv("K1_GRID")) grid = atoi(gs);
-#endif
-  hipLaunchKernelGGL(gatv2_hetero_fwd_kernel, dim3(grid), dim3(kThreads), 0, st, x_gt, seen_off, seen_order, x_ubs, near_off,
-                     x_dst, N, E_seen, ps, pn, slope, out, ld_out, attn_save_seen, attn_save_near,
-                     K1_ABLATE ? phases : (phases & 3));
-  return launch_status();
-}
-}  // namespace uavgnn
-
-#if !defined(K1_F32_TU)
 extern "C" int uavgnn_gatv2_hetero_supported(int F_seen, int F_near, int F_dst, int nh, int D) {
   return (F_seen == FS_S && F_near == FS_N && F_dst == 2 && nh == NH && D == ::uavgnn::D) ? 1 : 0;
 }
 
 // phases: bit 0 = phase S, bit 1 = phase N (3 = the kernel; 1 / 2 are benchmark ablations, tools/kbench_hetero.py);
-// bit 8 (UAVGNN_K1_FP32_MFMA) = the score GEMM on fp32 MFMA instead of the bf16 matrix cores.
+// bit 8 (UAVGNN_K1_FP32_MFMA) = the round 1-3 kernel with the score GEMM on fp32 MFMA (csrc/gatv2_hetero_f32.hip).
 extern "C" int uavgnn_gatv2_hetero_fwd_phases(const float* x_gt, int E_seen, const int32_t* seen_off,
                                               const int32_t* seen_order, const float* x_ubs, int E_near,
                                               const int32_t* near_off, const float* x_dst, int N,
@@ -669,8 +728,21 @@ extern "C" int uavgnn_gatv2_hetero_fwd_phases(const float* x_gt, int E_seen, con
     return gatv2_hetero_launch_f32(x_gt, E_seen, seen_off, seen_order, x_ubs, near_off, x_dst, N, seen_params, near_params,
                                    slope, out, ld_out, attn_save_seen, attn_save_near, phases, st);
 #endif
-  return gatv2_hetero_launch(x_gt, E_seen, seen_off, seen_order, x_ubs, near_off, x_dst, N, seen_params, near_params, slope,
-                             out, ld_out, attn_save_seen, attn_save_near, phases, st);
+  RelParams ps{seen_params[0], seen_params[1], seen_params[2], seen_params[3], seen_params[4], seen_params[5], seen_params[6]};
+  RelParams pn{near_params[0], near_params[1], near_params[2], near_params[3], near_params[4], near_params[5], near_params[6]};
+  int grid = capped_grid(N, kWavesPerBlock, 256);   // persistent: one workgroup of eight wavefronts per CU
+#if K1_ABLATE
+  if (const char* gs = getenv("K1_GRID")) grid = atoi(gs);
+#endif
+  if (attn_save_near != nullptr)
+    hipLaunchKernelGGL(gatv2_hetero_fwd_kernel<true>, dim3(grid), dim3(kThreads), 0, st, x_gt, seen_off, seen_order, x_ubs, near_off,
+                       x_dst, N, E_seen, ps, pn, slope, out, ld_out, attn_save_seen, attn_save_near,
+                       K1_ABLATE ? phases : (phases & 3));
+  else
+    hipLaunchKernelGGL(gatv2_hetero_fwd_kernel<false>, dim3(grid), dim3(kThreads), 0, st, x_gt, seen_off, seen_order, x_ubs, near_off,
+                       x_dst, N, E_seen, ps, pn, slope, out, ld_out, attn_save_seen, attn_save_near,
+                       K1_ABLATE ? phases : (phases & 3));
+  return launch_status();
 }
 
 extern "C" int uavgnn_gatv2_hetero_fwd(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order,
@@ -681,4 +753,3 @@ extern "C" int uavgnn_gatv2_hetero_fwd(const float* x_gt, int E_seen, const int3
   return uavgnn_gatv2_hetero_fwd_phases(x_gt, E_seen, seen_off, seen_order, x_ubs, E_near, near_off, x_dst, N, seen_params,
                                         near_params, nh, D_, slope, out, ld_out, attn_save_seen, attn_save_near, 3, stream);
 }
-#endif

@@ -3,4 +3,4 @@
 // reference of the bf16-matrix-core score GEMM and the K1 part of bench.py's strict-fp32 leg (`fp32_mfma_leg`).
 #define K1_BF16Z 0
 #define K1_F32_TU 1
-#include "gatv2_hetero.hip"
+#include "gatv2_hetero_pair.inc"
