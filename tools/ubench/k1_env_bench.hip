@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
     printf("streaming write of %.1f MB, %4d blocks: plain %6.2f us (%.2f TB/s)  nontemporal %6.2f us (%.2f TB/s)\n", n4 * 16 / 1e6, g,
            t0, n4 * 16 / t0 / 1e6, t1, n4 * 16 / t1 / 1e6);
   }
-  for (int ph : {3, 2, 2 | 2048, 1, 0, 2 | 32, 2 | 64, 2 | 128, 2 | 32 | 64 | 128}) {
+  for (int ph : {3, 3 | 4096, 3 | 8192, 3 | 12288, 2, 1, 0, 2 | 32, 2 | 64, 2 | 128, 2 | 32 | 64 | 128}) {
     auto run = [&] {
       int rc = uavgnn_gatv2_hetero_fwd_phases(d_xg, Es, d_so, d_ord, d_xu, En, d_no, d_xa, N, ps, pn, 4, 64, 0.2f, out, 2 * H,
                                               nullptr, nullptr, ph, nullptr);
@@ -157,7 +157,7 @@ int main(int argc, char** argv) {
     unsigned long long* d_dbg;
     hipMalloc(&d_dbg, size_t(waves) * 8 * 8);
     std::vector<unsigned long long> st(size_t(waves) * 8);
-    for (int ph : {3, 2}) {
+    for (int ph : {3}) {
       for (int rep = 0; rep < 3; ++rep) {
         hipMemset(d_dbg, 0, size_t(waves) * 64);
         uavgnn_gatv2_hetero_fwd_phases(d_xg, Es, d_so, d_ord, d_xu, En, d_no, d_xa, N, ps, pn, 4, 64, 0.2f, out, 2 * H,

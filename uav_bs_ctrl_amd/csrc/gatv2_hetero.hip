@@ -46,6 +46,9 @@ int gatv2_hetero_launch_f32(const float* x_gt, int E_seen, const int32_t* seen_o
 
 namespace {
 
+#ifndef K1_STORE_FLAGS
+#define K1_STORE_FLAGS " nt"   // the rows are written once and read by the next kernel from L2 / HBM: non-temporal (23.7 -> 22.4 us)
+#endif
 #ifndef K1_ABLATE
 #define K1_ABLATE 0   // 1 (tools/ubench/k1_env_bench.hip only): `phases` bit 5 skips the score tiles of phase N, bit 6 its row stores, bit 7 its epilogue products
 #endif
@@ -122,7 +125,7 @@ __device__ __forceinline__ void store_piece(float* base, unsigned lane_off, f32x
       "s_mov_b64 vcc, exec\n\t"
       "s_and_b64 exec, exec, %3\n\t"
       "s_nop 4\n\t"
-      "global_store_dwordx4 %0, %1, %2\n\t"
+      "global_store_dwordx4 %0, %1, %2" K1_STORE_FLAGS "\n\t"
       "s_mov_b64 exec, vcc"
       :
       : "v"(lane_off), "v"(v), "s"(base), "s"(lanes)
@@ -215,7 +218,19 @@ __device__ __forceinline__ void k1_fma_abs(float& acc, float z, float a) {
     E_OUT = reduce_heads(pe[0][0] + pe[0][1], pe[1][0] + pe[1][1], pe[2][0] + pe[2][1], pe[3][0] + pe[3][1]); \
   }
 
-enum { kSetSeen = 0, kSetNear = 1, kSetEpiNear = 2, kSetEpiSeen = 3 };
+enum { kSetSeen = 0, kSetNear = 1, kSetEpiNear = 2, kSets = 3 };
+enum { K1_TILES = 0, K1_NEAR = 1, K1_SEEN = 2 };
+#ifndef K1_ORDER
+#define K1_ORDER 0   // (only the ablation harness selects an order by hand: `phases` bits 12-13 = order + 1)
+#endif
+// order 0: wave A (w < 4) seen, tiles, near / wave B (its SIMD mate w + 4) tiles, seen, near; 1: both seen, tiles, near;
+// 2: A tiles, near, seen / B seen, tiles, near
+__device__ __forceinline__ int k1_part(int order, bool tiles_first, int step) {
+  if (order == 1) return step == 0 ? K1_SEEN : step == 1 ? K1_TILES : K1_NEAR;
+  if (order == 2) return tiles_first ? (step == 0 ? K1_TILES : step == 1 ? K1_NEAR : K1_SEEN)
+                                     : (step == 0 ? K1_SEEN : step == 1 ? K1_TILES : K1_NEAR);
+  return tiles_first ? (step == 0 ? K1_TILES : step == 1 ? K1_SEEN : K1_NEAR) : (step == 0 ? K1_SEEN : step == 1 ? K1_TILES : K1_NEAR);
+}
 
 // SAVE: the attention weights of both relations are written for the backward pass (training forwards); the inference
 // instantiation does not carry them through the block.
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     float* __restrict__ a_save_n_arg, int phases) {
   float* const a_save_n = SAVE ? a_save_n_arg : nullptr;
   // prepared bf16 A operands, [set][channel tile][lane]: 64 KB
-  __shared__ __attribute__((aligned(16))) k1_u32x4 sA[4][CT * kWave];
+  __shared__ __attribute__((aligned(16))) k1_u32x4 sA[kSets][CT * kWave];
   // operands of phase S's lane <-> channel prologue / epilogue (read once per destination)
   __shared__ __attribute__((aligned(16))) float sWs[H * FS_S];     // fc_src.weight of `seen`, row-major [H, 4]
   __shared__ __attribute__((aligned(16))) float sWds[H * 2], sWrs[H * 2];   // seen fc_dst / res_fc
@@ -236,6 +251,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
   __shared__ float sWa[2][NH * 4];                                  // log2(e) (1 + slope) / 2 x sum_d attn[k,d] W_s[k,d,f] per relation
   __shared__ __attribute__((aligned(16))) float sC[kWavesPerBlock][H];   // phase S: destination term; phase N: aggregate hand-over
   __shared__ __attribute__((aligned(16))) float sRow[kWavesPerBlock][16 * kBounceLd];   // phase N: output rows of one pass
+  __shared__ int sS[kWavesPerBlock][3 * kWave];   // first hand-out chunk of phase S, requested in the prologue (+ the upper half of sC)
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -278,6 +294,10 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
       xq[u] = *reinterpret_cast<const float2*>(x_ubs + static_cast<size_t>(base + u < dg ? m.n0 + base + u : 0) * FS_N);
   };
   Meta mnext = load_meta(min(it0, nblk - 1));
+  // ... and so is the first hand-out chunk of phase S (destination, segment, features of 64 positions: two of the three
+  // dependent round trips of a phase that is pure latency on a rollout batch); it waits in LDS while phase N runs
+  const int s_it = min(it0 + lane * stride, N - 1);
+  const int p_v = seen_order != nullptr ? seen_order[s_it] : s_it;
 
   // ---- workgroup prologue: constants and prepared A operands into LDS ------------------------------------------------
   // Branch-free, every global load issued before anything waits (ONE round trip; a version with `if (tid < ...)` blocks and
@@ -304,9 +324,9 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
       l_wa_w[i] = ws[d * F + f];
     }
   }
-  float l_w[8], l_b[8];   // 4 sets x 1024 entries over 512 threads: weight and bias of entry q * 512 + tid
+  float l_w[2 * kSets], l_b[2 * kSets];   // 3 sets x 1024 entries over 512 threads: weight and bias of entry q * 512 + tid
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < 2 * kSets; ++q) {
     const int idx = (q & 1) * kThreads + tid;
     const int row = (idx >> 6) * 16 + (idx & 15), gg = (idx >> 4) & 3;
     if ((q >> 1) == kSetSeen) {
@@ -315,15 +335,14 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     } else if ((q >> 1) == kSetNear) {   // A = [W_s | W_d], the channel bias b_s + b_d in the free slots of K groups 0 / 1
       l_w[q] = *(gg < 2 ? pn.W_s + row * FS_N + gg : pn.W_d + row * 2 + gg - 2);
       l_b[q] = pn.b_s[row] + pn.b_d[row];
-    } else if ((q >> 1) == kSetEpiNear) {   // A = [W_s | W_r]; b_s against `has` in K groups 0 / 1, b_r against 1 in groups 2 / 3
+    } else {   // epilogue of `near`: A = [W_s | W_r]; b_s against `has` in K groups 0 / 1, b_r against 1 in groups 2 / 3
       l_w[q] = *(gg < 2 ? pn.W_s + row * FS_N + gg : pn.W_r + row * 2 + gg - 2);
       l_b[q] = *(gg < 2 ? pn.b_s + row : brn_p + row) * (gg < 2 ? 1.f : brn_on);
-    } else {   // residual-only `seen` row: A = [0 | W_r], b_r against 1 in groups 2 / 3
-      l_w[q] = ps.W_r[row * 2 + (gg & 1)] * (gg < 2 ? 0.f : 1.f);
-      l_b[q] = brs_p[row] * (gg < 2 ? 0.f : brs_on);
     }
   }
   load_edges(mnext, min(it0, nblk - 1), 0);   // needs the meta data requested first: the one dependent round trip
+  const int p_e0 = seen_off[p_v], p_e1 = seen_off[p_v + 1];
+  const float2 p_xv = *reinterpret_cast<const float2*>(x_dst + 2 * p_v);
   // unconditional stores (two / four threads write the same value to the same word): no branch, no pessimistic wait
   reinterpret_cast<float4*>(sWs)[t256] = l_ws;
   reinterpret_cast<float4*>(sWds)[t128] = l_wd;
@@ -341,16 +360,23 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     if (wa_part == 0) sWa[wa_rel][wa_kf & 15] = (wa_f < (wa_rel ? FS_N : FS_S)) ? c_lin * a0 : 0.f;
   }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < 2 * kSets; ++q) {
     const int idx = (q & 1) * kThreads + tid;
     const int gg = (idx >> 4) & 3;
     const int set = q >> 1;
-    const int part = set == kSetSeen ? 0 : set == kSetNear ? (gg == 0 ? 1 : gg == 1 ? 2 : 0)
-                   : set == kSetEpiNear ? ((gg & 1) ? 2 : 1) : (gg < 2 ? 0 : (gg & 1) ? 2 : 1);
+    const int part = set == kSetSeen ? 0 : set == kSetNear ? (gg == 0 ? 1 : gg == 1 ? 2 : 0) : ((gg & 1) ? 2 : 1);
     sA[set][idx] = k1_a_operand(l_w[q], l_b[q], part);
   }
   __syncthreads();
   K1_STAMP(1)
+  {   // per-wave hand-over (read back by this wavefront only): after the barrier, so that no wavefront holds the others up
+    int* st = reinterpret_cast<int*>(sC[wave]) + 2 * kWave;
+    st[lane] = p_v;
+    st[kWave + lane] = p_e0;
+    sS[wave][lane] = p_e1;
+    sS[wave][kWave + lane] = __float_as_int(p_xv.x);
+    sS[wave][2 * kWave + lane] = __float_as_int(p_xv.y);
+  }
 
   float* __restrict__ cw = sC[wave];
   const f32x4 czero = {0.f, 0.f, 0.f, 0.f};
@@ -372,6 +398,10 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     // so that one of them always has instructions to issue (in lock step - both storing, then both computing - the phase took
     // 11.8 us of a rollout launch for 5.5 us of issue time).
     const bool tiles_first = (wave & 4) != 0;
+    // one block per wavefront (a rollout launch): both wavefronts of a SIMD emit the residual-only rows first - the earlier the
+    // 31 MB of them are on their way, the shorter the HBM-bound tail (measured 19.2 vs 20.8 us); several blocks per wavefront (the
+    // time-batched launches): opposite order on the two wavefronts of a SIMD (830 vs 945 us)
+    const int order = (K1_ABLATE && (phases & (3 << 12))) ? ((phases >> 12) & 3) - 1 : (nblk > stride ? 0 : 1);
     for (int blk = it0; blk < nblk; blk += stride) {
       const Meta mt = mnext;
       const int v0 = blk << 4;
@@ -439,103 +469,125 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
       for (int u = 0; u < UB; ++u) K1_TOUCH(xu[u].x);   // in flight since the previous block (or the prologue): landed before the first store
       float m = -INFINITY, den = 0.f, s0 = 0.f, s1 = 0.f;
       float pw[UB];
-      for (int step = 0; step < 2; ++step) {
-        if ((step == 0) != tiles_first) {
-          // the residual-only `seen` rows of the isolated destinations need x_v only
+      // Order of the three parts of a block - K1_SEEN: residual-only `seen` rows (store-bound), K1_TILES: score tiles + softmax
+      // (issue-bound), K1_NEAR: `near` rows (store-bound, needs the tiles).
+      for (int step = 0; step < 3; ++step) {
+        const int what = k1_part(order, tiles_first, step);
+        if (what == K1_SEEN) {
+          // The residual-only `seen` rows of the isolated destinations, ReLU(W_r x_v + b_r): two FMAs per channel, no
+          // contraction worth a matrix-core product - lane <-> four consecutive channels, one full 1-KB row per store
+          // instruction straight from the registers (as a matrix-core product + LDS transposition like the `near` rows the
+          // part took 2.2-3.9 us of a rollout launch, bound by the 16-byte LDS writes and the store pipeline).
           if (imask != 0u) {
-            const k1_bf16x8 bx = k1_b_operand(g < 2 ? 0.f : xvg, (g & 1) ? 0x00003F80u : 0x3F803F80u);
-            emit(kSetEpiSeen, 0, imask, &bx, false);
-          }
-          if (blk == it0) { K1_STAMP(3) }
-          continue;
-        }
-        // A operands and attention vector of the score tiles: (re)read from LDS per block - 32 ds_read_b128 - instead of held
-        // across the row-store parts of the block, whose LDS round trips want the registers (the opaque lane index keeps the
-        // compiler from hoisting the reads out of the block loop)
-        int lane_v = lane;
-        asm volatile("" : "+v"(lane_v));
-        k1_u32x4 Wa[CT];
-        float att[CT][4], wlin[NH];
+            int lane_s = lane;
+            asm volatile("" : "+v"(lane_s));   // constants re-read per block, not held across the tile part
+            const float4 br4 = reinterpret_cast<const float4*>(sBrs)[lane_s];
+            const float4 wr_lo = reinterpret_cast<const float4*>(sWrs)[2 * lane_s], wr_hi = reinterpret_cast<const float4*>(sWrs)[2 * lane_s + 1];
+            float* const rs = row0 + 4 * lane;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          Wa[ct] = sA[kSetNear][ct * kWave + lane_v];
-          const float4 a4 = *reinterpret_cast<const float4*>(sAn + ct * 16 + 4 * (lane_v >> 4));
-          att[ct][0] = a4.x; att[ct][1] = a4.y; att[ct][2] = a4.z; att[ct][3] = a4.w;
-        }
-#pragma unroll
-        for (int k = 0; k < NH; ++k) wlin[k] = (g < 2) ? sWa[1][k * 4 + (lane_v >> 4)] : 0.f;
-        for (int base = 0; base < maxdeg; base += UB) {
-          if (base > 0) {   // degrees above 8: further passes through the online softmax
-            load_edges(mt, blk, base);
-          }
-          float e[UB];
-#pragma unroll
-          for (int u = 0; u < UB; ++u) {
-            e[u] = 0.f;
-            if (base + u < maxdeg) {   // wave-uniform
-              const float xB = (g == 0) ? xu[u].x : (g == 1) ? xu[u].y : xvg;
-#if K1_ABLATE
-              if (phases & 32) e[u] = xB; else
-#endif
-#define K1_CINIT_N(ct) czero
-              UAVGNN_TILE_SCORE(Wa, att, K1_CINIT_N, wlin, xB, k1_b_operand(xB, one_tile), e[u])
+            for (int d = 0; d < 16; ++d) {
+              if ((imask >> d) & 1u) {   // wave-uniform
+                const float x0 = rl(mt.xv.x, d), x1 = rl(mt.xv.y, d);
+                f32x4 o;
+                o[0] = fmaxf(fmaf(wr_lo.y, x1, fmaf(wr_lo.x, x0, br4.x)), 0.f);
+                o[1] = fmaxf(fmaf(wr_lo.w, x1, fmaf(wr_lo.z, x0, br4.y)), 0.f);
+                o[2] = fmaxf(fmaf(wr_hi.y, x1, fmaf(wr_hi.x, x0, br4.z)), 0.f);
+                o[3] = fmaxf(fmaf(wr_hi.w, x1, fmaf(wr_hi.z, x0, br4.w)), 0.f);
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(rs + static_cast<size_t>(d) * ld_out));
+              }
             }
           }
-          // ---- lane-local segment softmax over the slots of this pass (lane (j, k): destination j, head k) -----------
-          float mx = -INFINITY;
-#pragma unroll
-          for (int u = 0; u < UB; ++u) {
-            e[u] = (base + u < deg) ? e[u] : -INFINITY;
-            mx = fmaxf(mx, e[u]);
+          if (blk == it0) { K1_STAMP(3) }
+        } else if (what == K1_TILES) {
+          // A operands and attention vector of the score tiles: (re)read from LDS per block - 32 ds_read_b128 - instead of held
+          // across the row-store parts of the block, whose LDS round trips want the registers (the opaque lane index keeps the
+          // compiler from hoisting the reads out of the block loop)
+          int lane_v = lane;
+          asm volatile("" : "+v"(lane_v));
+          k1_u32x4 Wa[CT];
+          float att[CT][4], wlin[NH];
+  #pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            Wa[ct] = sA[kSetNear][ct * kWave + lane_v];
+            const float4 a4 = *reinterpret_cast<const float4*>(sAn + ct * 16 + 4 * (lane_v >> 4));
+            att[ct][0] = a4.x; att[ct][1] = a4.y; att[ct][2] = a4.z; att[ct][3] = a4.w;
           }
-          const float mn = fmaxf(m, mx);
-          const float mref = (mn == -INFINITY) ? 0.f : mn;      // destination without in-edges so far: every weight is exp2(-inf) = 0
-          const float sc = __builtin_amdgcn_exp2f(m - mref);     // exp2(-inf) = 0 on the first pass
-          den *= sc;
-          s0 *= sc;
-          s1 *= sc;
-#pragma unroll
-          for (int u = 0; u < UB; ++u) {
-            pw[u] = __builtin_amdgcn_exp2f(e[u] - mref);
-            den += pw[u];
-            s0 = fmaf(pw[u], xu[u].x, s0);
-            s1 = fmaf(pw[u], xu[u].y, s1);
+  #pragma unroll
+          for (int k = 0; k < NH; ++k) wlin[k] = (g < 2) ? sWa[1][k * 4 + (lane_v >> 4)] : 0.f;
+          for (int base = 0; base < maxdeg; base += UB) {
+            if (base > 0) {   // degrees above 8: further passes through the online softmax
+              load_edges(mt, blk, base);
+            }
+            float e[UB];
+  #pragma unroll
+            for (int u = 0; u < UB; ++u) {
+              e[u] = 0.f;
+              if (base + u < maxdeg) {   // wave-uniform
+                const float xB = (g == 0) ? xu[u].x : (g == 1) ? xu[u].y : xvg;
+  #if K1_ABLATE
+                if (phases & 32) e[u] = xB; else
+  #endif
+  #define K1_CINIT_N(ct) czero
+                UAVGNN_TILE_SCORE(Wa, att, K1_CINIT_N, wlin, xB, k1_b_operand(xB, one_tile), e[u])
+              }
+            }
+            // ---- lane-local segment softmax over the slots of this pass (lane (j, k): destination j, head k) -----------
+            float mx = -INFINITY;
+  #pragma unroll
+            for (int u = 0; u < UB; ++u) {
+              e[u] = (base + u < deg) ? e[u] : -INFINITY;
+              mx = fmaxf(mx, e[u]);
+            }
+            const float mn = fmaxf(m, mx);
+            const float mref = (mn == -INFINITY) ? 0.f : mn;      // destination without in-edges so far: every weight is exp2(-inf) = 0
+            const float sc = __builtin_amdgcn_exp2f(m - mref);     // exp2(-inf) = 0 on the first pass
+            den *= sc;
+            s0 *= sc;
+            s1 *= sc;
+  #pragma unroll
+            for (int u = 0; u < UB; ++u) {
+              pw[u] = __builtin_amdgcn_exp2f(e[u] - mref);
+              den += pw[u];
+              s0 = fmaf(pw[u], xu[u].x, s0);
+              s1 = fmaf(pw[u], xu[u].y, s1);
+            }
+            m = mn;
+            if (a_save_n != nullptr && maxdeg > UB) {   // raw scores now, weights once the maximum and the sum are final
+  #pragma unroll
+              for (int u = 0; u < UB; ++u)
+                if (base + u < deg) a_save_n[static_cast<size_t>(mt.n0 + base + u) * NH + g] = e[u];
+            }
           }
-          m = mn;
-          if (a_save_n != nullptr && maxdeg > UB) {   // raw scores now, weights once the maximum and the sum are final
-#pragma unroll
-            for (int u = 0; u < UB; ++u)
-              if (base + u < deg) a_save_n[static_cast<size_t>(mt.n0 + base + u) * NH + g] = e[u];
-          }
-        }
-        if (blk == it0) { K1_STAMP(4) }
-      }
-      const float inv = den > 0.f ? __builtin_amdgcn_rcpf(den) : 0.f;      // isolated destination: aggregate = 0
-      if (a_save_n != nullptr) {
-        if (maxdeg <= UB) {
-#pragma unroll
-          for (int u = 0; u < UB; ++u)
-            if (u < deg) a_save_n[static_cast<size_t>(mt.n0 + u) * NH + g] = pw[u] * inv;
+          if (blk == it0) { K1_STAMP(4) }
         } else {
-          for (int u = 0; u < deg; ++u) {
-            float* ap = a_save_n + static_cast<size_t>(mt.n0 + u) * NH + g;
-            *ap = __builtin_amdgcn_exp2f(*ap - m) * inv;
+          const float inv = den > 0.f ? __builtin_amdgcn_rcpf(den) : 0.f;      // isolated destination: aggregate = 0
+          if (a_save_n != nullptr) {
+            if (maxdeg <= UB) {
+    #pragma unroll
+              for (int u = 0; u < UB; ++u)
+                if (u < deg) a_save_n[static_cast<size_t>(mt.n0 + u) * NH + g] = pw[u] * inv;
+            } else {
+              for (int u = 0; u < deg; ++u) {
+                float* ap = a_save_n + static_cast<size_t>(mt.n0 + u) * NH + g;
+                *ap = __builtin_amdgcn_exp2f(*ap - m) * inv;
+              }
+            }
           }
+          // ---- hand the aggregates of head k over to the lanes that feed K group g of the epilogue product ---------------
+          cw[j * 8 + g] = s0 * inv;
+          cw[j * 8 + 4 + g] = s1 * inv;
+          wave_sync_lds();
+          const f32x4 ag = *reinterpret_cast<const f32x4*>(cw + j * 8 + (g & 1) * 4);   // feature g of heads 0..3 (groups 0, 1)
+          const unsigned has_w = deg > 0 ? 0xffffffffu : 0u;
+          const unsigned one_epi = (g & 1 ? 0x00003F80u : 0x3F803F80u) & (g < 2 ? has_w : 0xffffffffu);
+          k1_bf16x8 bop[NH];
+    #pragma unroll
+          for (int k = 0; k < NH; ++k) bop[k] = k1_b_operand(g < 2 ? ag[k] : xvg, one_epi);
+          wave_sync_lds();   // cw is rewritten by the next block
+          emit(kSetEpiNear, H, vmask, bop, true);
+          if (blk == it0) { K1_STAMP(5) }
         }
       }
-      // ---- hand the aggregates of head k over to the lanes that feed K group g of the epilogue product ---------------
-      cw[j * 8 + g] = s0 * inv;
-      cw[j * 8 + 4 + g] = s1 * inv;
-      wave_sync_lds();
-      const f32x4 ag = *reinterpret_cast<const f32x4*>(cw + j * 8 + (g & 1) * 4);   // feature g of heads 0..3 (groups 0, 1)
-      const unsigned has_w = deg > 0 ? 0xffffffffu : 0u;
-      const unsigned one_epi = (g & 1 ? 0x00003F80u : 0x3F803F80u) & (g < 2 ? has_w : 0xffffffffu);
-      k1_bf16x8 bop[NH];
-#pragma unroll
-      for (int k = 0; k < NH; ++k) bop[k] = k1_b_operand(g < 2 ? ag[k] : xvg, one_epi);
-      wave_sync_lds();   // cw is rewritten by the next block
-      emit(kSetEpiNear, H, vmask, bop, true);
-      if (blk == it0) { K1_STAMP(5) }
       load_edges(mnext, nb, 0);   // first-pass inputs of the next block
     }
 #if K1_ABLATE
@@ -660,12 +712,22 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     // the look-ahead s_loads of the NEXT destination (an L2 round trip per destination).
     bool done = false;
     for (int kb = 0; !done && it0 + kb * stride < N; kb += kWave) {
-      const int my_it = it0 + (kb + lane) * stride;
-      const bool mine = my_it < N;
-      const int m_v = mine ? (seen_order ? seen_order[my_it] : my_it) : 0;
-      const int m_e0 = mine ? seen_off[m_v] : 0;
-      const int m_e1 = mine ? seen_off[m_v + 1] : 0;
-      const float2 m_xv = mine ? *reinterpret_cast<const float2*>(x_dst + 2 * m_v) : make_float2(0.f, 0.f);
+      int m_v, m_e0, m_e1;
+      float2 m_xv;
+      if (kb == 0) {   // requested in the prologue
+        const int* st = reinterpret_cast<const int*>(sC[wave]) + 2 * kWave;
+        m_v = st[lane];
+        m_e0 = st[kWave + lane];
+        m_e1 = sS[wave][lane];
+        m_xv = make_float2(__int_as_float(sS[wave][kWave + lane]), __int_as_float(sS[wave][2 * kWave + lane]));
+      } else {
+        const int my_it = it0 + (kb + lane) * stride;
+        const bool mine = my_it < N;
+        m_v = mine ? (seen_order ? seen_order[my_it] : my_it) : 0;
+        m_e0 = mine ? seen_off[m_v] : 0;
+        m_e1 = mine ? seen_off[m_v + 1] : 0;
+        m_xv = mine ? *reinterpret_cast<const float2*>(x_dst + 2 * m_v) : make_float2(0.f, 0.f);
+      }
       const int cnt = min(kWave, (N - it0 - kb * stride + stride - 1) / stride);
       {
         const int e0 = __builtin_amdgcn_readlane(m_e0, 0);
@@ -689,6 +751,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
       }
     }
   }
+  K1_STAMP(7)
 }
 
 }  // namespace
