@@ -1882,3 +1882,77 @@ def test_no_grad_tarmac_step_without_the_concatenated_copy_equals_the_training_f
         q0, h0 = agent(g, h)
     q1, h1 = agent(g.fresh(), h.clone().requires_grad_(True))
     assert th.equal(q0, q1.detach()) and th.equal(h0, h1.detach())
+
+
+def _small_learner_and_batch(B=160, n=8, M=20, T=3, seed=0, **over):
+    """exp3 learner + a synthetic sampled batch of B sequences (bench.py's generator): N = B n >= 1024 rows, so the recurrent
+    step takes the fused matrix-core kernels the benchmark runs."""
+    import bench
+    from uav_bs_ctrl_amd.learner import MultiAgentQLearner
+    th.manual_seed(seed)
+    args = bench.exp3_args("cuda")
+    for k, v in over.items():
+        setattr(args, k, v)
+    learner = MultiAgentQLearner(dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=9, n_agents=n, episode_limit=T), args)
+    batch = bench.make_sequence(B, n, M, T, "env", th.device("cuda"), seed=7, distinct=2)
+    return learner, batch
+
+
+@pytest.mark.gpu
+def test_time_batched_weight_gradient_staging_equals_the_per_step_reductions(monkeypatch):
+    """ops.WeightGradSink.begin_sequence / end_sequence (learner.accumulate): the weight and bias gradients of the T + 1
+    recurrent steps reduced ONCE from time-batched buffers equal the per-step reductions of round 3 (same products, another
+    summation order: 1e-5 relative), the staging is actually taken, and two staged runs agree bit for bit."""
+    from uav_bs_ctrl_amd import ops
+    learner, batch = _small_learner_and_batch()
+    taken = []
+    orig = ops.WeightGradSink.end_sequence
+
+    def spy(self):
+        taken.append(0 if self.seq is None else len(self.seq.bwd_steps))
+        return orig(self)
+    monkeypatch.setattr(ops.WeightGradSink, "end_sequence", spy)
+
+    def grads(staged):
+        monkeypatch.setattr(ops, "SEQ_STAGING", staged)
+        fb = dict(batch, obs=[g.fresh() for g in batch["obs"]], obs_all=batch["obs_all"].fresh(),
+                  obs_all_next=batch["obs_all_next"].fresh())
+        learner.accumulate(fb)
+        return learner.grads.flat.clone()
+    g_step = grads(False)
+    assert max(taken) == 0
+    g_seq, g_seq2 = grads(True), grads(True)
+    assert max(taken) == len(batch["obs"])                      # every recurrent step of the sequence was staged
+    assert th.equal(g_seq, g_seq2)
+    assert float(g_step.abs().max()) > 0
+    assert_close(g_seq, g_step, 1e-5, "flat gradient, staged vs per-step")
+
+
+@pytest.mark.gpu
+def test_plane_cache_never_serves_a_recycled_weight_address():
+    """TarMAC with a dueling head builds its stacked projection weight with th.cat on every call; with msg + 2 key =
+    128 columns and N >= 4096 rows it takes the bf16x3 GEMM whose weight planes are cached per frozen_weights() scope under
+    the weight's ADDRESS.  The target network's temporary is freed after its no-grad step, the policy network's next
+    temporary may land on the same address: the cache entry keeps its weight alive, so the address cannot be recycled and
+    the gradients with the scope equal the gradients without it."""
+    from uav_bs_ctrl_amd import ops
+    learner, batch = _small_learner_and_batch(B=512, n=8, M=10, T=2, dueling=True, msg_size=64, key_size=32)
+
+    def grads(scope):
+        fb = dict(batch, obs=[g.fresh() for g in batch["obs"]], obs_all=batch["obs_all"].fresh(),
+                  obs_all_next=batch["obs_all_next"].fresh())
+        if scope:
+            learner.accumulate(fb)
+        else:
+            class _NoScope:
+                def __enter__(self): return self
+                def __exit__(self, *e): return False
+            orig, ops.frozen_weights = ops.frozen_weights, _NoScope
+            try:
+                learner.accumulate(fb)
+            finally:
+                ops.frozen_weights = orig
+        return learner.grads.flat.clone()
+    g0, g1 = grads(False), grads(True)
+    assert float(g0.abs().max()) > 0
+    assert th.equal(g0, g1)

@@ -375,3 +375,17 @@ def test_kernel_timer_filter_selects_spans_by_name():
     with t.span("graded") as s:
         assert s.on is False
     assert t._spans == {}
+
+
+def test_weight_plane_cache_keeps_the_weights_it_is_keyed_on_alive():
+    """The cache key holds weight ADDRESSES: the entry holds the weights, so the allocator cannot recycle an address while a
+    scope could still hit it (TarMAC's per-call th.cat weight of the target net vs the policy net's next one)."""
+    import weakref
+    from uav_bs_ctrl_amd import ops
+    w = th.zeros(8)
+    ref = weakref.ref(w)
+    with ops.frozen_weights():
+        ops._cached_planes(("mat", w.data_ptr()), 8, "cpu", lambda p: None, keep=(w,))
+        del w
+        assert ref() is not None
+    assert ref() is None

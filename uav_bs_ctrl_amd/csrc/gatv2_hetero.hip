@@ -477,7 +477,9 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
           // The residual-only `seen` rows of the isolated destinations, ReLU(W_r x_v + b_r): two FMAs per channel, no
           // contraction worth a matrix-core product - lane <-> four consecutive channels, one full 1-KB row per store
           // instruction straight from the registers (as a matrix-core product + LDS transposition like the `near` rows the
-          // part took 2.2-3.9 us of a rollout launch, bound by the 16-byte LDS writes and the store pipeline).
+          // part took 2.2-3.9 us of a rollout launch, bound by the 16-byte LDS writes and the store pipeline).  Issued in one
+          // burst the 16 stores hold the wavefront for ~2.8 us on a full store queue; spread over the score tiles, two per
+          // tile, they hold the TILES up instead (measured: 22.2 vs 20.0 us) - the burst stays.
           if (imask != 0u) {
             int lane_s = lane;
             asm volatile("" : "+v"(lane_s));   // constants re-read per block, not held across the tile part

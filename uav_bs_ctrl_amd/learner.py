@@ -196,6 +196,9 @@ class MultiAgentQLearner:
             # per-step views + the slices of ONE gradient buffer the steps' backward passes write into (no stack)
             xs, slots = ops.time_split(x_pol, T + 1)
             xt = x_tgt.view(T, N, -1)
+            if ops.GRAD_SINK is not None and th.is_grad_enabled() and ops.SEQ_STAGING:
+                # the weight / bias gradients of the T + 1 recurrent steps are reduced ONCE, from time-batched buffers
+                ops.GRAD_SINK.begin_sequence(T + 1, N, x_pol)
             for t in range(T):
                 logits, h = self.policy_net.step(obs[t], xs[t], h, slots[t])
                 agent_out.append(logits)
@@ -263,6 +266,8 @@ class MultiAgentQLearner:
                     if len(chunks) > 1:
                         loss_b = loss_b / len(chunks)
                     loss_b.backward()
+                    if sink is not None:
+                        sink.end_sequence()
                     loss = loss_b.detach() if loss is None else loss + loss_b.detach()
             if sink is not None:
                 sink.flush()

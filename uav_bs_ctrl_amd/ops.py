@@ -338,16 +338,22 @@ class frozen_weights:
         return False
 
 
-def _cached_planes(key, nbytes, device, build):
-    """planes tensor for `key`; `build(planes)` launches the split when the scope has not seen the key yet."""
+def _cached_planes(key, nbytes, device, build, keep=()):
+    """planes tensor for `key`; `build(planes)` launches the split when the scope has not seen the key yet.
+
+    The key holds device ADDRESSES of the weights, so an entry also holds strong references to them (`keep`): while the
+    entry lives the caching allocator cannot hand those addresses to another tensor, i.e. a hit IS the same storage.  (A
+    temporary weight - TarMAC's stacked projection built by th.cat on every call - freed after a no-grad target-network
+    step would otherwise let the next policy step's temporary of the same shape land on the same address and pick up the
+    TARGET network's planes.)"""
     if _PLANES is not None:
         hit = _PLANES.get(key)
         if hit is not None:
-            return hit
+            return hit[0]
     planes = th.empty(nbytes, dtype=th.uint8, device=device)
     build(planes)
     if _PLANES is not None:
-        _PLANES[key] = planes
+        _PLANES[key] = (planes, tuple(keep))
     return planes
 
 
@@ -361,11 +367,12 @@ def gru_cell_two_piece_supported(x, c, h) -> bool:
                 and 4 * x.shape[0] * max(x.stride(0), c.stride(0), H) < 2 ** 32)
 
 
-def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save, inp2=None):
+def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save, inp2=None, h2_out=None):
     """h' (and the [N, 4H] pre-activation sets when `save`) of the fused GRU cell.  inp2: second piece of the input
-    ([inp || inp2] is what W_ih multiplies; the caller checked gru_cell_two_piece_supported)."""
+    ([inp || inp2] is what W_ih multiplies; the caller checked gru_cell_two_piece_supported).  h2_out: contiguous [N, H]
+    buffer h' is written into (a slot of the time-batched staging of a BPTT sequence)."""
     N, H = h.shape
-    h2 = th.empty_like(h)
+    h2 = th.empty_like(h) if h2_out is None else h2_out
     pre = th.empty((N, 4 * H), dtype=th.float32, device=h.device) if save else None
     _apply_variant_env()
     if inp2 is not None or (GRU_X3 and L.lib().uavgnn_gru_cell_x3_supported(inp.shape[1], H)
@@ -379,7 +386,7 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save, inp2=None):
                                     lib.uavgnn_gru_cell_x3_workspace_bytes(K_in, H), h.device,
                                     lambda p: L.check(lib.uavgnn_gru_split_weights(W_ih.data_ptr(), K_in, W_hh.data_ptr(), H,
                                                                                    p.data_ptr(), L.stream()),
-                                                      "uavgnn_gru_split_weights"))
+                                                      "uavgnn_gru_split_weights"), keep=(W_ih, W_hh))
             rc = lib.uavgnn_gru_cell_fwd_x3_cat(inp.data_ptr(), inp.stride(0), K1, L.ptr(inp2),
                                                 0 if inp2 is None else inp2.stride(0), K2, h.data_ptr(), N, H, planes.data_ptr(),
                                                 b_ih.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), L.ptr(pre), L.stream())
@@ -393,10 +400,13 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save, inp2=None):
     return h2, pre
 
 
-def _gru_gates_bwd_from_pre(pre, h, d_hout):
+def _gru_gates_bwd_from_pre(pre, h, d_hout, d_gi=None, d_gh=None):
     N, H = h.shape
-    d_gi = th.empty((N, 3 * H), dtype=th.float32, device=h.device)
-    d_gh, dh = th.empty_like(d_gi), th.empty_like(h)
+    if d_gi is None:
+        d_gi = th.empty((N, 3 * H), dtype=th.float32, device=h.device)
+    if d_gh is None:
+        d_gh = th.empty_like(d_gi)
+    dh = th.empty_like(h)
     with KERNEL_TIMER.span("gru_gates_bwd"):
         rc = L.lib().uavgnn_gru_gates_bwd_fused(pre.data_ptr(), h.data_ptr(), d_hout.data_ptr(), N, H, d_gi.data_ptr(),
                                                 d_gh.data_ptr(), dh.data_ptr(), L.stream())
@@ -512,7 +522,8 @@ def gemm_x3(a, W, transpose_w=False, bias=None, out=None, accumulate=False, relu
     with KERNEL_TIMER.span("gemm_x3", (M, n_out, K)):
         planes = _cached_planes(("mat", W.data_ptr(), W.stride(0), R, C, bool(transpose_w)), 6 * R * C, a.device,
                                 lambda p: L.check(lib.uavgnn_split_bf16x3(W.data_ptr(), W.stride(0), R, C, int(transpose_w),
-                                                                          p.data_ptr(), L.stream()), "uavgnn_split_bf16x3"))
+                                                                          p.data_ptr(), L.stream()), "uavgnn_split_bf16x3"),
+                                keep=(W,))
         rc = lib.uavgnn_gemm_nt_x3(a.data_ptr(), a.stride(0), M, K, planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(),
                                    out.stride(0), (1 if accumulate else 0) | (2 if relu else 0), L.stream())
     L.check(rc, "uavgnn_gemm_nt_x3")
@@ -646,6 +657,8 @@ class WeightGradSink:
     accumulators into ``param.grad`` once, in a fixed order (deterministic)."""
 
     def __init__(self):
+        self.seq = None      # time-batched staging of the sequence in flight (begin_sequence)
+        self._seq_bufs = None
         self.slots = {}      # (key, chunk count) -> (buffer, flush_fn)
         # d h buffer the fused step's backward handed to autograd LAST (private), keyed by its address.  The entry holds a
         # strong reference: while it is alive the allocator cannot hand that address to another tensor, so an incoming
@@ -696,12 +709,68 @@ class WeightGradSink:
         L.check(L.lib().uavgnn_colsum_acc(dy.data_ptr(), dy.stride(0), n, C, slot[0].data_ptr(), S, L.stream()),
                 "uavgnn_colsum_acc")
 
+    # ---- time-batched staging of ONE BPTT sequence -------------------------------------------------------------------
+    # None of the weight / bias gradient reductions of the recurrent step depends on the recurrence: they are sums over
+    # (time step, agent).  Inside begin_sequence() ... end_sequence() the fused step therefore does not reduce anything per
+    # step: its forward writes [x || c] and h' into slots of [T1, N, .] buffers, its backward writes d_gi, d_gh, d_proj (and
+    # copies dq) into slots of the same shape - the kernels that produce them write there directly, no extra traffic - and
+    # end_sequence() issues ONE dy^T x per weight over T1 * N rows (1.67 M at C3: the shape class where csrc/gemm_tn_x3.hip
+    # beats the vendor's split-K GEMM) and ONE column sum per bias: 5 + 4 launches per sequence instead of (5 + 4) * T1
+    # (autograd of gnn_agents.py:243-246,:56 under learner.py:157).
+    def begin_sequence(self, T1, N, x_all):
+        """x_all: the time-major [T1 * N, H] input of the T1 recurrent steps (the time-batched encoder's output)."""
+        self.seq = _SequenceStage(T1, N, x_all.detach(), getattr(self, "_seq_bufs", None))
+        self._seq_bufs = self.seq.bufs          # the buffers are reused by the next sequence (chunks of one accumulate)
+
+    def end_sequence(self):
+        seq, self.seq = getattr(self, "seq", None), None
+        if seq is None or not seq.bwd_steps:
+            return
+        T1, N = seq.T1, seq.N
+        full = sorted(seq.bwd_steps) == list(range(T1)) and seq.t_fwd == T1
+        spans = [(0, T1)] if full else [(t, t + 1) for t in sorted(seq.bwd_steps)]
+        split, ids, H = seq.split, seq.ids, seq.H
+        for (t0, t1) in spans:
+            rows = lambda name, lo=0: seq.bufs[name][t0 + lo:t1 + lo].reshape((t1 - t0) * N, -1)   # noqa: E731
+            d_proj, d_gi, d_gh, dq = rows("d_proj"), rows("d_gi"), rows("d_gh"), rows("dq")
+            x = seq.x_all[t0 * N:t1 * N]
+            h, h2, inp = rows("h"), rows("h", 1), rows("inp")
+            self.weight(("Wp_x", ids["Wp"]), d_proj, x, lambda g: split("Wp", g, 0))
+            self.weight(("Wp_h", ids["Wp"]), d_proj, h, lambda g: split("Wp", g, H))
+            self.bias(("bp", ids["Wp"]), d_proj, lambda g: split("bp", g, 0))
+            self.weight(("W_ih", ids["W_ih"]), d_gi, inp, lambda g: split("W_ih", g, 0))
+            self.bias(("b_ih", ids["W_ih"]), d_gi, lambda g: split("b_ih", g, 0))
+            self.weight(("W_hh", ids["W_hh"]), d_gh, h, lambda g: split("W_hh", g, 0))
+            self.bias(("b_hh_n", ids["W_hh"]), d_gh[:, 2 * H:], lambda g: split("b_hh", g, 2 * H))
+            self.weight(("W_out", ids["W_out"]), dq, h2, lambda g: split("W_out", g, 0))
+            self.bias(("b_out", ids["W_out"]), dq, lambda g: split("b_out", g, 0))
+
     def flush(self):
+        self.end_sequence()
         for key, (buf, fn) in self.slots.items():
             if fn is not None:
                 fn(buf.sum(0))
         self.slots = {}
         self.owned.clear()
+        self._seq_bufs = None
+
+
+class _SequenceStage:
+    """Slots of the time-batched buffers of one BPTT sequence (WeightGradSink.begin_sequence)."""
+
+    def __init__(self, T1, N, x_all, bufs=None):
+        self.T1, self.N, self.x_all = T1, N, x_all
+        self.bufs = bufs if bufs is not None else {}
+        self.t_fwd = 0
+        self.bwd_steps = []
+        self.split = self.ids = self.H = None
+
+    def slot(self, name, t, cols, extra=0):
+        """[N, cols] slot t of the [T1 + extra, N, cols] buffer `name`."""
+        b = self.bufs.get(name)
+        if b is None or b.shape != (self.T1 + extra, self.N, cols) or b.device != self.x_all.device:
+            b = self.bufs[name] = th.empty((self.T1 + extra, self.N, cols), dtype=th.float32, device=self.x_all.device)
+        return b[t]
 
 
 def _wgrad(dy, x):
@@ -715,6 +784,7 @@ def _wgrad(dy, x):
 
 
 GRAD_SINK = None   # set by the learner around loss.backward(); None -> gradients are returned to autograd as usual
+SEQ_STAGING = os.environ.get("UAVGNN_SEQ_STAGING", "1") != "0"   # weight / bias gradients of a BPTT sequence reduced once (A/B switch)
 
 
 def _add_grad(p, g):
@@ -787,6 +857,7 @@ class _TarmacStep(th.autograd.Function):
         E = talk_src.shape[0]
         a_save = th.empty(max(E, 1), dtype=th.float32, device=x.device)
         ld = M + 2 * K
+        ctx.seq = ctx.seq_t = None
         aligned = all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (W_ih, W_hh))
         c_only = None
         if not train and aligned and h.shape[0] >= GRU_FUSED_MIN_ROWS and GRU_FUSED:
@@ -802,13 +873,29 @@ class _TarmacStep(th.autograd.Function):
             inp, fused = c_only, True
             gi = gh = h2                                           # placeholders keep save_for_backward's arity
         else:
-            inp = th.empty((N, H + M), dtype=th.float32, device=x.device)     # [x || c], both halves filled by K3b
+            # inside a staged BPTT sequence (WeightGradSink.begin_sequence) [x || c] and h' are written into the slots of
+            # step t of the time-batched buffers the weight gradients are reduced from at the end of the sequence
+            seq = GRAD_SINK.seq if (train and GRAD_SINK is not None) else None
+            if seq is not None and (seq.t_fwd >= seq.T1 or N != seq.N or seq.x_all.shape[1] != H or
+                                    x.data_ptr() != seq.x_all.data_ptr() + 4 * H * N * seq.t_fwd):
+                seq = None           # not a step of the sequence that was announced (or more steps than announced)
+            if seq is not None:
+                seq_t = seq.t_fwd
+                seq.t_fwd += 1
+                inp = seq.slot("inp", seq_t, H + M)
+                if seq_t == 0:
+                    seq.slot("h", 0, H, extra=1).copy_(h)
+            else:
+                inp = th.empty((N, H + M), dtype=th.float32, device=x.device)     # [x || c], both halves filled by K3b
             _launch_talk_fwd(env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld, K, M,
                              talk_off, talk_src, N, 1.0 / K, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(), x.data_ptr(),
                              x.stride(0), H)
             fused = gru_cell_supported(inp, h) and aligned
             if fused:      # K4 in one launch: gi / gh never reach HBM; training forwards keep the [N, 4H] pre-activation sets
-                h2, pre = _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save=bool(train))
+                h2, pre = _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save=bool(train),
+                                           h2_out=None if seq is None else seq.slot("h", seq_t + 1, H, extra=1))
+                if seq is not None and pre is not None:
+                    ctx.seq, ctx.seq_t = seq, seq_t
                 gi = gh = pre if pre is not None else h2           # placeholders keep save_for_backward's arity
             else:
                 gi = th.addmm(b_ih, inp, W_ih.t())
@@ -847,7 +934,11 @@ class _TarmacStep(th.autograd.Function):
             dh2_tot = dh2.addmm_(dq, W_out)
         else:
             dh2_tot = th.addmm(dh2, dq, W_out)
-        if ctx.fused_gru:
+        seq = ctx.seq if (sink is not None and ctx.seq is not None and sink.seq is ctx.seq) else None
+        if seq is not None:      # staged sequence: the gate gradients go straight into the time-batched buffers
+            t = ctx.seq_t
+            d_gi, d_gh, dh = _gru_gates_bwd_from_pre(gi, h, dh2_tot, seq.slot("d_gi", t, 3 * H), seq.slot("d_gh", t, 3 * H))
+        elif ctx.fused_gru:
             d_gi, d_gh, dh = _gru_gates_bwd_from_pre(gi, h, dh2_tot)      # gi holds the saved pre-activation sets
         else:
             d_gi, d_gh, dh = th.empty_like(gi), th.empty_like(gh), th.empty_like(h)
@@ -861,7 +952,7 @@ class _TarmacStep(th.autograd.Function):
             sink.owned.clear()
             sink.owned[dh.data_ptr()] = dh
         ld = M + 2 * K
-        d_proj = th.empty((N, ld), dtype=th.float32, device=x.device)
+        d_proj = th.empty((N, ld), dtype=th.float32, device=x.device) if seq is None else seq.slot("d_proj", ctx.seq_t, ld)
         _launch_talk_bwd(ctx.env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld,
                          K, M, talk_off, talk_src, (t_off, t_dst, t_pos), N, 1.0 / K, a_save, d_inp.data_ptr() + 4 * H,
                          H + M, d_proj.data_ptr() + 4 * M, ld, d_proj.data_ptr() + 4 * (M + K), ld, d_proj.data_ptr(),
@@ -871,7 +962,13 @@ class _TarmacStep(th.autograd.Function):
             th.addmm(d_inp[:, :H], d_proj, Wp[:, :H], out=dx)
         else:
             dx = th.addmm(d_inp[:, :H], d_proj, Wp[:, :H])                # h enters the projections stop-gradded
-        if sink is not None:
+        if seq is not None:      # reduced once per sequence (WeightGradSink.end_sequence)
+            seq.slot("dq", ctx.seq_t, dq.shape[1]).copy_(dq)
+            seq.bwd_steps.append(ctx.seq_t)
+            seq.split, seq.H = ctx.split, H
+            seq.ids = {"Wp": id(Wp), "W_ih": id(W_ih), "W_hh": id(W_hh), "W_out": id(W_out)}
+            gWp = gbp = gWih = gbih = gWhh = gbhh = gWo = gbo = None
+        elif sink is not None:
             split = ctx.split
             sink.weight(("Wp_x", id(Wp)), d_proj, x, lambda g: split("Wp", g, 0))
             sink.weight(("Wp_h", id(Wp)), d_proj, h, lambda g: split("Wp", g, H))
