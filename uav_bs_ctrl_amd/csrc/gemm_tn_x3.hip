@@ -21,6 +21,9 @@ namespace uavgnn {
 namespace {
 
 using namespace x3;
+#ifndef GEMM_TN_XCD_ORDER
+#define GEMM_TN_XCD_ORDER 0   // 1: all tiles of a row chunk on one XCD (measured with tools/gemm_tn_big_probe.py: +4 % on the 18-tile W_ih shape, -5 % on the 8-tile f_aggr shape, the one shape that runs here - the time-batched recurrent weights went to the vendor GEMM)
+#endif
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int PT = 128 * 4;   // 16-byte chunks per split plane of a 128-feature tile
 
@@ -32,7 +35,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l32 = lane & 31, lh = lane >> 5, sw = swz32(l32);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int tile = blockIdx.x, s = blockIdx.y;
+  // Workgroup -> (output tile, row chunk).  Consecutive workgroup ids go to consecutive XCDs (8, each with its own L2), and
+  // every tile of a row chunk reads the same rows of dY / X: all tiles of chunk s are therefore placed on XCD s % 8, next to
+  // each other in launch order, so that a row slice is fetched from HBM once per chunk and not once per tile (time-batched
+  // weight gradients: 18 tiles over 1.67 M rows moved 30 GB instead of 7 GB and ran at 120 instead of 160 TFLOP/s).
+  // S is a multiple of 8 whenever it is at least 8 (uavgnn_gemm_tn_x3_chunks); smaller S keep the plain order.
+  const int tiles = gridDim.x, S_all = gridDim.y;
+  int tile = blockIdx.x, s = blockIdx.y;
+  if (GEMM_TN_XCD_ORDER && (S_all & 7) == 0) {
+    const int id = blockIdx.y * tiles + blockIdx.x;   // launch order: x fastest
+    const int xcd = id & 7, k = id >> 3;
+    tile = k % tiles;
+    s = (k / tiles) * 8 + xcd;
+  }
   const int rb = tile / col_blocks, cb = tile - rb * col_blocks;
   const int m0 = rb * BM, n0 = cb * BN;
   const long long r_begin = static_cast<long long>(s) * chunk, r_end = min(r_begin + chunk, n_rows);
@@ -142,7 +157,8 @@ extern "C" int uavgnn_gemm_tn_x3_chunks(long long n_rows, int Mo, int Ko) {
   if (S < 1) S = 1;
   const long long max_s = (n_rows + 255) / 256;
   if (S > max_s) S = max_s;
-  if (S > 64) S = 64;
+  if (S > 256) S = 256;                      // few-tile outputs (a 96- or 9-row weight): enough chunks to fill the chip
+  if (S >= 8) S = (S + 7) / 8 * 8;           // whole rounds over the 8 XCDs (the kernel's tile order relies on it)
   return static_cast<int>(S);
 }
 

@@ -673,9 +673,9 @@ class WeightGradSink:
             S *= 2
         return S
 
-    def weight(self, key, dy, x, flush_fn):
+    def weight(self, key, dy, x, flush_fn, allow_tn=True):
         """buffer[S, out, in] += chunked dy^T x"""
-        if gemm_tn_x3_supported(dy, x):      # bf16x3 kernel: accumulates into its own [S, out, in] partials in place
+        if allow_tn and gemm_tn_x3_supported(dy, x):      # bf16x3 kernel: accumulates into its own [S, out, in] partials in place
             S = L.lib().uavgnn_gemm_tn_x3_chunks(x.shape[0], dy.shape[1], x.shape[1])
             key = (key, "tn", S)
             slot = self.slots.get(key)
@@ -735,14 +735,18 @@ class WeightGradSink:
             d_proj, d_gi, d_gh, dq = rows("d_proj"), rows("d_gi"), rows("d_gh"), rows("dq")
             x = seq.x_all[t0 * N:t1 * N]
             h, h2, inp = rows("h"), rows("h", 1), rows("inp")
-            self.weight(("Wp_x", ids["Wp"]), d_proj, x, lambda g: split("Wp", g, 0))
-            self.weight(("Wp_h", ids["Wp"]), d_proj, h, lambda g: split("Wp", g, H))
+            # the vendor's batched split-K fp32 GEMM (64 row chunks): at these shapes - 768-, 96- and 9-row outputs over
+            # 1.67 M rows - it runs at 135-141 TFLOP/s against 85-107 for csrc/gemm_tn_x3.hip (tools/gemm_tn_big_probe.py),
+            # and 25-30 % above its own per-step rate (32 768 rows per call)
+            tn = False
+            self.weight(("Wp_x", ids["Wp"]), d_proj, x, lambda g: split("Wp", g, 0), tn)
+            self.weight(("Wp_h", ids["Wp"]), d_proj, h, lambda g: split("Wp", g, H), tn)
             self.bias(("bp", ids["Wp"]), d_proj, lambda g: split("bp", g, 0))
-            self.weight(("W_ih", ids["W_ih"]), d_gi, inp, lambda g: split("W_ih", g, 0))
+            self.weight(("W_ih", ids["W_ih"]), d_gi, inp, lambda g: split("W_ih", g, 0), tn)
             self.bias(("b_ih", ids["W_ih"]), d_gi, lambda g: split("b_ih", g, 0))
-            self.weight(("W_hh", ids["W_hh"]), d_gh, h, lambda g: split("W_hh", g, 0))
+            self.weight(("W_hh", ids["W_hh"]), d_gh, h, lambda g: split("W_hh", g, 0), tn)
             self.bias(("b_hh_n", ids["W_hh"]), d_gh[:, 2 * H:], lambda g: split("b_hh", g, 2 * H))
-            self.weight(("W_out", ids["W_out"]), dq, h2, lambda g: split("W_out", g, 0))
+            self.weight(("W_out", ids["W_out"]), dq, h2, lambda g: split("W_out", g, 0), tn)
             self.bias(("b_out", ids["W_out"]), dq, lambda g: split("b_out", g, 0))
 
     def flush(self):
