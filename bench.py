@@ -111,30 +111,113 @@ def alg_k1_fwd(E_s, E_n, N, save_s, save_n):
     return b, 3360 * E_s + 2320 * E_n + 7168 * N
 
 
+K1_COUNTERS = os.path.join(ROOT, "profiles", "r04_k1_hetero_counters.json")
+
+
 def measured_traffic(dist_name, n_inf, n_tr, B, n, M):
-    """HBM bytes per fused K1 launch from the committed rocprofv3 PMC passes (profiles/r03_k1_hetero_traffic.json; method
+    """HBM bytes per fused K1 launch from the committed rocprofv3 PMC passes (profiles/r04_k1_hetero_counters.json; method
     and gfx950 correction are documented there), averaged over the inference / training launches of a step like
     ``achieved``.  (None, None) when the workload is not the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r03_k1_hetero_traffic.json")
-    if not os.path.exists(path) or (B, n, M) != (4096, 8, 80):
+    if not os.path.exists(K1_COUNTERS) or (B, n, M) != (4096, 8, 80):
         return None, None
-    t = json.load(open(path)).get(dist_name)
+    t = json.load(open(K1_COUNTERS)).get(dist_name)
     if not t:
         return None, None
     by = {k: (2.0 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0 for k, v in t.items()}
     src = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/k1_run.py on this workload, stamped in "
-           "profiles/r03_k1_hetero_traffic.json (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not "
+           "profiles/r04_k1_hetero_counters.json (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not "
            "collected inside this run")
     return (n_inf * by["inference"] + n_tr * by["training"]) / (n_inf + n_tr), src
 
 
-def cpu_baseline(n, M, dist_name, T_s=2, budget_s=24.0):
-    """The oracle timed on the host cores (SURVEY 8d protocol) on a bounded sample of the same cycle - T_s rollout
-    forwards + one update (2 T_s + 1 forwards + BPTT backward) on B_s env graphs of the SAME degree distribution as the
-    GPU leg: per thread count 2 warm-ups + median of 5 timed cycles, swept over {1, 8, 32, all} host threads (hosts with
-    more than 64 threads: all-thread cycles are replaced by a bounded single-forward probe, see below); ``value`` is the
-    best multi-thread figure (``cores`` = its thread count), the 1-thread figure and the whole sweep are reported next to
-    it.  B_s is calibrated per thread count so that the leg stays within ~budget_s seconds."""
+def pipe_bound(dist_name, avg_launch_ms_rollout, clock_mhz, B, n, M):
+    """What bounds a ROLLOUT launch of K1 on the instruction pipes, from the committed counter passes (SQ_INSTS_MFMA,
+    SQ_INSTS_VALU of one inference launch at C3 size): a SIMD issues a v_mfma_f32_16x16x32_bf16 every ~17 cycles and a VALU
+    instruction every 4 (MI355X_MICROARCH.md, per-instruction constants; DESIGN.md section 5: the two do not overlap inside one
+    wavefront, and two wavefronts share a SIMD), so the issue floor of a launch is max(N_mfma x 17, N_valu x 4) cycles spread
+    over 1024 SIMDs at the SUSTAINED shader clock sampled in this run.  frac_of_pipe_bound = that floor / measured time."""
+    if not os.path.exists(K1_COUNTERS) or (B, n, M) != (4096, 8, 80) or not avg_launch_ms_rollout:
+        return None
+    t = json.load(open(K1_COUNTERS)).get(dist_name, {}).get("inference")
+    if not t or "SQ_INSTS_VALU" not in t:
+        return None
+    clk = (clock_mhz or 2400.0) * 1e6
+    cyc_mfma, cyc_valu = 17.0 * t["SQ_INSTS_MFMA"], 4.0 * t["SQ_INSTS_VALU"]
+    floor_s = max(cyc_mfma, cyc_valu) / (1024.0 * clk)
+    sum_s = (cyc_mfma + cyc_valu) / (1024.0 * clk)
+    N = B * n
+    return {"launch_class": "rollout (inference launch over B n destinations)",
+            "valu_insts_per_launch": t["SQ_INSTS_VALU"], "mfma_insts_per_launch": t["SQ_INSTS_MFMA"],
+            "salu_insts_per_launch": t.get("SQ_INSTS_SALU"), "valu_per_destination": t["SQ_INSTS_VALU"] / N,
+            "salu_per_destination": (t.get("SQ_INSTS_SALU") or 0.0) / N,
+            "clock_mhz_used": clk / 1e6, "clock_source": "sampled in this run" if clock_mhz else "nominal 2400 MHz (no sample)",
+            "issue_floor_us_max_of_pipes": 1e6 * floor_s, "issue_floor_us_sum_of_pipes": 1e6 * sum_s,
+            "measured_us": 1e3 * avg_launch_ms_rollout,
+            "frac_of_pipe_bound": 1e6 * floor_s / (1e3 * avg_launch_ms_rollout),
+            "frac_of_additive_pipe_bound": 1e6 * sum_s / (1e3 * avg_launch_ms_rollout),
+            "counter_source": "profiles/r04_k1_hetero_counters.json (rocprofv3 --pmc passes of tools/k1_run.py, not collected inside this run)"}
+
+
+class ClockSampler:
+    """Shader clock while the timed region runs: a thread reads hwmon's freq1_input (sclk, Hz) of THIS device every 20 ms
+    (sysfs, no subprocess on the launch thread's core).  The box's sysfs lists every GPU of the node; the card is matched by
+    the PCI address PyTorch reports for the device.  None when no card matches."""
+
+    def __init__(self, index=0):
+        import glob
+        import threading
+        self.path = None
+        try:
+            pr = th.cuda.get_device_properties(index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+                if os.path.basename(os.path.realpath(os.path.join(card, "device"))) == want:
+                    f = sorted(glob.glob(os.path.join(card, "device", "hwmon", "hwmon*", "freq1_input")))
+                    self.path = f[0] if f else None
+        except Exception:   # noqa: BLE001 - an optional diagnostic never breaks the bench
+            self.path = None
+        self.samples, self._stop, self._thr, self._threading = [], False, None, threading
+
+    def _read(self):
+        try:
+            return float(open(self.path).read().strip()) / 1e6
+        except Exception:   # noqa: BLE001
+            return None
+
+    def __enter__(self):
+        if self.path is not None:
+            def loop():
+                while not self._stop:
+                    v = self._read()
+                    if v:
+                        self.samples.append(v)
+                    time.sleep(0.02)
+            self._thr = self._threading.Thread(target=loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thr is not None:
+            self._thr.join(timeout=1.0)
+        return False
+
+    def summary(self):
+        if not self.samples:
+            return None
+        s = sorted(self.samples)
+        return {"mean_mhz": sum(s) / len(s), "min_mhz": s[0], "max_mhz": s[-1], "samples": len(s),
+                "source": self.path + " (sclk of this device, 20 ms period, timed region only)"}
+
+
+def cpu_baseline(n, M, dist_name, T_s=2, B_fixed=64):
+    """The oracle timed on the host cores (SURVEY 8d protocol) on a bounded, FIXED sample of the same cycle - T_s rollout
+    forwards + one update (2 T_s + 1 forwards + BPTT backward) on B_fixed = 64 env graphs of the SAME degree distribution as
+    the GPU leg, the same sample every round (rounds 1-3 calibrated the sample size per run: 512 / 128 / 64 graphs, and the
+    figure moved by +-30 %): per thread count 2 warm-ups + median of 5 timed cycles (3 at one thread), threads in {1, 8, 32}
+    (hosts with more than 64 threads additionally get a bounded single-forward probe at all threads, see below); ``value`` is
+    the best multi-thread figure (``cores`` = its thread count), the 1-thread figure and the whole sweep are reported next
+    to it."""
     import statistics
 
     from oracle import restatement as R
@@ -184,8 +267,7 @@ def cpu_baseline(n, M, dist_name, T_s=2, budget_s=24.0):
         cycle()
         return time.perf_counter() - t0
 
-    counts = sorted({c for c in (1, 8, 32, ncpu if ncpu <= 64 else 32) if c <= ncpu})
-    per_count_budget = budget_s / len(counts)
+    counts = sorted({c for c in (1, 8, 32) if c <= ncpu})
     sweep = {}
     all_core_probe = None
     if ncpu > 64:
@@ -210,18 +292,11 @@ def cpu_baseline(n, M, dist_name, T_s=2, budget_s=24.0):
                               slowdown_vs_32_threads=t_all / max(t_32, 1e-9))
     for threads in counts:
         th.set_num_threads(threads)
-        t_start = time.perf_counter()
-        B_s = 2
+        B_s = B_fixed
         c = make(B_s)
         timed(c)                                            # warm-up 1 (thread pool, allocator)
-        dt = timed(c)                                       # warm-up 2, doubles as the calibration probe
-        # grow the sample while 2 warm-ups + 5 timed cycles at twice the size still fit into this thread count's share
-        while B_s < 512 and 2.0 * dt * 7.5 < per_count_budget - (time.perf_counter() - t_start):
-            B_s *= 2
-            c = make(B_s)
-            timed(c)
-            dt = timed(c)
-        ts = [timed(c) for _ in range(5)]
+        timed(c)                                            # warm-up 2
+        ts = [timed(c) for _ in range(3 if threads == 1 else 5)]
         med = statistics.median(ts)
         sweep[str(threads)] = dict(env_steps_per_s=B_s * T_s / med, sec_per_cycle_median=med, env_graphs=B_s,
                                    sec_min=min(ts), sec_max=max(ts))
@@ -230,7 +305,8 @@ def cpu_baseline(n, M, dist_name, T_s=2, budget_s=24.0):
     return dict(value=sweep[best]["env_steps_per_s"], unit="env-steps/s", cores=int(best), kind="port",
                 host_threads_available=ncpu, one_thread=sweep["1"]["env_steps_per_s"], thread_sweep=sweep,
                 all_core_probe=all_core_probe,
-                protocol="per thread count: 2 warm-up cycles, median of 5 timed cycles; value = best multi-thread count",
+                protocol=f"fixed sample of {B_fixed} env graphs; per thread count in {{1, 8, 32}}: 2 warm-up cycles, median of 5 "
+                         "timed cycles (3 at one thread); value = best multi-thread count",
                 torch_parallel_info=th.__config__.parallel_info().split("\n")[0],
                 sample=f"oracle/restatement.py (PyTorch CPU fp32): cycles of {T_s} rollout forwards + 1 update "
                        f"({2 * T_s + 1} forwards + BPTT backward) on {sweep[best]['env_graphs']} env graphs of {n}x{M}, "
@@ -339,6 +415,63 @@ def end_to_end(learner, a, device, mode="random", cycles=2):
                 mean_gt_visibility=seen, mean_d_seen=seen * M, mean_gt_served=served)
 
 
+def k1_roofline(k, a, dist_name, clock_mhz):
+    """``roofline`` object of the fused K1 forward from the HIP-event spans `k` of a timed region (every launch of it:
+    rollout launches over N_a destinations, the two time-batched encoder launches of an update over (T+1) N_a / T N_a
+    destinations): achieved = sum(algorithmic bytes or flops) / sum(event durations)."""
+    work = [(Es, En, N, ss, sn) for (Es, En, N, ss, sn) in k["work"]]
+    tot_b = sum(alg_k1_fwd(*w)[0] for w in work)
+    tot_f = sum(alg_k1_fwd(*w)[1] for w in work)
+    sec = k["total_ms"] * 1e-3
+    ach = tot_b / sec / 1e9
+    by_class = {}
+    for cls, sel in (("rollout", lambda N: N <= a.B * a.n), ("update_time_batched", lambda N: N > a.B * a.n)):
+        ms_c = [m for m, w in zip(k["ms"], work) if sel(w[2])]
+        by_c = [alg_k1_fwd(*w)[0] for w in work if sel(w[2])]
+        fl_c = [alg_k1_fwd(*w)[1] for w in work if sel(w[2])]
+        if ms_c:
+            g = sum(by_c) / (sum(ms_c) * 1e-3) / 1e9
+            tf = sum(fl_c) / (sum(ms_c) * 1e-3) / 1e12
+            by_class[cls] = {"launches": len(ms_c), "avg_launch_ms": sum(ms_c) / len(ms_c), "achieved": g,
+                             "frac": g / HBM_PEAK_GBS, "hbm_frac": g / HBM_PEAK_GBS, "tflops": tf,
+                             "mfma_fp32_frac": tf / FP32_PEAK_TFLOPS}
+    n_units = sum(w[2] for w in work) / (a.B * a.n)                # launches in units of one env-step batch
+    n_tr = sum(w[2] for w in work if w[3]) / (a.B * a.n)
+    traffic, traffic_src = measured_traffic(dist_name, n_units - n_tr, n_tr, a.B, a.n, a.M)
+    tfl = tot_f / sec / 1e12
+    # The roof that binds is the lower one at this launch mix's arithmetic intensity (classic roofline):
+    # AI = algorithmic FLOP / algorithmic byte vs the machine balance fp32-MFMA peak / HBM peak (~19.7 FLOP/B).
+    ai = tot_f / max(tot_b, 1)
+    balance = FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    hbm = {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    mfma = {"achieved": tfl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP32_PEAK_TFLOPS}
+    bound = "mfma" if ai > balance else "hbm"
+    top = mfma if bound == "mfma" else hbm
+    return {"bound": bound,
+            "kernel": "gatv2_hetero_fwd_kernel (K1 forward, `seen` + `near` relations in one launch)",
+            "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+            "frac": top["frac"],
+            "traffic": None if traffic is None else traffic * n_units / k["count"],
+            "traffic_source": traffic_src,
+            "arithmetic_intensity": ai, "machine_balance": balance,
+            "hbm": hbm, "mfma_fp32": mfma,
+            "avg_launch_ms": k["avg_ms"], "launches": k["count"],
+            "alg_bytes_per_launch": tot_b / k["count"], "alg_flops_per_launch": tot_f / k["count"],
+            "ms_per_env_step_batch": k["total_ms"] / n_units,
+            "by_launch_class": by_class,
+            "pipe_bound": pipe_bound(dist_name, by_class.get("rollout", {}).get("avg_launch_ms"), clock_mhz, a.B, a.n, a.M),
+            "note": ("D-dense: AI ~ 86 FLOP/B (SURVEY 8d) is 4x the machine balance, so the roof SURVEY 8d prices the kernel against "
+                     "is the fp32 MFMA / vector peak (157.3 TF); even there it could move only ~23 % of the HBM peak.  `frac` is "
+                     "that throughput ratio and NOT a bound the kernel lives under: the score GEMM (2048 of the 3360 FLOP per "
+                     "`seen` edge) and the epilogue products of `near` run on the bf16 matrix cores as six exact bf16 products per "
+                     "fp32 product.  What does bound a launch is instruction issue - `pipe_bound` (counter passes + the clock "
+                     "sampled in this run)"
+                     if bound == "mfma" else
+                     "D-env (94 % of agents see no GT): AI below the machine balance, the launch mix is bound by HBM "
+                     "(output-row writes: 2 KB per agent, 67 MB per rollout launch; a pure streaming write of them runs at "
+                     "5.2-6.2 TB/s on this part, profiles/r04_k1_standalone.txt)")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,6 +488,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (smoke test)")
     ap.add_argument("--rho", type=int, default=32, help="replay ratio of the extra `replay_ratio_leg` (headline: 1)")
     ap.add_argument("--no-rho-leg", action="store_true", help="skip the replay-ratio leg (one cycle with rho chunks per update)")
+    ap.add_argument("--no-env-leg", action="store_true", help="skip the short D-env leg (`roofline_env`: the HBM-bound regime of K1)")
+    ap.add_argument("--env-steps", type=int, default=5, help="timed steps of the D-env leg")
     ap.add_argument("--no-fp32-leg", action="store_true",
                     help="skip the second timing with the bf16x3 kernels off (fp32-MFMA GRU cell, vendor fp32 GEMMs)")
     a = ap.parse_args()
@@ -419,16 +554,23 @@ def main():
     gc.collect()
     gc.disable()
     ops.KERNEL_TIMER.reset(enabled=True, only=GRADED)
-    t0 = time.perf_counter()
-    marks = []
-    for _ in range(a.steps):
-        out = step()
-        ev = th.cuda.Event(enable_timing=True)
-        ev.record()
-        marks.append(ev)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    learner.grads.collective_events = []            # HIP events around the one collective of an update (when there is one)
+    clock = ClockSampler(local)
+    with clock:
+        t0 = time.perf_counter()
+        marks = []
+        for _ in range(a.steps):
+            out = step()
+            ev = th.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
+        barrier()
+        elapsed = time.perf_counter() - t0
     ktimes = ops.KERNEL_TIMER.summary()
+    coll_ms = [e0.elapsed_time(e1) for e0, e1 in learner.grads.collective_events]
+    learner.grads.collective_events = None
+    clock_info = clock.summary()
+    clock_mhz = clock_info["mean_mhz"] if clock_info else None
     ops.KERNEL_TIMER.reset(enabled=True)              # every span: one more cycle, on every rank (the update holds a collective)
     t_i = time.perf_counter()
     step()
@@ -463,60 +605,20 @@ def main():
                        "global_batch": world * a.B, "seq_len": a.T, "parallelism": f"dp{world}",
                        **({} if backend == "nccl" else {"collective_backend": backend + " (test hook, not RCCL)"})},
             "loss": loss,
+            "tuned_gemms": bool(tuned),        # recorded vendor-GEMM solutions (uav_bs_ctrl_amd/tuned/gemm_gfx950.csv) accepted by this box's hipBLASLt
+            "shader_clock": clock_info,        # sustained clock of the timed region (the part runs at its power limit: DESIGN.md section 6)
+            "rccl_ranks": (dist.get_world_size() if use_dist else 1),
+            "collective_ms": (None if not coll_ms else {"per_update_mean": sum(coll_ms) / len(coll_ms), "max": max(coll_ms),
+                                                        "calls": len(coll_ms), "bytes": 4 * learner.grads.flat.numel(),
+                                                        "what": "all-reduce (sum) of the flat fp32 gradient buffer + the 1/G scaling, "
+                                                                "HIP events on the compute stream"}),
             "params_checksum": [float(ck[0]), float(ck[1])],   # sum / sum of squares of the policy parameters after the timed steps
             "step_ms_device": [round(marks[i - 1].elapsed_time(marks[i]), 1) for i in range(1, len(marks))],
         }
         # ---- roofline of the dominant message-passing kernel: K1 forward, BOTH relations (one fused launch) ----------
         k = ktimes.get("gatv2_hetero_fwd")
         if k:
-            # every K1 launch of the timed region (rollout launches over N_a destinations, the two time-batched encoder
-            # launches of the update over (T+1) N_a / T N_a): achieved = sum(bytes) / sum(time)
-            work = [(Es, En, N, ss, sn) for (Es, En, N, ss, sn) in k["work"]]
-            tot_b = sum(alg_k1_fwd(*w)[0] for w in work)
-            tot_f = sum(alg_k1_fwd(*w)[1] for w in work)
-            sec = k["total_ms"] * 1e-3
-            ach = tot_b / sec / 1e9
-            by_class = {}
-            for cls, sel in (("rollout", lambda N: N <= a.B * a.n), ("update_time_batched", lambda N: N > a.B * a.n)):
-                ms_c = [m for m, w in zip(k["ms"], work) if sel(w[2])]
-                by_c = [alg_k1_fwd(*w)[0] for w in work if sel(w[2])]
-                fl_c = [alg_k1_fwd(*w)[1] for w in work if sel(w[2])]
-                if ms_c:
-                    g = sum(by_c) / (sum(ms_c) * 1e-3) / 1e9
-                    tf = sum(fl_c) / (sum(ms_c) * 1e-3) / 1e12
-                    by_class[cls] = {"launches": len(ms_c), "avg_launch_ms": sum(ms_c) / len(ms_c), "achieved": g,
-                                     "frac": g / HBM_PEAK_GBS, "hbm_frac": g / HBM_PEAK_GBS, "tflops": tf,
-                                     "mfma_fp32_frac": tf / FP32_PEAK_TFLOPS}
-            n_units = sum(w[2] for w in work) / (a.B * a.n)                # launches in units of one env-step batch
-            n_tr = sum(w[2] for w in work if w[3]) / (a.B * a.n)
-            traffic, traffic_src = measured_traffic(a.dist, n_units - n_tr, n_tr, a.B, a.n, a.M)
-            tfl = tot_f / sec / 1e12
-            # The roof that binds is the lower one at this launch mix's arithmetic intensity (classic roofline):
-            # AI = algorithmic FLOP / algorithmic byte vs the machine balance fp32-MFMA peak / HBM peak (~19.7 FLOP/B).
-            ai = tot_f / max(tot_b, 1)
-            balance = FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-            hbm = {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-            mfma = {"achieved": tfl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP32_PEAK_TFLOPS}
-            bound = "mfma" if ai > balance else "hbm"
-            top = mfma if bound == "mfma" else hbm
-            res["roofline"] = {"bound": bound,
-                               "kernel": "gatv2_hetero_fwd_kernel (K1 forward, `seen` + `near` relations in one launch)",
-                               "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
-                               "frac": top["frac"],
-                               "traffic": None if traffic is None else traffic * n_units / k["count"],
-                               "traffic_source": traffic_src,
-                               "arithmetic_intensity": ai, "machine_balance": balance,
-                               "hbm": hbm, "mfma_fp32": mfma,
-                               "avg_launch_ms": k["avg_ms"], "launches": k["count"],
-                               "alg_bytes_per_launch": tot_b / k["count"], "alg_flops_per_launch": tot_f / k["count"],
-                               "ms_per_env_step_batch": k["total_ms"] / n_units,
-                               "by_launch_class": by_class,
-                               "note": ("D-dense: AI ~ 86 FLOP/B (SURVEY 8d) is 4x the machine balance, so the fp32 MFMA "
-                                        "peak is the binding roof (fp32 MFMA issues at the fp32 vector rate on gfx950); "
-                                        "even at that peak the kernel could move only ~23 % of the HBM peak"
-                                        if bound == "mfma" else
-                                        "D-env (94 % of agents see no GT): AI below the machine balance, the launch mix is "
-                                        "bound by HBM (output-row writes)")}
+            res["roofline"] = k1_roofline(k, a, a.dist, clock_mhz)
         # ---- the GEMM-shaped kernels by time share (the GRU cell is the largest kernel of a dense cycle): MFMA roofs ----------
         sec = []
         kc = kfull.get("gru_cell_fwd")
@@ -557,6 +659,7 @@ def main():
                              "profiles/r03_gemm_tn_probe.txt).  `fp32_mfma_leg` is the same cycle with all of them switched to fp32 "
                              "MFMA / vendor fp32 GEMMs (UAVGNN_GRU_X3=0 UAVGNN_GEMM_X3=0 UAVGNN_K1_BF16Z=0).")
         if world == 1 and not a.no_fp32_leg:
+            saved_flags = (ops.GRU_X3, ops.GEMM_X3, ops.K1_BF16Z)     # a run started with UAVGNN_*=0 keeps its own setting afterwards
             ops.GRU_X3 = ops.GEMM_X3 = ops.K1_BF16Z = False
             try:
                 step()
@@ -575,7 +678,44 @@ def main():
                                                   "(csrc/gru_fused.hip), every dense layer on the vendor fp32 GEMM, K1's score GEMM "
                                                   "on fp32 MFMA (csrc/gatv2_hetero_f32.hip): no bf16 instruction anywhere"}
             finally:
-                ops.GRU_X3 = ops.GEMM_X3 = ops.K1_BF16Z = True
+                ops.GRU_X3, ops.GEMM_X3, ops.K1_BF16Z = saved_flags
+        if world == 1 and a.dist == "dense" and not a.no_env_leg:
+            # ---- the HBM-bound regime of the graded kernel inside the default run: the same cycle on D-env degrees (94 % of the
+            # agents see no GT - a random-policy rollout), a few steps, K1 forward timed live the same way
+            env_batch = make_sequence(a.B, a.n, a.M, a.T, "env", device, seed=4321, distinct=a.distinct)
+
+            def step_env():
+                obs = [g.fresh() for g in env_batch["obs"]]
+                fb = dict(env_batch, obs=obs, obs_all=env_batch["obs_all"].fresh(), obs_all_next=env_batch["obs_all_next"].fresh())
+                h = learner.init_hidden(a.B)
+                for t in range(a.T):
+                    _, h = learner.act(obs[t].fresh(), h, 0.05)
+                return learner.update(fb)
+            ops.KERNEL_TIMER.reset(enabled=True, only=GRADED)
+            step_env()
+            th.cuda.synchronize()
+            gc.collect()
+            gc.disable()
+            ops.KERNEL_TIMER.reset(enabled=True, only=GRADED)
+            clock_e = ClockSampler(local)
+            with clock_e:
+                t1 = time.perf_counter()
+                for _ in range(a.env_steps):
+                    step_env()
+                th.cuda.synchronize()
+                e1 = time.perf_counter() - t1
+            gc.enable()
+            ke = ops.KERNEL_TIMER.summary().get("gatv2_hetero_fwd")
+            ops.KERNEL_TIMER.enabled = False
+            ce = clock_e.summary()
+            if ke:
+                r_env = k1_roofline(ke, a, "env", ce["mean_mhz"] if ce else None)
+                r_env.update({"steps": a.env_steps, "ms_per_step": 1e3 * e1 / a.env_steps,
+                              "env_steps_per_s": a.B * a.T * a.env_steps / e1, "shader_clock": ce,
+                              "workload": f"the same cycle on D-env degrees (B={a.B}, {a.n} x {a.M}): {a.env_steps} timed steps after "
+                                          "one warm-up, K1 forward between HIP events as in the timed region"})
+                res["roofline_env"] = r_env
+            del env_batch
         if world == 1 and not a.no_rho_leg:
             # the reference's own replay ratio (run.py:55-57,:97: 32 stored sequences per T steps of one environment):
             # T act forwards on B environments + ONE optimizer step over rho chunks of B sequences (gradient accumulation)

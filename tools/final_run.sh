@@ -11,7 +11,7 @@ python bench.py --dist env > gpurun_out/${R}_final_bench_env.json 2> gpurun_out/
 python tools/kbench_hetero.py > gpurun_out/${R}_final_kbench_hetero.txt 2>&1
 python tools/kbench.py > gpurun_out/${R}_final_kbench.txt 2>&1
 for d in env zero dense; do tools/ubench/bin/k1_env_bench $d 4096 50; done > gpurun_out/${R}_final_k1_standalone.txt 2>&1
-cd /tmp && export TMPDIR=/tmp && rm -rf /root/repo/gpurun_out/prof_bench && rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_bench -o bench -- python /root/repo/bench.py --steps 2 --warmup 1 --no-end-to-end --no-cpu-baseline --no-fp32-leg --no-rho-leg > /root/repo/gpurun_out/prof_bench_stdout.txt 2>&1
+cd /tmp && export TMPDIR=/tmp && rm -rf /root/repo/gpurun_out/prof_bench && rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_bench -o bench -- python /root/repo/bench.py --steps 2 --warmup 1 --no-end-to-end --no-cpu-baseline --no-fp32-leg --no-rho-leg --no-env-leg > /root/repo/gpurun_out/prof_bench_stdout.txt 2>&1
 cd /root/repo; db=$(find gpurun_out/prof_bench -name "*results.db" | head -1)
 python tools/rocprof_summary.py $db > gpurun_out/${R}_final_bench_kernel_stats.txt 2>&1
 python tools/rocprof_by_grid.py $db > gpurun_out/${R}_final_bench_by_grid.txt 2>&1

@@ -46,6 +46,7 @@ class FlatGradBuffer:
         dev = self.params[0].device
         self.flat = th.zeros(numel, dtype=th.float32, device=dev)
         self.force_collective = False   # run the collective even at world size 1 (RCCL smoke test / bench --force-dist)
+        self.collective_events = None   # a list: all_reduce_mean_ appends a HIP event pair per call (bench.py `collective_ms`)
         for p, o in zip(self.params, self.offsets):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
 
@@ -57,9 +58,16 @@ class FlatGradBuffer:
 
     def all_reduce_mean_(self, group=None):
         if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.force_collective):
+            timed = self.collective_events is not None and self.flat.is_cuda
+            if timed:      # HIP events around the ONE collective of the data path (bench.py: `collective_ms`)
+                e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             if dist.get_world_size(group) > 1:
                 self.flat.div_(dist.get_world_size(group))
+            if timed:
+                e1.record()
+                self.collective_events.append((e0, e1))
 
 
 def broadcast_parameters(module: th.nn.Module, src: int = 0, group=None, force: bool = False) -> None:
