@@ -360,7 +360,6 @@ def end_to_end(learner, a, device, mode="random", cycles=2):
             ubs = th.randint(0, 30, (B, n, 2), device=device, generator=gen).double() * grid
         return ubs.clamp(0, mp.range_pos), gts.clamp(0, mp.range_pos).float()
 
-    zero_done = th.zeros(B, 1, device=device)
 
     vis = []
 
@@ -378,10 +377,12 @@ def end_to_end(learner, a, device, mode="random", cycles=2):
                 acts, h2 = learner.act(g, h, eps)
             if mode == "hotspot":
                 acts = th.zeros_like(acts)        # hover: the UBSs stay on the hotspot
-            o, rew, done, _ = env.step(acts)      # overwrites the observation buffers in place: they are in the replay already
+            o, rew, done, info = env.step(acts)   # overwrites the observation buffers in place: they are in the replay already
             vis.append(o["gt"][..., 0].mean())
-            rb.push(dict(act=acts.view(B, n), rew=rew.float(), done=zero_done, next_gt=o["gt"], next_ubs=o["ubs"],
-                         next_agent=o["agent"], next_d_u2u=o["d_u2u"], next_h=h2.view(B, n, -1)))
+            # learner.cache (learner.py:82-92): done muted by the time-limit mask, next_h zeroed by the raw done flag; the
+            # observation half of the transition was staged before the step, so only the next_* fields travel here
+            learner.cache(rb, {}, h, None, acts, rew.float(), dict(gt=o["gt"], ubs=o["ubs"], agent=o["agent"], d_u2u=o["d_u2u"]),
+                          h2, None, done, info["BadMask"], staged=True)
             h = h2
         m = rb.mem                                              # all B sequences, time-major padded tensors
         tm = {k: m[k].transpose(0, 1).contiguous() for k in ("gt", "ubs", "agent", "d_u2u")}

@@ -316,7 +316,6 @@ int uavgnn_gru_cell_fwd(const float* inp, int ld_inp, int K_in, const float* h, 
  * uavgnn_gru_cell_fwd with `planes` in place of the two weight matrices; 4 N max(ld_inp, H) must stay below 2^32 (32-bit byte
  * offsets inside the kernel: 3.3 M rows at K_in = 320), UAVGNN_EUNSUPPORTED otherwise. */
 int uavgnn_gru_cell_x3_supported(int K_in, int H);   /* K_in % 32 == 0 and H % 64 == 0 */
-void uavgnn_gru_x3_set_variant(int interleave);      /* A/B of tools/gru_probe.py: 1 (default) = staging interleaved with the MFMAs, 0 = staging as a block in front of them (bit-identical results) */
 long long uavgnn_gru_cell_x3_workspace_bytes(int K_in, int H);
 int uavgnn_gru_split_weights(const float* W_ih, int K_in, const float* W_hh, int H, void* planes, uavgnn_stream_t stream);
 int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, const float* h, int N, int H, const void* planes,
@@ -327,6 +326,13 @@ int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, const float* 
 int uavgnn_gru_cell_fwd_x3_cat(const float* inp, int ld_inp, int K1, const float* inp2, int ld_inp2, int K2, const float* h,
                                int N, int H, const void* planes, const float* b_ih, const float* b_hh, float* h_out,
                                float* pre_save, uavgnn_stream_t stream);
+/* ... with a per-call variant word (0 = uavgnn_gru_cell_fwd_x3_cat).  UAVGNN_GRU_STAGING_BLOCKS: the staging of a K slice as a
+ * block in front of / behind its first MFMA group (the round-2 schedule; the A/B reference of tools/gru_probe.py) instead of
+ * interleaved with it - bit-identical results.  A call argument, not process state: the library keeps no mutable globals. */
+#define UAVGNN_GRU_STAGING_BLOCKS 1
+int uavgnn_gru_cell_fwd_x3_opts(const float* inp, int ld_inp, int K1, const float* inp2, int ld_inp2, int K2, const float* h,
+                                int N, int H, const void* planes, const float* b_ih, const float* b_hh, float* h_out,
+                                float* pre_save, int flags, uavgnn_stream_t stream);
 /* Dense layers on the bf16 matrix cores (csrc/gemm_x3.hip; reference: the nn.Linear layers of
  * algos/madrqn/agents/gnn_agents.py - f_aggr :101-102, :106, TarMAC projections :227-236 - and the input-gradient GEMMs of
  * loss.backward(), learner.py:157): Y[M, N] = X[M, K] B[N, K]^T (+ bias[N]) (+ Y) (then ReLU), fp32 in / out, each fp32 product
@@ -335,8 +341,13 @@ int uavgnn_gru_cell_fwd_x3_cat(const float* inp, int ld_inp, int K1, const float
  * 6 R C bytes, 16-byte aligned.  K % 32 == 0, ldx % 4 == 0, X 16-byte aligned; M, N arbitrary. */
 #define UAVGNN_GEMM_ACCUMULATE 1
 #define UAVGNN_GEMM_RELU 2
+/* kernel variants, selected per call by further bits of `epilogue` (A/B references of tools/gemm_x3_probe.py; same results bit
+ * for bit): default = 256 x 128 tiles, eight waves, double-buffered LDS, staging of a slice as a block;
+ * STAGING_INTERLEAVED = the same with the staging interleaved with the MFMAs (faster per launch, not per power-limited cycle);
+ * TILE_128 = 128 x 128 tiles, four waves */
+#define UAVGNN_GEMM_STAGING_INTERLEAVED 4
+#define UAVGNN_GEMM_TILE_128 8
 int uavgnn_gemm_x3_supported(int M, int N, int K);
-void uavgnn_gemm_x3_set_variant(int variant);   /* A/B of tools/gemm_x3_probe.py: 8 (default) = 256 x 128 tiles, eight waves, double-buffered LDS; 9 = the same with the staging interleaved with the MFMAs (faster per launch, not per power-limited cycle); 4 = 128 x 128 tiles, four waves */
 int uavgnn_split_bf16x3(const float* W, int ld, int R, int C, int transpose, void* planes, uavgnn_stream_t stream);
 int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const void* planes, int N, const float* bias, float* Y, int ldy,
                       int epilogue, uavgnn_stream_t stream);
@@ -352,6 +363,32 @@ int uavgnn_gemm_tn_x3(const float* dY, int ldy, int Mo, const float* X, int ldx,
                       int S, int accumulate, uavgnn_stream_t stream);
 int uavgnn_gru_gates_bwd_fused(const float* pre, const float* h, const float* d_hout, int N, int H, float* d_gi, float* d_gh,
                                float* d_h, uavgnn_stream_t stream);
+
+/* Backward of the fused GRU cell as ONE call (csrc/gru_bwd.hip; reference: autograd of nn.GRUCell at gnn_agents.py:246,:270
+ * under learner.py:157): gate gradients from the pre-activation sets saved by the forward (pre [N, 4H]), d_inp [N, K_in]
+ * (leading dimension ld_dinp) = d_gi W_ih, d_h [N, H] = d_hout * z + d_gh W_hh, both GEMMs on the bf16x3 arithmetic.
+ * d_gi / d_gh [N, 3H] are OUTPUTS kept for the caller: the weight / bias gradients (dW_ih = d_gi^T inp, dW_hh = d_gh^T h, db_ih =
+ * colsum d_gi, db_hh = [colsum d_gi[:, :2H] | colsum d_gh[:, 2H:]]) are sums over agents AND time steps, which a BPTT caller
+ * forms once per sequence (uavgnn_gemm_tn_x3 / uavgnn_colsum_acc over the stacked operands).  planes_bwd: bf16 planes of
+ * W_ih^T then W_hh^T written by uavgnn_gru_split_weights_bwd (uavgnn_gru_cell_bwd_workspace_bytes bytes, 16-byte aligned);
+ * 3H % 32 == 0, pre / d_gi / d_gh / d_inp 16-byte aligned, ld_dinp % 4 == 0. */
+long long uavgnn_gru_cell_bwd_workspace_bytes(int K_in, int H);
+int uavgnn_gru_split_weights_bwd(const float* W_ih, int K_in, const float* W_hh, int H, void* planes, uavgnn_stream_t stream);
+int uavgnn_gru_cell_bwd(const float* pre, const float* h, const float* d_hout, int N, int K_in, int H, const void* planes_bwd,
+                        float* d_gi, float* d_gh, float* d_inp, int ld_dinp, float* d_h, uavgnn_stream_t stream);
+
+/* ONE query for every caller-provided scratch / plane buffer (bytes; 0 = unknown kind or bad sizes).  Arguments per kind:
+ *   GATV2_BWD (F_src, H)            partial rows of uavgnn_gatv2_bwd          DEGREE_ORDER (N)   CSC_TRANSPOSE (N)
+ *   GRU_PLANES (K_in, H)            uavgnn_gru_split_weights                  GRU_BWD_PLANES (K_in, H)  uavgnn_gru_split_weights_bwd
+ *   GEMM_PLANES (R, C)              uavgnn_split_bf16x3                       GEMM_TN_PARTIALS (n_rows, Mo, Ko)  uavgnn_gemm_tn_x3 */
+#define UAVGNN_WS_GATV2_BWD 1
+#define UAVGNN_WS_DEGREE_ORDER 2
+#define UAVGNN_WS_CSC_TRANSPOSE 3
+#define UAVGNN_WS_GRU_PLANES 4
+#define UAVGNN_WS_GRU_BWD_PLANES 5
+#define UAVGNN_WS_GEMM_PLANES 6
+#define UAVGNN_WS_GEMM_TN_PARTIALS 7
+long long uavgnn_workspace_bytes(int kind, long long a, long long b, long long c);
 
 #ifdef __cplusplus
 }

@@ -1709,6 +1709,55 @@ def test_gemm_bf16x3_operand_range(ea, eb):
     assert bool((err <= 6e-7 * scale + tiny)[sure].all()), float((err / (6e-7 * scale + tiny))[sure].max())
 
 
+@pytest.mark.gpu
+def test_bf16x3_non_finite_and_near_overflow_operands_follow_the_documented_contract():
+    """VERDICT r3 item 7.  The three-way split forms x - bf16(x): an Inf operand gives Inf - Inf = NaN where an fp32 GEMM gives
+    Inf, and a FINITE |x| >= 0x7F7F8000 (within half a bf16 ulp of FLT_MAX: 3.3895e38) rounds its first term to Inf.  The
+    contract (behavioural differences): a non-finite or near-overflow operand makes the outputs that depend
+    on it NON-FINITE (NaN where fp32 may say Inf) and touches nothing else - every other output row / column carries the bits
+    of the clean run; the largest operand that is still exact is 0x7F7F7FFF."""
+    import struct
+    from uav_bs_ctrl_amd import ops
+    f = lambda bits: struct.unpack("f", struct.pack("I", bits))[0]   # noqa: E731
+    M, N, K = 4096, 256, 320
+    gen = th.Generator().manual_seed(5)
+    a = th.randn(M, K, generator=gen).cuda()
+    W = (0.05 * th.randn(N, K, generator=gen)).cuda()
+    clean = ops.gemm_x3(a, W, False)
+    bad = a.clone()
+    bad[7, 3], bad[100, 0], bad[2000, 319] = float("inf"), float("nan"), f(0x7F7F8000)
+    bad[3000, 5] = f(0x7F7F7FFF) * 2.0 ** -120           # ordinary value: a control row that stays clean
+    out = ops.gemm_x3(bad, W, False)
+    rows = th.tensor([7, 100, 2000], device="cuda")
+    for r in (7, 100, 2000):
+        assert not bool(th.isfinite(out[r]).all()), r
+    keep = th.ones(M, dtype=th.bool, device="cuda")
+    keep[rows] = False
+    keep[3000] = False
+    assert th.equal(out[keep], clean[keep])               # nothing leaks into other rows
+    assert bool(th.isfinite(out[3000]).all())
+    # the largest exactly representable operand: 0x7F7F7FFF splits into finite terms (products kept small by the weights)
+    big = th.zeros(M, K, device="cuda")
+    big[:, 0] = f(0x7F7F7FFF)
+    Wt = th.zeros(N, K, device="cuda")
+    Wt[:, 0] = 2.0 ** -10
+    ob = ops.gemm_x3(big, Wt, False)
+    assert bool(th.isfinite(ob).all())
+    assert float((ob.double() - float(f(0x7F7F7FFF)) * 2.0 ** -10).abs().max()) <= 1e-6 * f(0x7F7F7FFF) * 2.0 ** -10
+    # GRU cell: a non-finite input row gives a non-finite h' row and leaves the other agents alone
+    cell = th.nn.GRUCell(K, 256).cuda()
+    inp, h = th.randn(M, K, device="cuda"), th.randn(M, 256, device="cuda")
+    with th.no_grad():
+        y0 = ops.gru_cell(inp, h, cell)
+        inp2 = inp.clone()
+        inp2[11, 17] = float("inf")
+        y1 = ops.gru_cell(inp2, h, cell)
+    assert not bool(th.isfinite(y1[11]).all())
+    m = th.ones(M, dtype=th.bool, device="cuda")
+    m[11] = False
+    assert th.equal(y1[m], y0[m])
+
+
 def test_fused_gru_cell_operand_range():
     """K4 on the bf16 matrix cores with activations at the ends of the range: hidden state / input of magnitude 2^-115
     (their low split terms underflow bf16: they contribute < 2^-126 to a pre-activation of O(0.1)) and of magnitude 2^12
@@ -1956,3 +2005,40 @@ def test_plane_cache_never_serves_a_recycled_weight_address():
     g0, g1 = grads(False), grads(True)
     assert float(g0.abs().max()) > 0
     assert th.equal(g0, g1)
+
+
+@pytest.mark.gpu
+def test_gru_cell_backward_as_one_c_abi_call_equals_the_host_sequence():
+    """uavgnn_gru_cell_bwd ("uavgnn_gru_cell_{fwd,bwd}"): gate gradients + d_inp = d_gi W_ih + d_h += d_gh W_hh in
+    ONE C-ABI call equal what ops issues as three calls, and the gradients of nn.GRUCell in float64 (1e-5); the single
+    workspace query agrees with the per-kernel queries."""
+    from uav_bs_ctrl_amd import _lib as L, ops
+    th.manual_seed(21)
+    N, K, H = 4096 + 40, 320, 256          # not a multiple of the tiles
+    cell = th.nn.GRUCell(K, H).cuda()
+    inp, h = th.randn(N, K, device="cuda"), 0.5 * th.randn(N, H, device="cuda")
+    d_hout = th.randn(N, H, device="cuda")
+    lib = L.lib()
+    with th.no_grad():
+        h2, pre = ops._gru_cell_launch(inp, h, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, save=True)
+    nbytes = lib.uavgnn_gru_cell_bwd_workspace_bytes(K, H)
+    assert nbytes == lib.uavgnn_workspace_bytes(5, K, H, 0) == 6 * 3 * H * (K + H)
+    assert lib.uavgnn_workspace_bytes(4, K, H, 0) == lib.uavgnn_gru_cell_x3_workspace_bytes(K, H)
+    assert lib.uavgnn_workspace_bytes(1, 4, 256, 0) == lib.uavgnn_gatv2_bwd_workspace_bytes(4, 256)
+    assert lib.uavgnn_workspace_bytes(99, 1, 1, 1) == 0
+    planes = th.empty(nbytes, dtype=th.uint8, device="cuda")
+    L.check(lib.uavgnn_gru_split_weights_bwd(cell.weight_ih.data_ptr(), K, cell.weight_hh.data_ptr(), H, planes.data_ptr(),
+                                             L.stream()), "split_bwd")
+    d_gi, d_gh = th.empty(N, 3 * H, device="cuda"), th.empty(N, 3 * H, device="cuda")
+    d_inp, d_h = th.empty(N, K, device="cuda"), th.empty(N, H, device="cuda")
+    L.check(lib.uavgnn_gru_cell_bwd(pre.data_ptr(), h.data_ptr(), d_hout.data_ptr(), N, K, H, planes.data_ptr(), d_gi.data_ptr(),
+                                    d_gh.data_ptr(), d_inp.data_ptr(), K, d_h.data_ptr(), L.stream()), "uavgnn_gru_cell_bwd")
+    g_gi, g_gh, g_dh = ops._gru_gates_bwd_from_pre(pre, h, d_hout)
+    assert th.equal(d_gi, g_gi) and th.equal(d_gh, g_gh)
+    c64 = th.nn.GRUCell(K, H).cuda().double()
+    c64.load_state_dict({k: v.double() for k, v in cell.state_dict().items()})
+    i64, h64 = inp.double().requires_grad_(True), h.double().requires_grad_(True)
+    (c64(i64, h64) * d_hout.double()).sum().backward()
+    assert_close(d_inp, i64.grad, 1e-5, "d_inp")
+    assert_close(d_h, h64.grad, 1e-5, "d_h")
+    assert_close(d_gi.t() @ inp, c64.weight_ih.grad, 1e-5, "dW_ih from the kept operands")

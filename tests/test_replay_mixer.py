@@ -90,7 +90,30 @@ def test_sequence_replay_on_the_device_reproduces_the_reference_replay_buffer():
     _check_replay_against_reference_buffer("cuda")
 
 
-def _check_replay_against_reference_buffer(device):
+def test_learner_cache_applies_the_reference_rules_to_the_raw_transition():
+    """MultiAgentQLearner.cache (learner.py:82-92): fed the RAW arguments the reference's cache received in the captured
+    rollout - done and bad_mask as the env returned them, next_h before it is zeroed - it must leave the sequences the
+    reference's cache + ReplayBuffer left: done muted by bad_mask (push 9: the episode ends by its time limit), next_h zeroed
+    by the raw done flag.  share_reward: the team mean, stored once."""
+    _check_replay_against_reference_buffer("cpu", via_cache=True)
+    import types
+    from uav_bs_ctrl_amd.learner import MultiAgentQLearner
+    rb = SequenceReplay(capacity=4, max_seq_len=2, n_agents=3, n_gts=2, hidden_size=4, n_envs=2, rew_dim=1, device="cpu")
+    me = types.SimpleNamespace(n_agents=3, args=types.SimpleNamespace(share_reward=True))
+    o = dict(gt=th.zeros(2, 3, 2, 5), ubs=th.zeros(2, 3, 2, 3), agent=th.zeros(2, 3, 2), d_u2u=th.zeros(2, 3, 3))
+    rew = th.tensor([[1.0, 2.0, 6.0], [0.0, 0.0, 3.0]])
+    MultiAgentQLearner.cache(me, rb, o, th.ones(6, 4), None, th.zeros(6, dtype=th.long), rew, o, th.ones(6, 4), None,
+                             th.tensor([1.0, 0.0]), th.tensor([0.0, 0.0]))
+    assert rb.cur["rew"][:, 0].flatten().tolist() == [3.0, 1.0]           # team means
+    assert rb.cur["done"][:, 0].flatten().tolist() == [1.0, 0.0]          # a real terminal state stays done
+
+
+@pytest.mark.gpu
+def test_learner_cache_on_the_device_applies_the_reference_rules():
+    _check_replay_against_reference_buffer("cuda", via_cache=True)
+
+
+def _check_replay_against_reference_buffer(device, via_cache=False):
     import ast
     z = np.load(f"{GOLDEN}/replay_buffer.npz")
     meta = ast.literal_eval(str(z["meta"]))
@@ -107,7 +130,17 @@ def _check_replay_against_reference_buffer(device):
         tr["act"] = f(f"push{i}:act").reshape(1, n)
         tr["rew"] = f(f"push{i}:rew").reshape(1, n)
         tr["done"] = f(f"push{i}:done").reshape(1, 1)
-        rb.push(tr)
+        if via_cache:     # the raw arguments through the learner's cache (the reference's run had share_reward = False)
+            import types
+            from uav_bs_ctrl_amd.learner import MultiAgentQLearner
+            me = types.SimpleNamespace(n_agents=n, args=types.SimpleNamespace(share_reward=False))
+            obs = {k: tr[k] for k in ("gt", "ubs", "agent", "d_u2u")}
+            nxt = {k: tr["next_" + k] for k in ("gt", "ubs", "agent", "d_u2u")}
+            MultiAgentQLearner.cache(me, rb, obs, tr["h"], tr["state"], f(f"push{i}:act"), f(f"push{i}:raw_rew"), nxt,
+                                     f(f"push{i}:raw_next_h"), tr["next_state"], float(z[f"push{i}:raw_done"]),
+                                     float(z[f"push{i}:raw_bad_mask"]))
+        else:
+            rb.push(tr)
     assert len(rb) == meta["n_seqs"] == 4 and rb.ptr == meta["n_pushes"] - 4 * T
     b = rb.gather(th.arange(4, device=device))
     if device == "cuda":

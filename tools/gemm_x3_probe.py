@@ -41,12 +41,12 @@ for name, M, n_out, K, tr in cases:
     f_x3 = lambda: ops.gemm_x3(a, W, tr)
     f_v = (lambda: th.mm(a, W)) if tr else (lambda: th.mm(a, W.t()))
     from uav_bs_ctrl_amd import _lib as L
-    L.lib().uavgnn_gemm_x3_set_variant(4)
+    ops.GEMM_X3_FLAGS = 8   # UAVGNN_GEMM_TILE_128
     t_x3_w4 = time_us(f_x3)
-    L.lib().uavgnn_gemm_x3_set_variant(9)     # eight waves, staging interleaved with the MFMAs
+    ops.GEMM_X3_FLAGS = 4     # eight waves, staging interleaved with the MFMAs
     t_x3_il = time_us(f_x3)
     y_il = f_x3()
-    L.lib().uavgnn_gemm_x3_set_variant(8)     # the default: eight waves, the staging of a slice as a block in front of its MFMAs
+    ops.GEMM_X3_FLAGS = 0     # the default: eight waves, the staging of a slice as a block in front of its MFMAs
     t_x3, t_v = time_us(f_x3), time_us(f_v)
     same = bool(th.equal(y_il, f_x3()))
     rows = slice(0, 2048)

@@ -85,9 +85,9 @@ cell = th.nn.GRUCell(320, H).to(dev)
 inp, h = th.randn(N, 320, device=dev), th.randn(N, H, device=dev)
 with th.no_grad():
     tot += run("GRU cell bf16x3 forward (no-grad)", lambda: ops.gru_cell(inp, h, cell), 151)
-    L.lib().uavgnn_gru_x3_set_variant(0)
+    ops.GRU_X3_FLAGS = 1   # UAVGNN_GRU_STAGING_BLOCKS
     run("   same, staging in blocks", lambda: ops.gru_cell(inp, h, cell), 151)
-    L.lib().uavgnn_gru_x3_set_variant(1)
+    ops.GRU_X3_FLAGS = 0
     ops.GRU_X3 = False
     run("   same on fp32 MFMA (csrc/gru_fused.hip)", lambda: ops.gru_cell(inp, h, cell), 151)
     ops.GRU_X3 = True
@@ -95,9 +95,9 @@ with th.no_grad():
 x512, W = th.randn(N, 512, device=dev), th.randn(256, 512, device=dev) * 0.05
 with th.no_grad():
     run("f_aggr GEMM bf16x3 [N,512] x [256,512]^T", lambda: ops.gemm_x3(x512, W), 100)
-    L.lib().uavgnn_gemm_x3_set_variant(9)
+    ops.GEMM_X3_FLAGS = 4   # UAVGNN_GEMM_STAGING_INTERLEAVED
     run("   same, staging interleaved", lambda: ops.gemm_x3(x512, W), 100)
-    L.lib().uavgnn_gemm_x3_set_variant(8)
+    ops.GEMM_X3_FLAGS = 0
     run("   same on the vendor fp32 GEMM", lambda: th.mm(x512, W.t()), 100)
 dgi, xin = th.randn(N, 768, device=dev), th.randn(N, 320, device=dev)
 tot += run("weight gradient d_gi^T inp (vendor fp32, batched split-K)", lambda: ops._wgrad(dgi, xin), 102)

@@ -8,7 +8,7 @@
 #include <vector>
 int main(int argc, char** argv) {
   const int il = argc > 1 ? atoi(argv[1]) : 1;   // 1 = staging interleaved with the MFMAs (default of the library), 0 = staging in blocks
-  uavgnn_gru_x3_set_variant(il);
+  const int flags = il ? 0 : UAVGNN_GRU_STAGING_BLOCKS;
   const int N = 32768, K = 320, H = 256;
   float *inp, *h, *Wih, *Whh, *bih, *bhh, *out;
   void* planes;
@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
   hipMemcpy(Wih, v.data(), 4ll * 3 * H * K, hipMemcpyHostToDevice); hipMemcpy(Whh, v.data(), 4ll * 3 * H * H, hipMemcpyHostToDevice);
   hipMemset(bih, 0, 4 * 3 * H); hipMemset(bhh, 0, 4 * 3 * H);
   uavgnn_gru_split_weights(Wih, K, Whh, H, planes, nullptr);
-  auto run = [&] { uavgnn_gru_cell_fwd_x3(inp, K, K, h, N, H, planes, bih, bhh, out, nullptr, nullptr); };
+  auto run = [&] { uavgnn_gru_cell_fwd_x3_opts(inp, K, K, nullptr, 0, 0, h, N, H, planes, bih, bhh, out, nullptr, flags, nullptr); };
   for (int i = 0; i < 3; ++i) run();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);

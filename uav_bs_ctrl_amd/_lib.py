@@ -86,13 +86,18 @@ SIGNATURES = {
     "uavgnn_gru_cell_supported": (_c_int, [_c_int, _c_int]),
     "uavgnn_gru_cell_fwd": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_st]),
     "uavgnn_gru_cell_x3_supported": (_c_int, [_c_int, _c_int]),
-    "uavgnn_gru_x3_set_variant": (None, [_c_int]),
     "uavgnn_gru_cell_x3_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
     "uavgnn_gru_split_weights": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, ctypes.c_void_p, _c_st]),
     "uavgnn_gru_cell_fwd_x3": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_fp, _c_fp, _c_fp, _c_st]),
     "uavgnn_gru_cell_fwd_x3_cat": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_fp,
                                             _c_fp, _c_fp, _c_st]),
-    "uavgnn_gemm_x3_set_variant": (None, [_c_int]),
+    "uavgnn_gru_cell_fwd_x3_opts": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_fp,
+                                             _c_fp, _c_fp, _c_int, _c_st]),
+    "uavgnn_gru_cell_bwd_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
+    "uavgnn_gru_split_weights_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, ctypes.c_void_p, _c_st]),
+    "uavgnn_gru_cell_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_fp, _c_fp, _c_int, _c_fp,
+                                     _c_st]),
+    "uavgnn_workspace_bytes": (ctypes.c_longlong, [_c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong]),
     "uavgnn_gemm_tn_x3_chunks": (_c_int, [ctypes.c_longlong, _c_int, _c_int]),
     "uavgnn_gemm_tn_x3": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, ctypes.c_longlong, _c_fp, _c_int, _c_int, _c_st]),
     "uavgnn_gemm_x3_supported": (_c_int, [_c_int, _c_int, _c_int]),

@@ -343,11 +343,12 @@ __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __res
 
 using namespace uavgnn;
 
-static int g_gemm_x3_variant = 8;   // A/B switch of tools/gemm_x3_probe.py (uavgnn_gemm_x3_set_variant): 4 = 128 x 128 tiles, four waves;
-                                    // 8 = eight waves, staging in blocks (default); 9 = eight waves, staging interleaved with the
-                                    // MFMAs: 7-15 % faster launch by launch, but a C3 cycle runs at the package power limit and is
-                                    // 0.5-2 ms SLOWER with it (profiles/r03_staging_interleave.txt)
-extern "C" void uavgnn_gemm_x3_set_variant(int v) { g_gemm_x3_variant = v; }
+// Kernel variants are selected PER CALL by bits of the `epilogue` word (no process-wide state: the library is re-entrant):
+//   default                          256 x 128 tiles, eight waves, the staging of a slice as a block in front of its MFMAs;
+//   UAVGNN_GEMM_STAGING_INTERLEAVED  the same with the staging interleaved with the MFMAs: 7-15 % faster launch by launch, but a
+//                                    C3 cycle runs at the package power limit and is 0.5-2 ms SLOWER with it
+//                                    (profiles/r03_staging_interleave.txt);
+//   UAVGNN_GEMM_TILE_128             128 x 128 tiles, four waves (the round-2 kernel).
 
 extern "C" int uavgnn_gemm_x3_supported(int M, int N, int K) {
   // 32-bit element offsets inside the kernel: every operand below 2^31 elements
@@ -377,7 +378,7 @@ extern "C" int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const vo
   const unsigned short* bp = static_cast<const unsigned short*>(planes);
   const bool acc = (epilogue & UAVGNN_GEMM_ACCUMULATE) != 0, relu = (epilogue & UAVGNN_GEMM_RELU) != 0;
   const int col_blocks = (N + BN - 1) / BN;
-  if (g_gemm_x3_variant >= 8) {
+  if (!(epilogue & UAVGNN_GEMM_TILE_128)) {
     const int row_blocks = (M + w8::BM8 - 1) / w8::BM8;
     const dim3 grid(((row_blocks + 7) / 8) * 8 * col_blocks), block(w8::NT);
 #define UAVGNN_X3_GEMM(ACC, RELU, IL)                                                                                        \
@@ -388,7 +389,7 @@ extern "C" int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const vo
   else if (acc) UAVGNN_X3_GEMM(true, false, IL);      \
   else if (relu) UAVGNN_X3_GEMM(false, true, IL);     \
   else UAVGNN_X3_GEMM(false, false, IL);
-    if (g_gemm_x3_variant == 9) { UAVGNN_X3_GEMM_IL(true) }
+    if (epilogue & UAVGNN_GEMM_STAGING_INTERLEAVED) { UAVGNN_X3_GEMM_IL(true) }
     else { UAVGNN_X3_GEMM_IL(false) }
 #undef UAVGNN_X3_GEMM_IL
 #undef UAVGNN_X3_GEMM

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
   // their use - f1 = (slice t, second half) under the MFMAs of f0, f0 = (slice t + 1, first half) right after the barrier
   // under the MFMAs of f1.  Iteration t also stages slice t + 1 into the other buffer (its readers passed the barrier of
   // iteration t - 1) and starts the loads of slice t + 2; the tail re-stages / re-loads the last slice (unconditional).
-  // Two schedules of the staging (template parameter IL, uavgnn_gru_x3_set_variant; bit-identical results):
+  // Two schedules of the staging (template parameter IL, UAVGNN_GRU_STAGING_BLOCKS of uavgnn_gru_cell_fwd_x3_opts; bit-identical results):
   //   blocks      - waves w and w + 4 share a SIMD: the first four stage BEFORE their first MFMA group, the last four AFTER it;
   //   interleaved - every wave stages INSIDE its first MFMA group (the default; see UAVGNN_X3_W8_STEP_IL).
   // sched_barrier pins the order (left alone, the compiler sinks the global loads below the MFMAs - prefetch distance zero -
@@ -349,9 +349,6 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
 
 using namespace uavgnn;
 
-static int g_gru_x3_interleave = 1;   // A/B switch (uavgnn_gru_x3_set_variant): 0 = staging as a block in front of the MFMAs (round 2)
-extern "C" void uavgnn_gru_x3_set_variant(int interleave) { g_gru_x3_interleave = interleave; }
-
 extern "C" int uavgnn_gru_cell_x3_supported(int K_in, int H) {
   return (K_in >= BK && K_in % BK == 0 && H >= w8::BJ && H % w8::BJ == 0) ? 1 : 0;
 }
@@ -376,9 +373,12 @@ extern "C" int uavgnn_gru_split_weights(const float* W_ih, int K_in, const float
   return launch_status();
 }
 
-extern "C" int uavgnn_gru_cell_fwd_x3_cat(const float* inp, int ld_inp, int K1, const float* inp2, int ld_inp2, int K2,
-                                          const float* h, int N, int H, const void* planes, const float* b_ih,
-                                          const float* b_hh, float* h_out, float* pre_save, uavgnn_stream_t stream) {
+// flags: UAVGNN_GRU_STAGING_BLOCKS = the round-2 schedule (staging of a slice as a block in front of / behind the first MFMA
+// group) instead of the interleaved one - the A/B of tools/gru_probe.py, bit-identical results.  Per call: no global state.
+extern "C" int uavgnn_gru_cell_fwd_x3_opts(const float* inp, int ld_inp, int K1, const float* inp2, int ld_inp2, int K2,
+                                           const float* h, int N, int H, const void* planes, const float* b_ih,
+                                           const float* b_hh, float* h_out, float* pre_save, int flags,
+                                           uavgnn_stream_t stream) {
   const int K_in = K1 + K2;
   if (N < 0 || !inp || !h || !planes || !b_ih || !b_hh || !h_out || ld_inp < K1 || K2 < 0 || (K2 > 0 && (!inp2 || ld_inp2 < K2)))
     return UAVGNN_EINVAL;
@@ -401,7 +401,7 @@ extern "C" int uavgnn_gru_cell_fwd_x3_cat(const float* inp, int ld_inp, int K1, 
 #define UAVGNN_X3_LAUNCH(KERNEL, BJ_, NT_)                                                                                  \
   hipLaunchKernelGGL(KERNEL, dim3(rb8 * (H / (BJ_))), dim3(NT_), 0, st, inp, ld_inp, K1, inp2, ld_inp2, K2, h, N, H, p0, b_ih, \
                      p1, b_hh, h_out, pre_save, row_blocks)
-  if (g_gru_x3_interleave) {
+  if (!(flags & UAVGNN_GRU_STAGING_BLOCKS)) {
     if (pre_save != nullptr) UAVGNN_X3_LAUNCH((gru_cell_fwd_x3w8_kernel<true, true>), w8::BJ, w8::NT);
     else UAVGNN_X3_LAUNCH((gru_cell_fwd_x3w8_kernel<false, true>), w8::BJ, w8::NT);
   } else {
@@ -410,6 +410,12 @@ extern "C" int uavgnn_gru_cell_fwd_x3_cat(const float* inp, int ld_inp, int K1, 
   }
 #undef UAVGNN_X3_LAUNCH
   return launch_status();
+}
+
+extern "C" int uavgnn_gru_cell_fwd_x3_cat(const float* inp, int ld_inp, int K1, const float* inp2, int ld_inp2, int K2,
+                                          const float* h, int N, int H, const void* planes, const float* b_ih,
+                                          const float* b_hh, float* h_out, float* pre_save, uavgnn_stream_t stream) {
+  return uavgnn_gru_cell_fwd_x3_opts(inp, ld_inp, K1, inp2, ld_inp2, K2, h, N, H, planes, b_ih, b_hh, h_out, pre_save, 0, stream);
 }
 
 extern "C" int uavgnn_gru_cell_fwd_x3(const float* inp, int ld_inp, int K_in, const float* h, int N, int H,

@@ -182,6 +182,41 @@ class MultiAgentQLearner:
         acts = th.where(explore.repeat_interleave(self.n_agents), rand, greedy)
         return acts, h
 
+    # ---- replay -----------------------------------------------------------------------------------------------------
+    def cache(self, buffer, obs: Dict, h, state, act, rew, next_obs: Dict, next_h, next_state, done, bad_mask,
+              staged: bool = False) -> None:
+        """learner.py:82-92 for E parallel environments on the device: one transition per environment is pushed into
+        ``buffer`` (a ``replay.SequenceReplay``) with the reference's three rules -
+          * ``share_reward``: every agent is credited the team MEAN of the step's rewards (``rew.mean()``), stored as one value;
+          * the stored ``done`` is muted when the episode ended by its time limit: ``done = (1 - bad_mask) * done``;
+          * the next hidden state is zeroed by the RAW done flag: ``next_h = (1 - done) * next_h`` (an episode that ends -
+            for whatever reason - hands no recurrent state to the next one).
+        obs / next_obs: the padded observation fields of the replay (gt, ubs, agent, d_u2u), each [E, ...]; h / next_h
+        [E * n, H] or [E, n, H]; state / next_state [E, state_dim] or None; act [E * n] or [E, n]; rew [E, n] (or [E, 1] /
+        [E]); done, bad_mask [E], [E, 1] or scalars.  staged: the observation half (obs fields, h, state) was written with
+        ``buffer.stage_obs`` before the simulator overwrote its buffers - only act / rew / done / next_* are pushed."""
+        E, n = buffer.n_envs, self.n_agents
+        dev = buffer.device
+        f32 = lambda x: th.as_tensor(x, dtype=th.float32, device=dev)   # noqa: E731
+        done_raw = f32(done).reshape(-1, 1).expand(E, 1)
+        bad = f32(0.0 if bad_mask is None else bad_mask).reshape(-1, 1).expand(E, 1)
+        rew = f32(rew).reshape(E, -1)
+        if getattr(self.args, "share_reward", False):
+            rew = rew.mean(1, keepdim=True)
+        tr = dict(act=th.as_tensor(act, device=dev).reshape(E, n).long(), rew=rew, done=(1.0 - bad) * done_raw,
+                  next_h=(1.0 - done_raw).unsqueeze(2) * f32(next_h).reshape(E, n, -1))
+        if not staged:
+            tr["h"] = f32(h).reshape(E, n, -1)
+        for k in ("gt", "ubs", "agent", "d_u2u"):
+            if not staged:
+                tr[k] = obs[k]
+            tr["next_" + k] = next_obs[k]
+        if state is not None:
+            if not staged:
+                tr["state"] = f32(state).reshape(E, -1)
+            tr["next_state"] = f32(next_state).reshape(E, -1)
+        buffer.push(tr)
+
     # ---- training -------------------------------------------------------------------------------------------------
     def loss(self, batch: Dict) -> tuple:
         """Forward part of ``update`` (learner.py:110-154).  batch: obs (list of T+1 HeteroBatch of B envs each),

@@ -374,7 +374,6 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save, inp2=None, h2_out=Non
     N, H = h.shape
     h2 = th.empty_like(h) if h2_out is None else h2_out
     pre = th.empty((N, 4 * H), dtype=th.float32, device=h.device) if save else None
-    _apply_variant_env()
     if inp2 is not None or (GRU_X3 and L.lib().uavgnn_gru_cell_x3_supported(inp.shape[1], H)
                             and 4 * N * max(inp.stride(0), H) < 2 ** 32):   # 32-bit byte offsets inside the kernel (3.3 M rows at K_in = 320)
         lib, K1, K2 = L.lib(), inp.shape[1], (0 if inp2 is None else inp2.shape[1])
@@ -387,10 +386,11 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save, inp2=None, h2_out=Non
                                     lambda p: L.check(lib.uavgnn_gru_split_weights(W_ih.data_ptr(), K_in, W_hh.data_ptr(), H,
                                                                                    p.data_ptr(), L.stream()),
                                                       "uavgnn_gru_split_weights"), keep=(W_ih, W_hh))
-            rc = lib.uavgnn_gru_cell_fwd_x3_cat(inp.data_ptr(), inp.stride(0), K1, L.ptr(inp2),
-                                                0 if inp2 is None else inp2.stride(0), K2, h.data_ptr(), N, H, planes.data_ptr(),
-                                                b_ih.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), L.ptr(pre), L.stream())
-        L.check(rc, "uavgnn_gru_cell_fwd_x3_cat")
+            rc = lib.uavgnn_gru_cell_fwd_x3_opts(inp.data_ptr(), inp.stride(0), K1, L.ptr(inp2),
+                                                 0 if inp2 is None else inp2.stride(0), K2, h.data_ptr(), N, H, planes.data_ptr(),
+                                                 b_ih.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), L.ptr(pre), GRU_X3_FLAGS,
+                                                 L.stream())
+        L.check(rc, "uavgnn_gru_cell_fwd_x3_opts")
         return h2, pre
     with KERNEL_TIMER.span("gru_cell_fwd", (N, inp.shape[1], H, "f32")):
         rc = L.lib().uavgnn_gru_cell_fwd(inp.data_ptr(), inp.stride(0), inp.shape[1], h.data_ptr(), N, H, W_ih.data_ptr(),
@@ -487,22 +487,14 @@ GEMM_X3 = os.environ.get("UAVGNN_GEMM_X3", "1") != "0"   # False: vendor fp32 GE
 # outputs that tile by 128 columns (256, 512), 1.01x on 320 (2.5 tiles), 0.84x on 96: only the first group takes the kernel.
 
 
-_gemm_x3_variant_set = False
-
-
-def _apply_variant_env():
-    """A/B switches of the probes from the environment, once (include/uavgnn.h): GEMM 9 / 8 / 4, GRU cell 1 / 0."""
-    global _gemm_x3_variant_set
-    if not _gemm_x3_variant_set:
-        if "UAVGNN_GEMM_X3_VARIANT" in os.environ:
-            L.lib().uavgnn_gemm_x3_set_variant(int(os.environ["UAVGNN_GEMM_X3_VARIANT"]))
-        if "UAVGNN_GRU_X3_VARIANT" in os.environ:
-            L.lib().uavgnn_gru_x3_set_variant(int(os.environ["UAVGNN_GRU_X3_VARIANT"]))
-    _gemm_x3_variant_set = True
+# A/B variants of the bf16x3 kernels are PER-CALL flag words of the C ABI (include/uavgnn.h: the library keeps no process-wide
+# state); the probes set these module attributes, the environment seeds them: GEMM 8 (default) / 9 (staging interleaved) / 4
+# (128 x 128 tiles), GRU cell 1 (default: staging interleaved) / 0 (staging in blocks)
+GEMM_X3_FLAGS = {"8": 0, "9": 4, "4": 8}.get(os.environ.get("UAVGNN_GEMM_X3_VARIANT", "8"), 0)
+GRU_X3_FLAGS = 1 if os.environ.get("UAVGNN_GRU_X3_VARIANT", "1") == "0" else 0
 
 
 def gemm_x3_supported(a, n_out, k) -> bool:
-    _apply_variant_env()
     return bool(GEMM_X3 and a.is_cuda and a.dtype == th.float32 and a.dim() == 2 and a.stride(1) == 1
                 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and n_out % 128 == 0 and a.shape[0] >= 4096
                 and a.shape[0] * a.stride(0) < 2 ** 31 and L.lib().uavgnn_gemm_x3_supported(a.shape[0], n_out, k))
@@ -525,7 +517,7 @@ def gemm_x3(a, W, transpose_w=False, bias=None, out=None, accumulate=False, relu
                                                                           p.data_ptr(), L.stream()), "uavgnn_split_bf16x3"),
                                 keep=(W,))
         rc = lib.uavgnn_gemm_nt_x3(a.data_ptr(), a.stride(0), M, K, planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(),
-                                   out.stride(0), (1 if accumulate else 0) | (2 if relu else 0), L.stream())
+                                   out.stride(0), (1 if accumulate else 0) | (2 if relu else 0) | GEMM_X3_FLAGS, L.stream())
     L.check(rc, "uavgnn_gemm_nt_x3")
     return out
 
