@@ -609,6 +609,10 @@ def main():
             "tuned_gemms": bool(tuned),        # recorded vendor-GEMM solutions (uav_bs_ctrl_amd/tuned/gemm_gfx950.csv) accepted by this box's hipBLASLt
             "shader_clock": clock_info,        # sustained clock of the timed region (the part runs at its power limit: DESIGN.md section 6)
             "rccl_ranks": (dist.get_world_size() if use_dist else 1),
+            "collective_backend": (None if not use_dist else
+                                   {"backend": dist.get_backend(), "rccl_version": ".".join(map(str, th.cuda.nccl.version())),
+                                    "NCCL_DEBUG": os.environ.get("NCCL_DEBUG"),
+                                    "note": "one process per GPU; set NCCL_DEBUG=INFO to see the transport (xGMI / P2P) RCCL picked"}),
             "collective_ms": (None if not coll_ms else {"per_update_mean": sum(coll_ms) / len(coll_ms), "max": max(coll_ms),
                                                         "calls": len(coll_ms), "bytes": 4 * learner.grads.flat.numel(),
                                                         "what": "all-reduce (sum) of the flat fp32 gradient buffer + the 1/G scaling, "

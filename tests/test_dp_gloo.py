@@ -174,3 +174,31 @@ def test_replay_ratio_chunks_accumulate_to_the_concatenated_batch_step():
     assert abs(float(out1["LossQ"]) - float(out2["LossQ"])) <= 1e-6 * max(1.0, abs(float(out2["LossQ"])))
     for (k, p1), (_, p2) in zip(L1.policy_net.named_parameters(), L2.policy_net.named_parameters()):
         assert float((p1 - p2).abs().max()) <= 1e-6, k
+
+
+def test_accumulate_rejects_empty_and_unequal_chunk_lists():
+    """the mean of the chunk means equals the mean over all sequences only for equally sized chunks, and an empty
+    list has no loss: both are refused instead of stepping on a silently different objective."""
+    import pytest
+    L1 = _learner()
+    with pytest.raises(ValueError):
+        L1.accumulate([])
+    with pytest.raises(ValueError):
+        L1.accumulate([_make_batch(1, 2), _make_batch(2, 3)])
+
+
+def test_discrete_comm_noise_key_survives_a_checkpoint(tmp_path):
+    """DiscreteComm's {seed, step} pair is not in the state_dict (its names are the reference's contract); the
+    learner's checkpoint carries it as an extra key and load_checkpoint puts it back."""
+    L1, L2 = _learner(), _learner()
+    fake = type("M", (nn.Module,), {})()
+    fake.rng_state = th.tensor([1234567, 89], dtype=th.int64)
+    L1.policy_net.add_module("f_comm_probe", fake)
+    probe2 = type("M", (nn.Module,), {})()
+    probe2.rng_state = None
+    L2.policy_net.add_module("f_comm_probe", probe2)
+    path = str(tmp_path / "ck.pt")
+    L1.save_checkpoint(path, dict(epoch=1, t=2))
+    assert th.load(path)["comm_rng_state"]["f_comm_probe"].tolist() == [1234567, 89]
+    L2.load_checkpoint(path)
+    assert L2.policy_net.f_comm_probe.rng_state.tolist() == [1234567, 89]

@@ -274,6 +274,10 @@ class DiscreteComm(nn.Module):
         if noise is None:
             if self.rng_state is None or self.rng_state.device != x.device:
                 seed = int(th.randint(0, 2 ** 62, (1,)).item())      # from torch's (seedable) default generator
+                if th.distributed.is_available() and th.distributed.is_initialized():
+                    # data-parallel ranks usually share torch.manual_seed: without the rank in the key every rank would draw
+                    # the same noise per (edge position, channel, step)
+                    seed = (seed ^ (th.distributed.get_rank() * 0x9E3779B97F4A7C15)) & (2 ** 62 - 1)
                 self.rng_state = th.tensor([seed, 0], dtype=th.int64, device=x.device)
             rng = self.rng_state
         c = ops.disc_comm_aggregate(logits, noise, g, tau=0.5, rng=rng)

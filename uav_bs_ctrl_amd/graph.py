@@ -437,6 +437,10 @@ def merge(graphs: Sequence[HeteroBatch]) -> HeteroBatch:
     for c in graphs[0]._rels:
         holders = [g for g in graphs if c in g._rels and has_edges(g, c)]
         if len(holders) > 1:
+            # the cheap test over-counts on the device (a capacity-sized relation without a real edge, a relation without a
+            # source array): only this ambiguous case pays for the exact question - one host read of off[-1] per candidate
+            holders = [g for g in holders if g._rels[c].num_edges > 0]
+        if len(holders) > 1:
             raise NotImplementedError("merge of two non-empty copies of one relation")
         if holders:
             rels[c] = holders[0]._rels[c]

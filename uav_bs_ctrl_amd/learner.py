@@ -296,6 +296,11 @@ class MultiAgentQLearner:
     def accumulate(self, batch) -> Dict:
         """Zero the flat gradient buffer, then loss + backward of every chunk into it (learner.py:110-157)."""
         chunks = batch if isinstance(batch, (list, tuple)) else [batch]
+        if len(chunks) == 0:
+            raise ValueError("accumulate: empty list of batches")
+        sizes = {tuple(b["acts"].shape) for b in chunks}
+        if len(sizes) > 1:      # the mean of chunk means is the mean over all sequences only for equally sized chunks
+            raise ValueError(f"accumulate: chunks of different sizes {sorted(sizes)}")
         self.grads.zero_()
         # weight gradients of the fused recurrent step are accumulated in place across the T+1 steps (and across the
         # chunks) and folded into the flat gradient buffer once (ops.WeightGradSink); everything else reaches it through
@@ -316,7 +321,7 @@ class MultiAgentQLearner:
                 sink.flush()
         finally:
             ops.GRAD_SINK = None
-        return dict(LossQ=loss, QVals=agent_out.detach())
+        return dict(LossQ=loss, QVals=agent_out.detach())      # QVals: the LAST chunk's (LossQ: the mean over all chunks)
 
     def apply(self) -> None:
         """clip_grad_value_(policy_net.parameters(), 1) (the mixer is NOT clipped, learner.py:159) + AdamW step + polyak
@@ -347,6 +352,11 @@ class MultiAgentQLearner:
             ck["mixer_state_dict"] = self.mixer.state_dict()
         if self.anneal_lr:
             ck["lr_scheduler_state_dict"] = self.lr_scheduler.state_dict()
+        # the {seed, step} pair of DiscreteComm's in-kernel noise generator: an extra key, NOT a module buffer (the state_dict
+        # names are the reference's contract), so that a resumed run continues its noise stream
+        rng = {name: m.rng_state.cpu() for name, m in self.policy_net.named_modules() if getattr(m, "rng_state", None) is not None}
+        if rng:
+            ck["comm_rng_state"] = rng
         th.save(ck, path)
 
     def load_checkpoint(self, path: str) -> dict:
@@ -360,6 +370,9 @@ class MultiAgentQLearner:
             self.target_mixer.load_state_dict(self.mixer.state_dict())
         if self.anneal_lr and "lr_scheduler_state_dict" in ck:
             self.lr_scheduler.load_state_dict(ck["lr_scheduler_state_dict"])
+        for name, m in self.policy_net.named_modules():
+            if name in ck.get("comm_rng_state", {}) and hasattr(m, "rng_state"):
+                m.rng_state = ck["comm_rng_state"][name].to(self.device)
         return dict(epoch=ck.get("epoch"), t=ck.get("t"))
 
 
