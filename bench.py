@@ -396,7 +396,9 @@ def end_to_end(learner, a, device, mode="random", cycles=2):
                      dones=m["done"].permute(1, 0, 2).contiguous())
         return learner.update(batch)
 
-    cycle()
+    gc.collect()
+    th.cuda.empty_cache()        # every leg starts from a clean caching allocator: the blocks the previous legs left behind (the
+    cycle()                      # rho leg's 32 chunks, the staging buffers) cost the hotspot leg 28 ms per cycle otherwise
     th.cuda.synchronize()
     vis.clear()
     t0 = time.perf_counter()
