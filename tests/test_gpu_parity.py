@@ -1269,12 +1269,16 @@ def test_bench_step_under_force_dist_equals_the_plain_run():
 
 
 @pytest.mark.parametrize("B,n,M,dist,seed", [(16, 8, 80, "dense", 0), (64, 8, 80, "env", 1), (9, 5, 40, "ragged", 2),
-                                             (7, 16, 30, "ragged", 3), (1, 1, 12, "ragged", 4), (33, 3, 100, "env", 5)])
+                                             (7, 16, 30, "ragged", 3), (1, 1, 12, "ragged", 4), (33, 3, 100, "env", 5),
+                                             (5, 20, 10, "ragged", 6), (4400, 8, 12, "env", 7)])
 def test_fused_hetero_k1_equals_per_relation_kernels(B, n, M, dist, seed):
-    """gatv2_hetero.hip (both relations, one launch; `near` two destinations per MFMA row tile with [x_u ; x_v] in the
-    K = 4 contraction) against the per-relation kernels on the same inputs: outputs, saved attention weights and - through
-    them - the parameter gradients.  Covers odd N (last pair half empty), near degrees above 8 (n = 16: two passes),
-    isolated `near` destinations, and destinations isolated in `seen` with / without a hand-out order."""
+    """gatv2_hetero.hip (both relations, one launch; `near` on blocks of 16 destinations, one score tile per edge slot with
+    [x_u ; x_v] in the contraction) against the per-relation kernels on the same inputs: outputs, saved attention weights and
+    - through them - the parameter gradients.  Covers N that is not a multiple of 16 (masked rows of the last block), near
+    degrees above 8 and above 16 (n = 16 / 20: two / three passes through the online softmax, raw scores re-normalised in
+    place), isolated `near` destinations, destinations isolated in `seen` with / without a hand-out order, and - 35 200
+    destinations = 2 200 blocks for 2 048 wavefronts - the several-blocks-per-wavefront path of the time-batched launches
+    (next block's inputs prefetched, opposite part order on the two wavefronts of a SIMD)."""
     from uav_bs_ctrl_amd import ops
     from uav_bs_ctrl_amd.agents.gnn_agents import GraphObservationEncoder
     import types
@@ -2042,3 +2046,51 @@ def test_gru_cell_backward_as_one_c_abi_call_equals_the_host_sequence():
     assert_close(d_inp, i64.grad, 1e-5, "d_inp")
     assert_close(d_h, h64.grad, 1e-5, "d_h")
     assert_close(d_gi.t() @ inp, c64.weight_ih.grad, 1e-5, "dW_ih from the kept operands")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dist,save", [("env", False), ("dense", False), ("env", True)])
+def test_fused_hetero_k1_writes_every_row_and_repeats_bit_for_bit(dist, save):
+    """The fused K1 forward at C3 size, six launches into NaN-POISONED outputs: every element is written (a row store lost
+    under a mask, an out-of-range buffer offset that wraps - both happened while the round-4 row-store path was built) and
+    every launch returns the same bits (the raw-buffer-store variant returned another store's address operand in ~0.003 % of
+    the rows under store back-pressure: tools/k1_check.py); the saved attention weights likewise."""
+    import bench
+    from uav_bs_ctrl_amd import _lib as L
+    from uav_bs_ctrl_amd.agents.gnn_agents import GATv2Conv
+    dev = th.device("cuda")
+    gen = th.Generator(device=dev)
+    gen.manual_seed(3)
+    th.manual_seed(3)
+    hb = bench.synth_batch_gpu(4096, 8, 80, dist, dev, gen)
+    xs, so = hb.relation_segments("seen")
+    xn, no = hb.relation_segments("near")
+    order, x_a = hb.relation_order("seen"), hb.agent_feat()
+    N = x_a.shape[0]
+    ps = []
+    for FS in (4, 2):
+        c = GATv2Conv((FS, 2), 64, 4).to(dev)
+        ps.append([t.detach().contiguous() for t in (c.fc_src.weight, c.fc_src.bias, c.fc_dst.weight, c.fc_dst.bias, c.attn,
+                                                     c.res_fc.weight, c.res_fc.bias)])
+    lib, st = L.lib(), L.stream()
+
+    def run():
+        out = th.full((N, 512), float("nan"), device=dev)
+        a_s = th.full((max(xs.shape[0], 1), 4), float("nan"), device=dev)
+        a_n = th.full((max(xn.shape[0], 1), 4), float("nan"), device=dev)
+        rc = lib.uavgnn_gatv2_hetero_fwd(xs.data_ptr(), xs.shape[0], so.data_ptr(), L.ptr(order), xn.data_ptr(), xn.shape[0],
+                                         no.data_ptr(), x_a.data_ptr(), N, L.ptr_array(ps[0]), L.ptr_array(ps[1]), 4, 64, 0.2,
+                                         out.data_ptr(), 512, a_s.data_ptr() if save else None,
+                                         a_n.data_ptr() if save else None, st)
+        assert rc == 0
+        th.cuda.synchronize()
+        return out, a_s, a_n
+    o1, s1, n1 = run()
+    assert not bool(th.isnan(o1).any())
+    if save:
+        assert not bool(th.isnan(n1).any()) and (xs.shape[0] == 0 or not bool(th.isnan(s1).any()))
+    for _ in range(5):
+        o2, s2, n2 = run()
+        assert th.equal(o1, o2)
+        if save:
+            assert th.equal(n1, n2) and th.equal(s1, s2)
