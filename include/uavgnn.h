@@ -96,6 +96,22 @@ int uavgnn_gatv2_hetero_fwd_phases(const float* x_gt, int E_seen, const int32_t*
                                    const float* const* seen_params, const float* const* near_params, int nh, int D,
                                    float slope, float* out, int ld_out, float* attn_save_seen, float* attn_save_near,
                                    int phases, uavgnn_stream_t stream);
+/* Prepared parameters.  Every workgroup of the forward kernel first turns the parameters of the two modules into the image its
+ * LDS holds (bf16 three-way splits of the weight tiles, scaled attention vectors, attn x W_s sums: one memory round trip + ~200
+ * VALU instructions per wavefront = 2.9 us of a 20-us rollout launch).  A caller whose parameters stay put over many launches - a
+ * rollout between two optimiser steps, the target network between two syncs - builds the image ONCE (uavgnn_gatv2_hetero_prepare,
+ * one workgroup) into a buffer of uavgnn_gatv2_hetero_image_bytes() bytes (16-byte aligned) and launches with
+ * uavgnn_gatv2_hetero_fwd_image, whose workgroups only copy it.  Results are bit-identical to uavgnn_gatv2_hetero_fwd_phases
+ * with the same `phases`.  The image is a function of the parameter VALUES and `slope`: the caller must rebuild it after any
+ * parameter change (the library cannot tell).  seen_params / near_params are still required (argument checks, fp32-MFMA route). */
+size_t uavgnn_gatv2_hetero_image_bytes(void);
+int uavgnn_gatv2_hetero_prepare(const float* const* seen_params, const float* const* near_params, int nh, int D, float slope,
+                                void* image, uavgnn_stream_t stream);
+int uavgnn_gatv2_hetero_fwd_image(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order,
+                                  const float* x_ubs, int E_near, const int32_t* near_off, const float* x_dst, int N,
+                                  const float* const* seen_params, const float* const* near_params, int nh, int D,
+                                  float slope, const void* image, float* out, int ld_out, float* attn_save_seen,
+                                  float* attn_save_near, int phases, uavgnn_stream_t stream);
 
 /* K1 backward: parameter gradients only (observations are leaves: the reference never needs d/dx, Appendix A.4).
  * out / d_out are the forward output and its gradient (same ld).  Gradients are OVERWRITTEN.  Deterministic: per
@@ -380,7 +396,8 @@ int uavgnn_gru_cell_bwd(const float* pre, const float* h, const float* d_hout, i
 /* ONE query for every caller-provided scratch / plane buffer (bytes; 0 = unknown kind or bad sizes).  Arguments per kind:
  *   GATV2_BWD (F_src, H)            partial rows of uavgnn_gatv2_bwd          DEGREE_ORDER (N)   CSC_TRANSPOSE (N)
  *   GRU_PLANES (K_in, H)            uavgnn_gru_split_weights                  GRU_BWD_PLANES (K_in, H)  uavgnn_gru_split_weights_bwd
- *   GEMM_PLANES (R, C)              uavgnn_split_bf16x3                       GEMM_TN_PARTIALS (n_rows, Mo, Ko)  uavgnn_gemm_tn_x3 */
+ *   GEMM_PLANES (R, C)              uavgnn_split_bf16x3                       GEMM_TN_PARTIALS (n_rows, Mo, Ko)  uavgnn_gemm_tn_x3
+ *   K1_IMAGE ()                     uavgnn_gatv2_hetero_prepare */
 #define UAVGNN_WS_GATV2_BWD 1
 #define UAVGNN_WS_DEGREE_ORDER 2
 #define UAVGNN_WS_CSC_TRANSPOSE 3
@@ -388,6 +405,7 @@ int uavgnn_gru_cell_bwd(const float* pre, const float* h, const float* d_hout, i
 #define UAVGNN_WS_GRU_BWD_PLANES 5
 #define UAVGNN_WS_GEMM_PLANES 6
 #define UAVGNN_WS_GEMM_TN_PARTIALS 7
+#define UAVGNN_WS_K1_IMAGE 8
 long long uavgnn_workspace_bytes(int kind, long long a, long long b, long long c);
 
 #ifdef __cplusplus

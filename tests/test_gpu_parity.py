@@ -2094,3 +2094,109 @@ def test_fused_hetero_k1_writes_every_row_and_repeats_bit_for_bit(dist, save):
         assert th.equal(o1, o2)
         if save:
             assert th.equal(n1, n2) and th.equal(s1, s2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,n,M,dist,save,bias", [(4096, 8, 80, "env", False, True), (64, 8, 80, "dense", True, True),
+                                                 (9, 5, 40, "ragged", True, False), (2, 1, 3, "env", False, True)])
+def test_fused_hetero_k1_prepared_image_is_bit_identical_and_follows_the_parameters(B, n, M, dist, save, bias):
+    """uavgnn_gatv2_hetero_prepare + uavgnn_gatv2_hetero_fwd_image: the parameter image built once by one workgroup and copied by
+    the forward's workgroups gives the SAME BITS as the in-kernel prologue (outputs and saved attention weights), also without a
+    res_fc bias and on a ragged N; a rebuilt image follows a parameter change; bad arguments are refused."""
+    import bench
+    from uav_bs_ctrl_amd import _lib as L
+    from uav_bs_ctrl_amd.agents.gnn_agents import GATv2Conv
+    dev = th.device("cuda")
+    gen = th.Generator(device=dev)
+    gen.manual_seed(11)
+    th.manual_seed(11)
+    hb = bench.synth_batch_gpu(B, n, M, dist, dev, gen)
+    xs, so = hb.relation_segments("seen")
+    xn, no = hb.relation_segments("near")
+    order, x_a = hb.relation_order("seen"), hb.agent_feat()
+    N = x_a.shape[0]
+    ps = []
+    for FS in (4, 2):
+        c = GATv2Conv((FS, 2), 64, 4).to(dev)
+        ps.append([t.detach().contiguous() for t in (c.fc_src.weight, c.fc_src.bias, c.fc_dst.weight, c.fc_dst.bias, c.attn,
+                                                     c.res_fc.weight)] + [c.res_fc.bias.detach().contiguous() if bias else None])
+    lib, st = L.lib(), L.stream()
+    nbytes = lib.uavgnn_gatv2_hetero_image_bytes()
+    assert nbytes > 0 and nbytes % 16 == 0 and lib.uavgnn_workspace_bytes(8, 0, 0, 0) == nbytes
+    image = th.empty(nbytes, dtype=th.uint8, device=dev)
+
+    def prepare():
+        assert lib.uavgnn_gatv2_hetero_prepare(L.ptr_array(ps[0]), L.ptr_array(ps[1]), 4, 64, 0.2, image.data_ptr(), st) == 0
+
+    def run(img):
+        out = th.full((N, 512), float("nan"), device=dev)
+        a_s = th.full((max(xs.shape[0], 1), 4), float("nan"), device=dev)
+        a_n = th.full((max(xn.shape[0], 1), 4), float("nan"), device=dev)
+        head = (xs.data_ptr(), xs.shape[0], so.data_ptr(), L.ptr(order), xn.data_ptr(), xn.shape[0], no.data_ptr(), x_a.data_ptr(), N,
+                L.ptr_array(ps[0]), L.ptr_array(ps[1]), 4, 64, 0.2)
+        tail = (out.data_ptr(), 512, a_s.data_ptr() if save else None, a_n.data_ptr() if save else None, 3, st)
+        rc = lib.uavgnn_gatv2_hetero_fwd_image(*head, img.data_ptr(), *tail) if img is not None else \
+            lib.uavgnn_gatv2_hetero_fwd_phases(*head, *tail)
+        assert rc == 0
+        th.cuda.synchronize()
+        return out, a_s, a_n
+
+    prepare()
+    for a, b in zip(run(None), run(image)):
+        assert th.equal(th.nan_to_num(a, nan=-7.0), th.nan_to_num(b, nan=-7.0))
+    assert not bool(th.isnan(run(image)[0]).any())
+    # the image is a function of the parameter values: stale until rebuilt
+    ps[1][0].mul_(1.5)
+    ps[0][4].add_(0.25)
+    fresh = run(None)[0]
+    assert not th.equal(run(image)[0], fresh)
+    prepare()
+    assert th.equal(run(image)[0], fresh)
+    # refused: no image, misaligned image, missing parameter
+    head = (xs.data_ptr(), xs.shape[0], so.data_ptr(), L.ptr(order), xn.data_ptr(), xn.shape[0], no.data_ptr(), x_a.data_ptr(), N,
+            L.ptr_array(ps[0]), L.ptr_array(ps[1]), 4, 64, 0.2)
+    out = th.empty((N, 512), device=dev)
+    assert lib.uavgnn_gatv2_hetero_fwd_image(*head, None, out.data_ptr(), 512, None, None, 3, st) == L.UAVGNN_EINVAL
+    assert lib.uavgnn_gatv2_hetero_fwd_image(*head, image.data_ptr() + 4, out.data_ptr(), 512, None, None, 3, st) == L.UAVGNN_EUNSUPPORTED
+    assert lib.uavgnn_gatv2_hetero_prepare(L.ptr_array(ps[0]), L.ptr_array(ps[1]), 4, 64, 0.2, None, st) == L.UAVGNN_EINVAL
+    assert lib.uavgnn_gatv2_hetero_prepare(L.ptr_array(ps[0]), L.ptr_array(ps[1]), 2, 64, 0.2, image.data_ptr(), st) == L.UAVGNN_EUNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_rollout_weight_cache_of_the_learner_is_invalidated_by_every_parameter_change(monkeypatch):
+    """MultiAgentQLearner.act keeps weight planes and the K1 parameter image between optimiser steps (ops.frozen_weights store
+    owned by the learner).  Rollout -> update -> rollout with the cache gives the same actions / hidden states as the same
+    sequence with the cache switched off; load_state_dict (version counters) and load_checkpoint are seen as well."""
+    import copy
+    from uav_bs_ctrl_amd import ops
+    import bench
+
+    def episode(cache_on):
+        monkeypatch.setattr(ops, "K1_IMAGE", cache_on)
+        learner, batch = _small_learner_and_batch(B=512, n=8, M=20, T=2, seed=5)
+        if not cache_on:       # no persistent store at all: every call rebuilds its planes
+            monkeypatch.setattr(learner, "_rollout_planes", None)
+        gen = th.Generator(device="cuda")
+        gen.manual_seed(1)
+        obs = bench.synth_batch_gpu(512, 8, 20, "env", th.device("cuda"), gen)
+        h = learner.init_hidden(512)
+        outs = []
+        for _ in range(2):
+            acts, h = learner.act(obs, h, 0.0)
+            outs += [acts.clone(), h.clone()]
+        if cache_on:
+            assert any(k[0] == "k1img" for k in learner._rollout_planes) and len(learner._rollout_planes) < 16
+        learner.update(batch)
+        assert not cache_on or len(learner._rollout_planes) == 0
+        acts, h = learner.act(obs, h, 0.0)
+        outs += [acts.clone(), h.clone()]
+        sd = copy.deepcopy(learner.policy_net.state_dict())
+        for k in sd:
+            sd[k] = sd[k] * 0.5
+        learner.policy_net.load_state_dict(sd)        # behind the learner's back, but through torch: version counters
+        acts, h = learner.act(obs, h, 0.0)
+        outs += [acts.clone(), h.clone()]
+        return outs
+    a, b = episode(True), episode(False)
+    for x, y in zip(a, b):
+        assert th.equal(x, y)

@@ -42,14 +42,21 @@ for FS in (4, 2):
 lib, st = L.lib(), L.stream()
 
 
-def run(phases):
+image = th.empty(lib.uavgnn_gatv2_hetero_image_bytes() // 4, device=dev)
+assert lib.uavgnn_gatv2_hetero_prepare(L.ptr_array(ps[0]), L.ptr_array(ps[1]), 4, 64, 0.2, image.data_ptr(), st) == 0
+
+
+def run(phases, with_image=False):
     out = th.full((N, 512), float("nan"), device=dev)
     a_s = th.full((max(xs.shape[0], 1), 4), float("nan"), device=dev)
     a_n = th.full((max(xn.shape[0], 1), 4), float("nan"), device=dev)
-    rc = lib.uavgnn_gatv2_hetero_fwd_phases(xs.data_ptr(), xs.shape[0], so.data_ptr(), L.ptr(order), xn.data_ptr(), xn.shape[0],
-                                            no.data_ptr(), x_a.data_ptr(), N, L.ptr_array(ps[0]), L.ptr_array(ps[1]), 4, 64, 0.2,
-                                            out.data_ptr(), 512, a_s.data_ptr() if a.save else None,
-                                            a_n.data_ptr() if a.save else None, phases, st)
+    head = (xs.data_ptr(), xs.shape[0], so.data_ptr(), L.ptr(order), xn.data_ptr(), xn.shape[0], no.data_ptr(), x_a.data_ptr(), N,
+            L.ptr_array(ps[0]), L.ptr_array(ps[1]), 4, 64, 0.2)
+    tail = (out.data_ptr(), 512, a_s.data_ptr() if a.save else None, a_n.data_ptr() if a.save else None, phases, st)
+    if with_image:
+        rc = lib.uavgnn_gatv2_hetero_fwd_image(*head, image.data_ptr(), *tail)
+    else:
+        rc = lib.uavgnn_gatv2_hetero_fwd_phases(*head, *tail)
     assert rc == 0
     th.cuda.synchronize()
     return out, a_s, a_n
@@ -70,6 +77,11 @@ o1, s1, n1 = run(3)
 for rep in range(5):
     o2, s2, n2 = run(3)
     report(f"run {rep + 2} vs run 1", o2, o1, 0.0)
+oi, si, ni = run(3, with_image=True)
+report("prepared image vs in-kernel prologue (bit-equal)", oi, o1, 0.0)
+if a.save:
+    report("  saved near weights", ni, n1, 0.0)
+    report("  saved seen weights", si, s1, 0.0)
 of, sf, nf = run(3 | 256)
 report("bf16 build vs fp32-MFMA build", o1, of, 1e-5)
 for o in (o1, o2):

@@ -48,6 +48,18 @@ static T* dev(const std::vector<T>& v) {
   return p;
 }
 
+// K1_IMAGE=1: launches go through uavgnn_gatv2_hetero_fwd_image with an image prepared once (the rollout path of the learner)
+static void* g_image = nullptr;
+static int k1_call(const float* xg, int Es, const int32_t* so, const int32_t* ord, const float* xu, int En, const int32_t* no,
+                   const float* xa, int N, const float* const* ps, const float* const* pn, float* out, int ld, float* sv_s,
+                   float* sv_n, int ph) {
+#if !defined(K1_OLD)
+  if (g_image != nullptr)
+    return uavgnn_gatv2_hetero_fwd_image(xg, Es, so, ord, xu, En, no, xa, N, ps, pn, 4, 64, 0.2f, g_image, out, ld, sv_s, sv_n, ph, nullptr);
+#endif
+  return uavgnn_gatv2_hetero_fwd_phases(xg, Es, so, ord, xu, En, no, xa, N, ps, pn, 4, 64, 0.2f, out, ld, sv_s, sv_n, ph, nullptr);
+}
+
 int main(int argc, char** argv) {
   const std::string dist = argc > 1 ? argv[1] : "env";
   const int B = argc > 2 ? atoi(argv[2]) : 4096, n = 8, M = 80, N = B * n, H = 256;
@@ -120,10 +132,17 @@ int main(int argc, char** argv) {
     printf("streaming write of %.1f MB, %4d blocks: plain %6.2f us (%.2f TB/s)  nontemporal %6.2f us (%.2f TB/s)\n", n4 * 16 / 1e6, g,
            t0, n4 * 16 / t0 / 1e6, t1, n4 * 16 / t1 / 1e6);
   }
+#if !defined(K1_OLD)
+  if (getenv("K1_IMAGE")) {
+    hipMalloc(&g_image, uavgnn_gatv2_hetero_image_bytes());
+    const int rc = uavgnn_gatv2_hetero_prepare(ps, pn, 4, 64, 0.2f, g_image, nullptr);
+    hipDeviceSynchronize();
+    printf("prepared image: %zu bytes, rc %d\n", uavgnn_gatv2_hetero_image_bytes(), rc);
+  }
+#endif
   for (int ph : {3, 3 | 4096, 3 | 8192, 3 | 12288, 2, 1, 0, 2 | 32, 2 | 64, 2 | 128, 2 | 32 | 64 | 128}) {
     auto run = [&] {
-      int rc = uavgnn_gatv2_hetero_fwd_phases(d_xg, Es, d_so, d_ord, d_xu, En, d_no, d_xa, N, ps, pn, 4, 64, 0.2f, out, 2 * H,
-                                              nullptr, nullptr, ph, nullptr);
+      int rc = k1_call(d_xg, Es, d_so, d_ord, d_xu, En, d_no, d_xa, N, ps, pn, out, 2 * H, nullptr, nullptr, ph);
       if (rc) { printf("rc %d\n", rc); exit(1); }
     };
     hipMemset(out, getenv("K1_POISON") ? 0xff : 0, size_t(N) * 2 * H * 4);   // K1_POISON: unwritten elements stay NaN
@@ -160,8 +179,7 @@ int main(int argc, char** argv) {
     for (int ph : {3}) {
       for (int rep = 0; rep < 3; ++rep) {
         hipMemset(d_dbg, 0, size_t(waves) * 64);
-        uavgnn_gatv2_hetero_fwd_phases(d_xg, Es, d_so, d_ord, d_xu, En, d_no, d_xa, N, ps, pn, 4, 64, 0.2f, out, 2 * H,
-                                       reinterpret_cast<float*>(d_dbg), nullptr, ph | 1024, nullptr);
+        k1_call(d_xg, Es, d_so, d_ord, d_xu, En, d_no, d_xa, N, ps, pn, out, 2 * H, reinterpret_cast<float*>(d_dbg), nullptr, ph | 1024);
         hipDeviceSynchronize();
       }
       hipMemcpy(st.data(), d_dbg, st.size() * 8, hipMemcpyDeviceToHost);

@@ -37,6 +37,12 @@ SIGNATURES = {
     "uavgnn_gatv2_hetero_fwd_phases": (_c_int, [_c_fp, _c_int, _c_ip, _c_ip, _c_fp, _c_int, _c_ip, _c_fp, _c_int,
                                                 ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _c_int,
                                                 _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_st]),
+    "uavgnn_gatv2_hetero_image_bytes": (ctypes.c_size_t, []),
+    "uavgnn_gatv2_hetero_prepare": (_c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int,
+                                             _c_f32, _c_fp, _c_st]),
+    "uavgnn_gatv2_hetero_fwd_image": (_c_int, [_c_fp, _c_int, _c_ip, _c_ip, _c_fp, _c_int, _c_ip, _c_fp, _c_int,
+                                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _c_int,
+                                               _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_st]),
     "uavgnn_gatv2_bwd_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
     "uavgnn_gatv2_bwd": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                   _c_int, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
@@ -109,6 +115,7 @@ SIGNATURES = {
 }
 
 _LIB = None
+UAVGNN_EINVAL = -1000
 UAVGNN_EUNSUPPORTED = -1001
 
 

@@ -133,6 +133,7 @@ __device__ __forceinline__ void store_piece(float* base, unsigned lane_off, f32x
 }
 #define K1_TOUCH(x) asm volatile("" ::"v"(x))
 
+
 __device__ __forceinline__ float rl(float v, int lane) {
   return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
 }
@@ -232,23 +233,144 @@ __device__ __forceinline__ int k1_part(int order, bool tiles_first, int step) {
   return tiles_first ? (step == 0 ? K1_TILES : step == 1 ? K1_SEEN : K1_NEAR) : (step == 0 ? K1_SEEN : step == 1 ? K1_TILES : K1_NEAR);
 }
 
+// What a workgroup needs from the parameters of the two GATv2Conv modules, in the layout its LDS holds it: the bf16 A operands of
+// the score tiles of both phases and of the `near` epilogue product ([set][channel tile][lane]), the fp32 operands of phase S's
+// lane <-> channel prologue / epilogue, the attention vectors x log2(e) (1 - slope) / 2 and wa[rel][k][f] = log2(e) (1 + slope) /
+// 2 x sum_d attn[k,d] W_s[k,d,f].  Built by every workgroup in its prologue (k1_build_image) - or ONCE by
+// uavgnn_gatv2_hetero_prepare into a caller-provided buffer that the workgroups only copy (one round trip instead of one round
+// trip + ~200 VALU per wavefront: 2.9 -> 1.x us of a 20-us rollout launch; worth it when the same weights serve many launches).
+struct K1Image {
+  k1_u32x4 A[kSets][CT * kWave];
+  float Ws[H * FS_S];                  // fc_src.weight of `seen`, row-major [H, 4]
+  float Wds[H * 2], Wrs[H * 2];        // seen fc_dst / res_fc
+  float Bss[H], Bds[H], Brs[H];        // seen biases (b_r: 0 when absent)
+  float As[H], An[H];
+  float Wa[2][NH * 4];
+};
+static_assert(sizeof(K1Image) % 16 == 0, "copied in 16-byte pieces");
+
+// The image is built in two halves so that a caller can put its own dependent loads between them: k1_load_raw issues every
+// global load (branch-free: ONE round trip; a version with `if (tid < ...)` blocks and null-pointer branches around the loads
+// cost ten dependent round trips = 4 us of a 20-us launch), k1_store_image converts and writes LDS with unconditional stores.
+struct K1Raw {
+  f32x4 ws, wd, wr;
+  float as, an, bs, bd, br;
+  float wa_a[4], wa_w[4];
+  float w[2 * kSets], b[2 * kSets];   // 3 sets x 1024 entries over 512 threads: weight and bias of entry q * 512 + tid
+};
+
+__device__ __forceinline__ K1Raw k1_load_raw(const RelParams& ps, const RelParams& pn, int tid) {
+  K1Raw r;
+  const float* const brs_p = ps.b_r != nullptr ? ps.b_r : ps.b_s;   // res_fc.bias may be absent: any valid address, scaled by 0
+  const float* const brn_p = pn.b_r != nullptr ? pn.b_r : pn.b_s;
+  const float brn_on = pn.b_r != nullptr ? 1.f : 0.f;
+  const int t256 = tid & 255, t128 = tid & 127;
+  r.ws = reinterpret_cast<const f32x4*>(ps.W_s)[t256];
+  r.wd = reinterpret_cast<const f32x4*>(ps.W_d)[t128];
+  r.wr = reinterpret_cast<const f32x4*>(ps.W_r)[t128];
+  r.as = ps.attn[t256];
+  r.an = pn.attn[t256];
+  r.bs = ps.b_s[t256];
+  r.bd = ps.b_d[t256];
+  r.br = brs_p[t256];
+  // wa[rel][k][f]: 2 x 16 outputs, 16 partial sums of 4 terms each; 512 threads = 32 rows of 16 lanes
+  const int wa_kf = tid >> 4, wa_part = tid & 15;
+  const int wa_rel = wa_kf >> 4, wa_k = (wa_kf >> 2) & 3, wa_f = wa_kf & 3;
+  {
+    const float* at = wa_rel ? pn.attn : ps.attn;
+    const float* ws = wa_rel ? pn.W_s : ps.W_s;
+    const int F = wa_rel ? FS_N : FS_S, f = min(wa_f, F - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = wa_k * D + wa_part + 16 * i;
+      r.wa_a[i] = at[d];
+      r.wa_w[i] = ws[d * F + f];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2 * kSets; ++q) {
+    const int idx = (q & 1) * kThreads + tid;
+    const int row = (idx >> 6) * 16 + (idx & 15), gg = (idx >> 4) & 3;
+    if ((q >> 1) == kSetSeen) {
+      r.w[q] = ps.W_s[row * FS_S + gg];
+      r.b[q] = 0.f;
+    } else if ((q >> 1) == kSetNear) {   // A = [W_s | W_d], the channel bias b_s + b_d in the free slots of K groups 0 / 1
+      r.w[q] = *(gg < 2 ? pn.W_s + row * FS_N + gg : pn.W_d + row * 2 + gg - 2);
+      r.b[q] = pn.b_s[row] + pn.b_d[row];
+    } else {   // epilogue of `near`: A = [W_s | W_r]; b_s against `has` in K groups 0 / 1, b_r against 1 in groups 2 / 3
+      r.w[q] = *(gg < 2 ? pn.W_s + row * FS_N + gg : pn.W_r + row * 2 + gg - 2);
+      r.b[q] = *(gg < 2 ? pn.b_s + row : brn_p + row) * (gg < 2 ? 1.f : brn_on);
+    }
+  }
+  return r;
+}
+
+// unconditional stores (two / four threads write the same value to the same word): no branch, no pessimistic wait
+__device__ __forceinline__ void k1_store_image(K1Image& sI, const K1Raw& r, bool seen_res_bias, float slope, int tid) {
+  const float c_abs = kLog2e * 0.5f * (1.f - slope), c_lin = kLog2e * 0.5f * (1.f + slope);
+  const int t256 = tid & 255, t128 = tid & 127;
+  reinterpret_cast<f32x4*>(sI.Ws)[t256] = r.ws;
+  reinterpret_cast<f32x4*>(sI.Wds)[t128] = r.wd;
+  reinterpret_cast<f32x4*>(sI.Wrs)[t128] = r.wr;
+  sI.As[t256] = c_abs * r.as;
+  sI.An[t256] = c_abs * r.an;
+  sI.Bss[t256] = r.bs;
+  sI.Bds[t256] = r.bd;
+  sI.Brs[t256] = seen_res_bias ? r.br : 0.f;
+  {
+    const int wa_kf = tid >> 4, wa_part = tid & 15;
+    const int wa_rel = wa_kf >> 4, wa_f = wa_kf & 3;
+    float a0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a0 = fmaf(r.wa_a[i], r.wa_w[i], a0);
+    a0 = row16_sum(a0);
+    if (wa_part == 0) sI.Wa[wa_rel][wa_kf & 15] = (wa_f < (wa_rel ? FS_N : FS_S)) ? c_lin * a0 : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < 2 * kSets; ++q) {
+    const int idx = (q & 1) * kThreads + tid;
+    const int gg = (idx >> 4) & 3;
+    const int set = q >> 1;
+    const int part = set == kSetSeen ? 0 : set == kSetNear ? (gg == 0 ? 1 : gg == 1 ? 2 : 0) : ((gg & 1) ? 2 : 1);
+    sI.A[set][idx] = k1_a_operand(r.w[q], r.b[q], part);
+  }
+}
+
+// One workgroup builds the image in LDS exactly as the forward's prologue does and copies it out.
+__global__ __launch_bounds__(kThreads) void gatv2_hetero_prepare_kernel(RelParams ps, RelParams pn, float slope,
+                                                                        k1_u32x4* __restrict__ image) {
+  __shared__ K1Image sI;
+  const K1Raw raw = k1_load_raw(ps, pn, threadIdx.x);
+  k1_store_image(sI, raw, ps.b_r != nullptr, slope, threadIdx.x);
+  __syncthreads();
+  const k1_u32x4* src = reinterpret_cast<const k1_u32x4*>(&sI);
+  for (int i = threadIdx.x; i < static_cast<int>(sizeof(K1Image) / 16); i += kThreads) image[i] = src[i];
+}
+
 // SAVE: the attention weights of both relations are written for the backward pass (training forwards); the inference
 // instantiation does not carry them through the block.
-template <bool SAVE>
+// IMG: the parameter image is copied from `image` (uavgnn_gatv2_hetero_prepare) instead of built (a template parameter, not a
+// branch: behind a run-time branch the compiler merges the load counts of the two sides pessimistically and the prologue waits
+// for its first round trip before it issues the second).
+template <bool SAVE, bool IMG>
 __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     const float* __restrict__ x_gt, const int32_t* __restrict__ seen_off, const int32_t* __restrict__ seen_order,
     const float* __restrict__ x_ubs, const int32_t* __restrict__ near_off, const float* __restrict__ x_dst, int N,
     int E_seen, RelParams ps, RelParams pn, float slope, float* __restrict__ out, int ld_out, float* __restrict__ a_save_s,
-    float* __restrict__ a_save_n_arg, int phases) {
+    float* __restrict__ a_save_n_arg, int phases, const k1_u32x4* __restrict__ image) {
   float* const a_save_n = SAVE ? a_save_n_arg : nullptr;
-  // prepared bf16 A operands, [set][channel tile][lane]: 64 KB
-  __shared__ __attribute__((aligned(16))) k1_u32x4 sA[kSets][CT * kWave];
-  // operands of phase S's lane <-> channel prologue / epilogue (read once per destination)
-  __shared__ __attribute__((aligned(16))) float sWs[H * FS_S];     // fc_src.weight of `seen`, row-major [H, 4]
-  __shared__ __attribute__((aligned(16))) float sWds[H * 2], sWrs[H * 2];   // seen fc_dst / res_fc
-  __shared__ __attribute__((aligned(16))) float sBss[H], sBds[H], sBrs[H];   // seen biases (b_r: 0 when absent)
-  __shared__ __attribute__((aligned(16))) float sAs[H], sAn[H];     // attention vectors x log2(e) (1 - slope) / 2
-  __shared__ float sWa[2][NH * 4];                                  // log2(e) (1 + slope) / 2 x sum_d attn[k,d] W_s[k,d,f] per relation
+  // everything a workgroup needs from the parameters (K1Image, 61 KB): built here, or copied from a caller-provided image
+  __shared__ K1Image sI;
+  auto& sA = sI.A;
+  auto& sWs = sI.Ws;
+  auto& sWds = sI.Wds;
+  auto& sWrs = sI.Wrs;
+  auto& sBss = sI.Bss;
+  auto& sBds = sI.Bds;
+  auto& sBrs = sI.Brs;
+  auto& sAs = sI.As;
+  auto& sAn = sI.An;
+  auto& sWa = sI.Wa;
   __shared__ __attribute__((aligned(16))) float sC[kWavesPerBlock][H];   // phase S: destination term; phase N: aggregate hand-over
   __shared__ __attribute__((aligned(16))) float sRow[kWavesPerBlock][16 * kBounceLd];   // phase N: output rows of one pass
   __shared__ int sS[kWavesPerBlock][3 * kWave];   // first hand-out chunk of phase S, requested in the prologue (+ the upper half of sC)
@@ -259,7 +381,6 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
   const int j = lane & 15;          // MFMA column (edge slot / destination of the block) / A row
   const int g = lane >> 4;          // lane group: K group of the A / B operands, head after the reduction
 
-  const float c_abs = kLog2e * 0.5f * (1.f - slope), c_lin = kLog2e * 0.5f * (1.f + slope);
   const int stride = gridDim.x * kWavesPerBlock;
   const int it0 = blockIdx.x * kWavesPerBlock + wave;
   const int nblk = (N + 15) >> 4;   // blocks of 16 destinations (phase N)
@@ -299,91 +420,64 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
   const int s_it = min(it0 + lane * stride, N - 1);
   const int p_v = seen_order != nullptr ? seen_order[s_it] : s_it;
 
-  // ---- workgroup prologue: constants and prepared A operands into LDS ------------------------------------------------
-  // Branch-free, every global load issued before anything waits (ONE round trip; a version with `if (tid < ...)` blocks and
-  // null-pointer branches around the loads cost ten dependent round trips = 4 us of a 20-us launch).
-  const float* const brs_p = ps.b_r != nullptr ? ps.b_r : ps.b_s;   // res_fc.bias may be absent: any valid address, scaled by 0
-  const float* const brn_p = pn.b_r != nullptr ? pn.b_r : pn.b_s;
-  const float brs_on = ps.b_r != nullptr ? 1.f : 0.f, brn_on = pn.b_r != nullptr ? 1.f : 0.f;
-  const int t256 = tid & 255, t128 = tid & 127;
-  const float4 l_ws = reinterpret_cast<const float4*>(ps.W_s)[t256];
-  const float4 l_wd = reinterpret_cast<const float4*>(ps.W_d)[t128], l_wr = reinterpret_cast<const float4*>(ps.W_r)[t128];
-  const float l_as = ps.attn[t256], l_an = pn.attn[t256], l_bs = ps.b_s[t256], l_bd = ps.b_d[t256], l_br = brs_p[t256];
-  // wa[rel][k][f]: 2 x 16 outputs, 16 partial sums of 4 terms each; 512 threads = 32 rows of 16 lanes
-  const int wa_kf = tid >> 4, wa_part = tid & 15;
-  const int wa_rel = wa_kf >> 4, wa_k = (wa_kf >> 2) & 3, wa_f = wa_kf & 3;
-  float l_wa_a[4], l_wa_w[4];
-  {
-    const float* at = wa_rel ? pn.attn : ps.attn;
-    const float* ws = wa_rel ? pn.W_s : ps.W_s;
-    const int F = wa_rel ? FS_N : FS_S, f = min(wa_f, F - 1);
+  // ---- workgroup prologue: the parameter image into LDS ------------------------------------------------------------------
+  __builtin_amdgcn_sched_barrier(0);   // order pinned: meta data (head of the dependent chain), parameters, dependent loads
+  // First half: every load that does not depend on another one.  With a prepared image (uavgnn_gatv2_hetero_prepare) that is a
+  // copy, 8 x 16 bytes per thread; else the parameters themselves.
+  constexpr int kPieces = sizeof(K1Image) / 16, kPer = (kPieces + kThreads - 1) / kThreads;
+  k1_u32x4 piece[kPer];
+  K1Raw raw;
+  if constexpr (IMG) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d = wa_k * D + wa_part + 16 * i;
-      l_wa_a[i] = at[d];
-      l_wa_w[i] = ws[d * F + f];
-    }
+    for (int i = 0; i < kPer; ++i) piece[i] = image[min(tid + i * kThreads, kPieces - 1)];
+  } else {
+    raw = k1_load_raw(ps, pn, tid);
   }
-  float l_w[2 * kSets], l_b[2 * kSets];   // 3 sets x 1024 entries over 512 threads: weight and bias of entry q * 512 + tid
-#pragma unroll
-  for (int q = 0; q < 2 * kSets; ++q) {
-    const int idx = (q & 1) * kThreads + tid;
-    const int row = (idx >> 6) * 16 + (idx & 15), gg = (idx >> 4) & 3;
-    if ((q >> 1) == kSetSeen) {
-      l_w[q] = ps.W_s[row * FS_S + gg];
-      l_b[q] = 0.f;
-    } else if ((q >> 1) == kSetNear) {   // A = [W_s | W_d], the channel bias b_s + b_d in the free slots of K groups 0 / 1
-      l_w[q] = *(gg < 2 ? pn.W_s + row * FS_N + gg : pn.W_d + row * 2 + gg - 2);
-      l_b[q] = pn.b_s[row] + pn.b_d[row];
-    } else {   // epilogue of `near`: A = [W_s | W_r]; b_s against `has` in K groups 0 / 1, b_r against 1 in groups 2 / 3
-      l_w[q] = *(gg < 2 ? pn.W_s + row * FS_N + gg : pn.W_r + row * 2 + gg - 2);
-      l_b[q] = *(gg < 2 ? pn.b_s + row : brn_p + row) * (gg < 2 ? 1.f : brn_on);
-    }
-  }
-  load_edges(mnext, min(it0, nblk - 1), 0);   // needs the meta data requested first: the one dependent round trip
+  __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks the parameter loads below the wait for the meta data)
+  // the one dependent round trip: needs the meta data requested first
+  load_edges(mnext, min(it0, nblk - 1), 0);
   const int p_e0 = seen_off[p_v], p_e1 = seen_off[p_v + 1];
   const float2 p_xv = *reinterpret_cast<const float2*>(x_dst + 2 * p_v);
-  // unconditional stores (two / four threads write the same value to the same word): no branch, no pessimistic wait
-  reinterpret_cast<float4*>(sWs)[t256] = l_ws;
-  reinterpret_cast<float4*>(sWds)[t128] = l_wd;
-  reinterpret_cast<float4*>(sWrs)[t128] = l_wr;
-  sAs[t256] = c_abs * l_as;
-  sAn[t256] = c_abs * l_an;
-  sBss[t256] = l_bs;
-  sBds[t256] = l_bd;
-  sBrs[t256] = l_br * brs_on;
-  {
-    float a0 = 0.f;
+  // second half: the image into LDS
+  if constexpr (IMG) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a0 = fmaf(l_wa_a[i], l_wa_w[i], a0);
-    a0 = row16_sum(a0);
-    if (wa_part == 0) sWa[wa_rel][wa_kf & 15] = (wa_f < (wa_rel ? FS_N : FS_S)) ? c_lin * a0 : 0.f;
+    for (int i = 0; i < kPer; ++i) reinterpret_cast<k1_u32x4*>(&sI)[min(tid + i * kThreads, kPieces - 1)] = piece[i];
+  } else {
+    k1_store_image(sI, raw, ps.b_r != nullptr, slope, tid);
   }
-#pragma unroll
-  for (int q = 0; q < 2 * kSets; ++q) {
-    const int idx = (q & 1) * kThreads + tid;
-    const int gg = (idx >> 4) & 3;
-    const int set = q >> 1;
-    const int part = set == kSetSeen ? 0 : set == kSetNear ? (gg == 0 ? 1 : gg == 1 ? 2 : 0) : ((gg & 1) ? 2 : 1);
-    sA[set][idx] = k1_a_operand(l_w[q], l_b[q], part);
-  }
-  __syncthreads();
+  // Workgroup barrier WITHOUT the memory fence of __syncthreads() (s_waitcnt vmcnt(0)): only the LDS image has to be complete.
+  // The second round trip of the prologue - first-pass edges of phase N, segment bounds of phase S - stays in flight behind the
+  // barrier, and the residual-only `seen` rows (which need the destination meta data only) are on their way one round trip
+  // earlier.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
   K1_STAMP(1)
-  {   // per-wave hand-over (read back by this wavefront only): after the barrier, so that no wavefront holds the others up
+  // per-wave hand-over of phase S's first chunk (read back by this wavefront only), stored where the second round trip is
+  // waited for anyway: in front of the first score tiles, or in front of phase S when the wavefront has no block
+  auto stash = [&] {
     int* st = reinterpret_cast<int*>(sC[wave]) + 2 * kWave;
     st[lane] = p_v;
     st[kWave + lane] = p_e0;
     sS[wave][lane] = p_e1;
     sS[wave][kWave + lane] = __float_as_int(p_xv.x);
     sS[wave][2 * kWave + lane] = __float_as_int(p_xv.y);
-  }
+  };
+  const bool phase_n = (phases & 2) && it0 < nblk;
+  if (!phase_n) stash();
+
+  const bool phase_s = it0 < N && (phases & 1) && E_seen > 0;
+  // (Requesting phase S's first tile from inside phase N, in front of the `near` row stores of the wavefront's last block, was
+  // measured: +0.5 us on a rollout launch - the loads queue behind 33 MB of stores and the wait for them is no shorter.  So was
+  // running the phases in opposite order on the two wavefronts of a SIMD: +2.5 us - phase S's loads crawl while the other
+  // wavefronts' rows fill the store queues, and the registers kept across the phase loop spill.)
 
   float* __restrict__ cw = sC[wave];
   const f32x4 czero = {0.f, 0.f, 0.f, 0.f};
 
   // ====== phase N: `near` + residual-only `seen` rows on blocks of 16 destinations (column j <-> destination) ========
   // Runs BEFORE phase S: it writes 2 KB per destination, and its row stores drain while phase S computes.
-  if ((phases & 2) && it0 < nblk) {
+  if (phase_n) {
     const unsigned one_tile = g == 0 ? 0x3F803F80u : g == 1 ? 0x00003F80u : 0u;   // bf16 1.0 against the bias slots of the A operand
     float* __restrict__ rw = sRow[wave];
     const int half = lane >> 5, c16 = lane & 31;   // row stores: destination 2i + half of the block, 16-byte chunk c16 of the pass
@@ -465,8 +559,6 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
         }
       };
 
-#pragma unroll
-      for (int u = 0; u < UB; ++u) K1_TOUCH(xu[u].x);   // in flight since the previous block (or the prologue): landed before the first store
       float m = -INFINITY, den = 0.f, s0 = 0.f, s1 = 0.f;
       float pw[UB];
       // Order of the three parts of a block - K1_SEEN: residual-only `seen` rows (store-bound), K1_TILES: score tiles + softmax
@@ -504,6 +596,9 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
           // A operands and attention vector of the score tiles: (re)read from LDS per block - 32 ds_read_b128 - instead of held
           // across the row-store parts of the block, whose LDS round trips want the registers (the opaque lane index keeps the
           // compiler from hoisting the reads out of the block loop)
+#pragma unroll
+          for (int u = 0; u < UB; ++u) K1_TOUCH(xu[u].x);   // in flight since the previous block (or the prologue): landed before the row stores of `near`
+          if (blk == it0) stash();
           int lane_v = lane;
           asm volatile("" : "+v"(lane_v));
           k1_u32x4 Wa[CT];
@@ -602,7 +697,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
   }
 
   // =========================== phase S: `seen` on the destinations that have in-edges ===============================
-  if (it0 < N && (phases & 1) && E_seen > 0) {
+  if (phase_s) {
     k1_u32x4 Wa[CT];
     float att[CT][4], wlin[NH];
 #pragma unroll
@@ -622,6 +717,8 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     // ALWAYS exactly two loads (clamped address, never predicated): a predicated load makes the number of outstanding
     // loads unknown to the compiler, which then drains the queue (s_waitcnt vmcnt(0)) right behind the request - the
     // prefetch would not overlap anything.  Columns j >= count read edge row 0; they are masked out of the softmax.
+    // (A queue of two / three / four tiles in flight filled by an independent cursor, with the C operands re-read from LDS per
+    // tile to pay for its registers, was measured: D-env rollout 20.1 vs 19.3 us, D-dense phase S 94 vs 79 us.)
     auto request = [&](const int e_first, const int count) {   // columns j < count of the tile starting at edge e_first
       const size_t u = (j < count) ? static_cast<size_t>(e_first + j) : 0;
       xr = *reinterpret_cast<const float4*>(x_gt + u * FS_S);
@@ -765,26 +862,29 @@ extern "C" int uavgnn_gatv2_hetero_supported(int F_seen, int F_near, int F_dst, 
   return (F_seen == FS_S && F_near == FS_N && F_dst == 2 && nh == NH && D == ::uavgnn::D) ? 1 : 0;
 }
 
-// phases: bit 0 = phase S, bit 1 = phase N (3 = the kernel; 1 / 2 are benchmark ablations, tools/kbench_hetero.py);
-// bit 8 (UAVGNN_K1_FP32_MFMA) = the round 1-3 kernel with the score GEMM on fp32 MFMA (csrc/gatv2_hetero_f32.hip).
-extern "C" int uavgnn_gatv2_hetero_fwd_phases(const float* x_gt, int E_seen, const int32_t* seen_off,
-                                              const int32_t* seen_order, const float* x_ubs, int E_near,
-                                              const int32_t* near_off, const float* x_dst, int N,
-                                              const float* const* seen_params, const float* const* near_params, int nh,
-                                              int D_, float slope, float* out, int ld_out, float* attn_save_seen,
-                                              float* attn_save_near, int phases, uavgnn_stream_t stream) {
-  if (N < 0 || E_seen < 0 || E_near < 0 || (E_seen > 0 && !x_gt) || (E_near > 0 && !x_ubs) || !seen_off || !near_off ||
-      !x_dst || !seen_params || !near_params || !out || ld_out < 2 * nh * D_)
-    return UAVGNN_EINVAL;
-  if (!uavgnn_gatv2_hetero_supported(FS_S, FS_N, 2, nh, D_) || (ld_out & 3) ||
-      (reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(x_gt) & 15) ||
-      (reinterpret_cast<uintptr_t>(x_ubs) & 7) || (reinterpret_cast<uintptr_t>(x_dst) & 7))
-    return UAVGNN_EUNSUPPORTED;
+static int check_params(const float* const* seen_params, const float* const* near_params) {
+  if (!seen_params || !near_params) return UAVGNN_EINVAL;
   for (int i = 0; i < 6; ++i)
     if (!seen_params[i] || !near_params[i]) return UAVGNN_EINVAL;
   for (int i = 0; i < 7; ++i)   // parameters are fetched with 16-byte loads
     if ((reinterpret_cast<uintptr_t>(seen_params[i]) & 15) || (reinterpret_cast<uintptr_t>(near_params[i]) & 15))
       return UAVGNN_EUNSUPPORTED;
+  return 0;
+}
+
+static int k1_launch(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order, const float* x_ubs,
+                     int E_near, const int32_t* near_off, const float* x_dst, int N, const float* const* seen_params,
+                     const float* const* near_params, int nh, int D_, float slope, float* out, int ld_out,
+                     float* attn_save_seen, float* attn_save_near, const void* image, int phases, uavgnn_stream_t stream) {
+  if (N < 0 || E_seen < 0 || E_near < 0 || (E_seen > 0 && !x_gt) || (E_near > 0 && !x_ubs) || !seen_off || !near_off ||
+      !x_dst || !out || ld_out < 2 * nh * D_)
+    return UAVGNN_EINVAL;
+  if (!uavgnn_gatv2_hetero_supported(FS_S, FS_N, 2, nh, D_) || (ld_out & 3) ||
+      (reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(x_gt) & 15) ||
+      (reinterpret_cast<uintptr_t>(x_ubs) & 7) || (reinterpret_cast<uintptr_t>(x_dst) & 7) ||
+      (reinterpret_cast<uintptr_t>(image) & 15))
+    return UAVGNN_EUNSUPPORTED;
+  if (const int rc = check_params(seen_params, near_params)) return rc;
   if (N == 0) return 0;
   if (E_near == 0) x_ubs = x_dst;   // masked slots read row 0 of x_ubs: any valid address will do when there are no edges
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -799,15 +899,62 @@ extern "C" int uavgnn_gatv2_hetero_fwd_phases(const float* x_gt, int E_seen, con
 #if K1_ABLATE
   if (const char* gs = getenv("K1_GRID")) grid = atoi(gs);
 #endif
-  if (attn_save_near != nullptr)
-    hipLaunchKernelGGL(gatv2_hetero_fwd_kernel<true>, dim3(grid), dim3(kThreads), 0, st, x_gt, seen_off, seen_order, x_ubs, near_off,
-                       x_dst, N, E_seen, ps, pn, slope, out, ld_out, attn_save_seen, attn_save_near,
-                       K1_ABLATE ? phases : (phases & 3));
-  else
-    hipLaunchKernelGGL(gatv2_hetero_fwd_kernel<false>, dim3(grid), dim3(kThreads), 0, st, x_gt, seen_off, seen_order, x_ubs, near_off,
-                       x_dst, N, E_seen, ps, pn, slope, out, ld_out, attn_save_seen, attn_save_near,
-                       K1_ABLATE ? phases : (phases & 3));
+  const k1_u32x4* img = static_cast<const k1_u32x4*>(image);
+  const int ph = K1_ABLATE ? phases : (phases & 3);
+  auto launch = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, st, x_gt, seen_off, seen_order, x_ubs, near_off, x_dst, N, E_seen, ps,
+                       pn, slope, out, ld_out, attn_save_seen, attn_save_near, ph, img);
+  };
+  if (attn_save_near != nullptr) {
+    if (img != nullptr) launch(gatv2_hetero_fwd_kernel<true, true>); else launch(gatv2_hetero_fwd_kernel<true, false>);
+  } else {
+    if (img != nullptr) launch(gatv2_hetero_fwd_kernel<false, true>); else launch(gatv2_hetero_fwd_kernel<false, false>);
+  }
   return launch_status();
+}
+
+// phases: bit 0 = phase S, bit 1 = phase N (3 = the kernel; 1 / 2 are benchmark ablations, tools/kbench_hetero.py);
+// bit 8 (UAVGNN_K1_FP32_MFMA) = the round 1-3 kernel with the score GEMM on fp32 MFMA (csrc/gatv2_hetero_f32.hip).
+extern "C" int uavgnn_gatv2_hetero_fwd_phases(const float* x_gt, int E_seen, const int32_t* seen_off,
+                                              const int32_t* seen_order, const float* x_ubs, int E_near,
+                                              const int32_t* near_off, const float* x_dst, int N,
+                                              const float* const* seen_params, const float* const* near_params, int nh,
+                                              int D_, float slope, float* out, int ld_out, float* attn_save_seen,
+                                              float* attn_save_near, int phases, uavgnn_stream_t stream) {
+  return k1_launch(x_gt, E_seen, seen_off, seen_order, x_ubs, E_near, near_off, x_dst, N, seen_params, near_params, nh, D_,
+                   slope, out, ld_out, attn_save_seen, attn_save_near, nullptr, phases, stream);
+}
+
+extern "C" size_t uavgnn_gatv2_hetero_image_bytes(void) { return sizeof(K1Image); }
+
+// The parameter image of the two modules (K1Image), built once for any number of uavgnn_gatv2_hetero_fwd_image launches with the
+// same parameter VALUES and slope.  The caller owns the buffer (16-byte aligned, uavgnn_gatv2_hetero_image_bytes()) and its
+// validity: an image is stale the moment a parameter changes.
+extern "C" int uavgnn_gatv2_hetero_prepare(const float* const* seen_params, const float* const* near_params, int nh, int D_,
+                                           float slope, void* image, uavgnn_stream_t stream) {
+  if (!image) return UAVGNN_EINVAL;
+  if (!uavgnn_gatv2_hetero_supported(FS_S, FS_N, 2, nh, D_) || (reinterpret_cast<uintptr_t>(image) & 15))
+    return UAVGNN_EUNSUPPORTED;
+  if (const int rc = check_params(seen_params, near_params)) return rc;
+  RelParams ps{seen_params[0], seen_params[1], seen_params[2], seen_params[3], seen_params[4], seen_params[5], seen_params[6]};
+  RelParams pn{near_params[0], near_params[1], near_params[2], near_params[3], near_params[4], near_params[5], near_params[6]};
+  hipLaunchKernelGGL(gatv2_hetero_prepare_kernel, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream), ps, pn, slope,
+                     static_cast<k1_u32x4*>(image));
+  return launch_status();
+}
+
+// uavgnn_gatv2_hetero_fwd with the parameters taken from a prepared image (the parameter arrays are still required: they select
+// nothing on this path but keep the fp32-MFMA A/B route and the argument checks identical).  Bit-identical results.
+extern "C" int uavgnn_gatv2_hetero_fwd_image(const float* x_gt, int E_seen, const int32_t* seen_off,
+                                             const int32_t* seen_order, const float* x_ubs, int E_near,
+                                             const int32_t* near_off, const float* x_dst, int N,
+                                             const float* const* seen_params, const float* const* near_params, int nh,
+                                             int D_, float slope, const void* image, float* out, int ld_out,
+                                             float* attn_save_seen, float* attn_save_near, int phases,
+                                             uavgnn_stream_t stream) {
+  if (!image) return UAVGNN_EINVAL;
+  return k1_launch(x_gt, E_seen, seen_off, seen_order, x_ubs, E_near, near_off, x_dst, N, seen_params, near_params, nh, D_,
+                   slope, out, ld_out, attn_save_seen, attn_save_near, image, phases, stream);
 }
 
 extern "C" int uavgnn_gatv2_hetero_fwd(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order,

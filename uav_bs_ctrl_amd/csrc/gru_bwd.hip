@@ -53,6 +53,7 @@ extern "C" long long uavgnn_workspace_bytes(int kind, long long a, long long b, 
       const int S = uavgnn_gemm_tn_x3_chunks(a, static_cast<int>(b), static_cast<int>(c));
       return 4LL * S * b * c;
     }
+    case UAVGNN_WS_K1_IMAGE: return static_cast<long long>(uavgnn_gatv2_hetero_image_bytes());
     default: return 0;
   }
 }

@@ -143,6 +143,7 @@ class GraphedUpdate:
         for dst, src in zip((learner.flat.flat, learner.flat_target, learner.optimizer.m, learner.optimizer.v,
                              learner.optimizer.hyper), snap):
             dst.copy_(src)
+        learner.invalidate_weight_cache()
 
     def _body(self) -> Dict:
         return self.learner.update(self._batch())
@@ -176,4 +177,5 @@ class GraphedUpdate:
         if self.split:
             self.learner.grads.all_reduce_mean_(self.learner.group)
             self.graph_tail.replay()
+        self.learner.invalidate_weight_cache()   # the replay moved the parameters without passing through learner.apply()
         return self.out

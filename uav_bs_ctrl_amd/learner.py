@@ -141,6 +141,7 @@ class MultiAgentQLearner:
         if self.anneal_lr:
             self.lr_scheduler = th.optim.lr_scheduler.LambdaLR(self.optimizer,
                                                                lr_lambda=lambda epoch: max(0.4, 1 - epoch / 100))
+        self._rollout_planes = {}     # ops.frozen_weights store of `act`
         self._gen = th.Generator(device=self.device)
         self._gen.manual_seed(int(getattr(args, "seed", 0)) + 7919 * (dist.get_rank() if dist.is_initialized() else 0))
 
@@ -163,7 +164,10 @@ class MultiAgentQLearner:
         """obs: HeteroBatch of B envs (B*n agents).  Returns (acts [B*n] int64 on device, h').  One epsilon draw per
         team, as in learner.py:75-78."""
         obs, h = obs.to(self.device), h.to(self.device)
-        logits, h = self.policy_net(obs, h)
+        # between two optimiser steps the policy's parameters stand still: weight planes / the K1 parameter image are built by
+        # the first rollout step and reused by the others (cleared by apply / load_checkpoint / invalidate_weight_cache)
+        with ops.frozen_weights(self._rollout_planes):
+            logits, h = self.policy_net(obs, h)
         N = logits.shape[0]
         B = N // self.n_agents
         if logits.is_cuda:
@@ -323,9 +327,18 @@ class MultiAgentQLearner:
             ops.GRAD_SINK = None
         return dict(LossQ=loss, QVals=agent_out.detach())      # QVals: the LAST chunk's (LossQ: the mean over all chunks)
 
+    def invalidate_weight_cache(self) -> None:
+        """Drops what ``act`` derived from the policy's parameters (bf16 weight planes, the K1 parameter image).  The learner
+        calls it wherever IT changes them (apply, load_checkpoint; graphs.GraphedUpdate after a replay); code that writes
+        ``policy_net`` parameters behind the learner's back (``p.data`` writes, raw-pointer kernels) must call it too -
+        ``load_state_dict`` / in-place torch ops are caught by the version counters in the cache keys."""
+        if self._rollout_planes is not None:     # None: no store across calls (every `act` builds its own)
+            self._rollout_planes.clear()
+
     def apply(self) -> None:
         """clip_grad_value_(policy_net.parameters(), 1) (the mixer is NOT clipped, learner.py:159) + AdamW step + polyak
         of target net / target mixer (learner.py:157-166)."""
+        self.invalidate_weight_cache()
         if self.fused_tail:     # one launch over the flat buffers
             if not self.flat.intact():
                 raise L.UavGnnError("a parameter was moved out of the learner's flat buffer (module.to() / p.data = ... "
@@ -361,6 +374,7 @@ class MultiAgentQLearner:
 
     def load_checkpoint(self, path: str) -> dict:
         ck = th.load(path, map_location=self.device)
+        self.invalidate_weight_cache()
         self.policy_net.load_state_dict(ck["model_state_dict"])
         self.target_net.load_state_dict(self.policy_net.state_dict())
         if "optimizer_state_dict" in ck:

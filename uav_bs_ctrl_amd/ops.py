@@ -11,6 +11,7 @@ import torch as th
 from . import _lib as L
 
 NEG_SLOPE = 0.2  # DGL GATv2Conv default, not overridden at gnn_agents.py:93-96
+K1_IMAGE = os.environ.get("UAVGNN_K1_IMAGE", "1") != "0"   # prepared parameter image inside frozen_weights() scopes (A/B switch)
 HETERO_FUSED = True   # K1 forward of both encoder relations in one launch (csrc/gatv2_hetero.hip); False: per relation
 # K1's score GEMM on the bf16 matrix cores (exact three-way splits: fp32-level accuracy); False: the fp32-MFMA build of the same
 # kernel (csrc/gatv2_hetero_f32.hip) - the A/B reference and the K1 part of bench.py's strict-fp32 leg
@@ -106,11 +107,26 @@ class _HeteroGATv2(th.autograd.Function):
             fused = fused and all(t.data_ptr() % 16 == 0 for t in p + ([b_r_c] if b_r_c is not None else []))
         if fused:
             (xs, so, oo, pS, brS, needS, aS, _, _), (xn, no, _, pN, brN, needN, aN, _, _) = prepared
+            lib, pa_s, pa_n = L.lib(), L.ptr_array(pS + [brS]), L.ptr_array(pN + [brN])
+            phases = 3 if K1_BF16Z else 3 | 256
+            image = None
+            if _PLANES is not None and K1_BF16Z and K1_IMAGE:
+                # the parameter image of the kernel's prologue, built once per scope instead of by every workgroup of every launch
+                # (csrc/gatv2_hetero.hip, K1Image: -0.85 us of a 20-us rollout launch).  Keyed by storage AND version counters.
+                ws = pS + pN + [t for t in (brS, brN) if t is not None]
+                key = ("k1img", nh, D) + tuple(t.data_ptr() for t in ws) + tuple(t._version for t in ws)
+                image = _cached_planes(key, lib.uavgnn_gatv2_hetero_image_bytes(), x_dst.device,
+                                       lambda buf: L.check(lib.uavgnn_gatv2_hetero_prepare(pa_s, pa_n, nh, D, NEG_SLOPE, buf.data_ptr(),
+                                                                                           L.stream()), "uavgnn_gatv2_hetero_prepare"),
+                                       keep=ws)
             with KERNEL_TIMER.span("gatv2_hetero_fwd", (xs.shape[0], xn.shape[0], N, int(needS), int(needN))):
-                rc = L.lib().uavgnn_gatv2_hetero_fwd_phases(L.ptr(xs), xs.shape[0], L.ptr(so), L.ptr(oo), L.ptr(xn), xn.shape[0],
-                                                            L.ptr(no), L.ptr(x_dst), N, L.ptr_array(pS + [brS]),
-                                                            L.ptr_array(pN + [brN]), nh, D, NEG_SLOPE, out.data_ptr(), R * H,
-                                                            L.ptr(aS), L.ptr(aN), 3 if K1_BF16Z else 3 | 256, L.stream())
+                head = (L.ptr(xs), xs.shape[0], L.ptr(so), L.ptr(oo), L.ptr(xn), xn.shape[0], L.ptr(no), L.ptr(x_dst), N, pa_s, pa_n,
+                        nh, D, NEG_SLOPE)
+                tail = (out.data_ptr(), R * H, L.ptr(aS), L.ptr(aN), phases, L.stream())
+                if image is not None:
+                    rc = lib.uavgnn_gatv2_hetero_fwd_image(*head, image.data_ptr(), *tail)
+                else:
+                    rc = lib.uavgnn_gatv2_hetero_fwd_phases(*head, *tail)
             if rc == L.UAVGNN_EUNSUPPORTED:
                 fused = False
             else:
@@ -317,19 +333,32 @@ def gru_cell_supported(inp, h) -> bool:
 
 GRU_X3 = os.environ.get("UAVGNN_GRU_X3", "1") != "0"   # the cell's GEMMs as bf16x3 splits on the bf16 matrix cores (csrc/gru_x3.hip)
 
-# bf16 planes of weight matrices, reused ONLY inside a `frozen_weights()` scope.  A drop-in module's weights may change behind
-# any cache (`.data` writes bump no version counter), so by default every call splits its weights again (3-5 us, one launch).
-# The learner's loss forward + backward is one call during which nobody can touch the parameters: 101 recurrent steps and 51
-# backward steps share their planes there (~250 launches, ~1.1 ms of a C3 cycle).
+# bf16 planes of weight matrices (and the parameter image of the fused K1 forward), reused ONLY inside a `frozen_weights()`
+# scope.  A drop-in module's weights may change behind any cache (`.data` writes bump no version counter), so by default every
+# call splits its weights again (3-5 us, one launch).  The learner's loss forward + backward is one call during which nobody
+# can touch the parameters: 101 recurrent steps and 51 backward steps share their planes there (~250 launches, ~1.1 ms of a C3
+# cycle).  A rollout between two optimiser steps is the other such interval: ``MultiAgentQLearner.act`` passes a store that
+# lives until the learner itself changes the parameters (``apply`` / ``load_checkpoint`` / ``invalidate_weight_cache``).
 _PLANES = None
+_PLANES_MAX = 128
 
 
 class frozen_weights:
-    """Scope in which the caller guarantees that no parameter changes: weight planes are built once per (storage, layout)."""
+    """Scope in which the caller guarantees that no parameter changes: weight planes are built once per (storage, layout).
+
+    ``store``: a dict owned by the caller that outlives the scope (entries are reused by later scopes over the same dict until
+    the caller clears it); default: a store that dies with the outermost scope."""
+
+    def __init__(self, store=None):
+        self.store = store
 
     def __enter__(self):
         global _PLANES
-        self.prev, _PLANES = _PLANES, ({} if _PLANES is None else _PLANES)
+        self.prev = _PLANES
+        if self.store is not None:
+            _PLANES = self.store
+        elif _PLANES is None:
+            _PLANES = {}
         return self
 
     def __exit__(self, *exc):
@@ -353,6 +382,8 @@ def _cached_planes(key, nbytes, device, build, keep=()):
     planes = th.empty(nbytes, dtype=th.uint8, device=device)
     build(planes)
     if _PLANES is not None:
+        if len(_PLANES) >= _PLANES_MAX:     # a long-lived store fed with temporaries (weights built by th.cat per call) must not grow without bound
+            _PLANES.clear()
         _PLANES[key] = (planes, tuple(keep))
     return planes
 
@@ -381,7 +412,7 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save, inp2=None, h2_out=Non
         with KERNEL_TIMER.span("gru_cell_fwd", (N, K_in, H, "bf16x3")):
             # the planes are rebuilt on every call outside a frozen_weights() scope: nothing observable tells when a drop-in
             # module's weights changed
-            planes = _cached_planes(("gru", W_ih.data_ptr(), W_hh.data_ptr(), K_in, H),
+            planes = _cached_planes(("gru", W_ih.data_ptr(), W_hh.data_ptr(), W_ih._version, W_hh._version, K_in, H),
                                     lib.uavgnn_gru_cell_x3_workspace_bytes(K_in, H), h.device,
                                     lambda p: L.check(lib.uavgnn_gru_split_weights(W_ih.data_ptr(), K_in, W_hh.data_ptr(), H,
                                                                                    p.data_ptr(), L.stream()),
@@ -512,7 +543,7 @@ def gemm_x3(a, W, transpose_w=False, bias=None, out=None, accumulate=False, relu
     if out is None:
         out = th.empty((M, n_out), dtype=th.float32, device=a.device)
     with KERNEL_TIMER.span("gemm_x3", (M, n_out, K)):
-        planes = _cached_planes(("mat", W.data_ptr(), W.stride(0), R, C, bool(transpose_w)), 6 * R * C, a.device,
+        planes = _cached_planes(("mat", W.data_ptr(), W._version, W.stride(0), R, C, bool(transpose_w)), 6 * R * C, a.device,
                                 lambda p: L.check(lib.uavgnn_split_bf16x3(W.data_ptr(), W.stride(0), R, C, int(transpose_w),
                                                                           p.data_ptr(), L.stream()), "uavgnn_split_bf16x3"),
                                 keep=(W,))
