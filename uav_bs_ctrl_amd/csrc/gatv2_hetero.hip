@@ -131,6 +131,14 @@ __device__ __forceinline__ void store_piece(float* base, unsigned lane_off, f32x
       : "v"(lane_off), "v"(v), "s"(base), "s"(lanes)
       : "vcc", "scc");
 }
+// ... and the same store for a block whose 16 destinations are all written (every block but the last of a ragged N): no EXEC
+// traffic, no mask arithmetic - 9 scalar instructions per store less
+__device__ __forceinline__ void store_piece_all(float* base, unsigned lane_off, f32x4 v) {
+  asm volatile("s_nop 4\n\t"
+               "global_store_dwordx4 %0, %1, %2" K1_STORE_FLAGS
+               :
+               : "v"(lane_off), "v"(v), "s"(base));
+}
 #define K1_TOUCH(x) asm volatile("" ::"v"(x))
 
 
@@ -548,11 +556,16 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
             f32x4 vals[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) vals[i] = *reinterpret_cast<const f32x4*>(rw + (2 * i + half) * kBounceLd + 4 * c16);
+            if (mask == 0xffffu) {   // wave-uniform
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const unsigned long long m64 = (((mask >> (2 * i)) & 1u) ? 0x00000000ffffffffull : 0ull) |
-                                             (((mask >> (2 * i + 1)) & 1u) ? 0xffffffff00000000ull : 0ull);
-              store_piece(row0 + static_cast<size_t>(2 * i) * ld_out + col0 + hp * 128, row_off, vals[i], m64);
+              for (int i = 0; i < 8; ++i) store_piece_all(row0 + static_cast<size_t>(2 * i) * ld_out + col0 + hp * 128, row_off, vals[i]);
+            } else {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const unsigned long long m64 = (((mask >> (2 * i)) & 1u) ? 0x00000000ffffffffull : 0ull) |
+                                               (((mask >> (2 * i + 1)) & 1u) ? 0xffffffff00000000ull : 0ull);
+                store_piece(row0 + static_cast<size_t>(2 * i) * ld_out + col0 + hp * 128, row_off, vals[i], m64);
+              }
             }
           }
           wave_sync_lds();   // the row buffer is rewritten by the next pass
