@@ -389,3 +389,50 @@ def test_weight_plane_cache_keeps_the_weights_it_is_keyed_on_alive():
         del w
         assert ref() is not None
     assert ref() is None
+
+
+def test_frozen_weights_store_outlives_the_scope_only_when_the_caller_owns_it():
+    """ops.frozen_weights(store): the learner's rollout store (MultiAgentQLearner.act) - entries survive the scope and are reused
+    by the next scope over the same dict until the owner clears it; a nested default scope shares it; a store that is fed with
+    never-repeating keys (weights built by th.cat per call) is bounded."""
+    from uav_bs_ctrl_amd import ops
+    built = []
+    build = lambda p: built.append(p.numel())  # noqa: E731
+    store = {}
+    with ops.frozen_weights(store):
+        a = ops._cached_planes(("w", 1), 16, "cpu", build)
+        with ops.frozen_weights():
+            assert ops._cached_planes(("w", 1), 16, "cpu", build) is a
+    assert ops._PLANES is None and len(store) == 1
+    with ops.frozen_weights(store):
+        assert ops._cached_planes(("w", 1), 16, "cpu", build) is a and built == [16]
+    store.clear()                                        # what learner.invalidate_weight_cache() does
+    with ops.frozen_weights(store):
+        assert ops._cached_planes(("w", 1), 16, "cpu", build) is not a and built == [16, 16]
+        for i in range(3 * ops._PLANES_MAX):
+            ops._cached_planes(("tmp", i), 4, "cpu", build)
+        assert len(store) <= ops._PLANES_MAX
+
+
+def test_learner_drops_its_rollout_cache_wherever_it_moves_the_parameters(tmp_path):
+    """MultiAgentQLearner keeps what `act` derived from the policy's parameters until apply / load_checkpoint /
+    invalidate_weight_cache (CPU harness: the store is exercised with a marker entry; the HIP path fills it itself)."""
+    import test_dp_gloo as dp
+    import uav_bs_ctrl_amd.learner as LM
+    saved = LM.agent_REGISTRY
+    try:
+        learner, batch = dp._learner(), dp._make_batch(0, 4)      # (the helper swaps the agent registry for its CPU stand-in)
+    finally:
+        LM.agent_REGISTRY = saved
+    learner._rollout_planes[("marker",)] = (th.zeros(1), ())
+    learner.update(batch)                                # accumulate -> apply
+    assert len(learner._rollout_planes) == 0
+    learner._rollout_planes[("marker",)] = (th.zeros(1), ())
+    path = str(tmp_path / "ck.pt")
+    learner.save_checkpoint(path, dict(epoch=0, t=0))
+    assert len(learner._rollout_planes) == 1             # saving moves nothing
+    learner.load_checkpoint(path)
+    assert len(learner._rollout_planes) == 0
+    learner._rollout_planes[("marker",)] = (th.zeros(1), ())
+    learner.invalidate_weight_cache()
+    assert len(learner._rollout_planes) == 0
