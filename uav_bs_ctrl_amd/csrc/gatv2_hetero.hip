@@ -331,9 +331,10 @@ template <bool SAVE, bool IMG>
 __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     const float* __restrict__ x_gt, const int32_t* __restrict__ seen_off, const int32_t* __restrict__ seen_order,
     const float* __restrict__ x_ubs, const int32_t* __restrict__ near_off, const float* __restrict__ x_dst, int N,
-    int E_seen, RelParams ps, RelParams pn, float slope, float* __restrict__ out, int ld_out, float* __restrict__ a_save_s,
+    int E_seen, RelParams ps, RelParams pn, float slope, float* __restrict__ out, int ld_out, float* __restrict__ a_save_s_arg,
     float* __restrict__ a_save_n_arg, int phases, const k1_u32x4* __restrict__ image) {
   float* const a_save_n = SAVE ? a_save_n_arg : nullptr;
+  float* a_save_s = SAVE ? a_save_s_arg : nullptr;   // (the host launches the SAVE instantiation when either buffer is given)
   // everything a workgroup needs from the parameters (K1Image, 61 KB): built here, or copied from a caller-provided image
   __shared__ K1Image sI;
   auto& sA = sI.A;
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
   const int it0 = blockIdx.x * kWavesPerBlock + wave;
   const int nblk = (N + 15) >> 4;   // blocks of 16 destinations (phase N)
 #if K1_ABLATE   // `phases` bit 10: per-wavefront time stamps (100 MHz s_memrealtime) into the buffer passed as attn_save_seen
-  unsigned long long* const dbg = (phases & 1024) ? reinterpret_cast<unsigned long long*>(a_save_s) : nullptr;
+  unsigned long long* const dbg = (phases & 1024) ? reinterpret_cast<unsigned long long*>(a_save_s_arg) : nullptr;
   if (phases & 1024) a_save_s = nullptr;
 #define K1_STAMP(i) if (dbg != nullptr && lane == 0) dbg[static_cast<size_t>(it0) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
 #else
@@ -678,6 +679,8 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
 
   // =========================== phase S: `seen` on the destinations that have in-edges ===============================
   if (phase_s) {
+    constexpr int kStashTiles = (16 * kBounceLd) / kWave;   // 33 row tiles = 528 in-edges fit the row buffer
+    float* __restrict__ srow = sRow[wave];
     k1_u32x4 Wa[CT];
     float att[CT][4], wlin[NH];
 #pragma unroll
@@ -735,7 +738,10 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
 #define K1_CINIT_S(ct) cinit[ct]
         UAVGNN_TILE_SCORE(Wa, att, K1_CINIT_S, wlin, xB, k1_b_operand(xB, 0u), e)
         if (valid) {
-          if (a_save_s != nullptr) a_save_s[static_cast<size_t>(ce0 + base + j) * NH + g] = e;
+          if (a_save_s != nullptr) {   // raw score now, weight once the maximum and the sum are final
+            if (base < 16 * kStashTiles) srow[(base >> 4) * kWave + lane] = e;     // ... parked in the wavefront's row buffer
+            else a_save_s[static_cast<size_t>(ce0 + base + j) * NH + g] = e;      // (more than 512 in-edges: through memory)
+          }
           const float mn = fmaxf(m, e);
           const float sc = __builtin_amdgcn_exp2f(m - mn);   // exp2(-inf) = 0 on the first edge
           const float p = __builtin_amdgcn_exp2f(e - mn);
@@ -757,10 +763,14 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
       sv[2] = row16_sum(s2 * scl) * inv;
       sv[3] = row16_sum(s3 * scl) * inv;
       if (a_save_s != nullptr) {
+        // The raw scores of a destination's tiles wait in the per-wave row buffer of phase N (free in this phase; each lane
+        // reads back what it wrote itself) instead of in a_save_s: written there and re-read for the normalisation they cost a
+        // store, a DEPENDENT load - an L2 round trip at the end of every destination - and a second store per tile.
         for (int base = 0; base < cdeg; base += 16) {
           if (base + j < cdeg) {
             float* ap = a_save_s + static_cast<size_t>(ce0 + base + j) * NH + g;
-            *ap = __builtin_amdgcn_exp2f(*ap - mx) * inv;
+            const float raw = base < 16 * kStashTiles ? srow[(base >> 4) * kWave + lane] : *ap;
+            *ap = __builtin_amdgcn_exp2f(raw - mx) * inv;
           }
         }
       }
@@ -885,7 +895,7 @@ static int k1_launch(const float* x_gt, int E_seen, const int32_t* seen_off, con
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, st, x_gt, seen_off, seen_order, x_ubs, near_off, x_dst, N, E_seen, ps,
                        pn, slope, out, ld_out, attn_save_seen, attn_save_near, ph, img);
   };
-  if (attn_save_near != nullptr) {
+  if (attn_save_near != nullptr || (attn_save_seen != nullptr && !(K1_ABLATE && (phases & 1024)))) {
     if (img != nullptr) launch(gatv2_hetero_fwd_kernel<true, true>); else launch(gatv2_hetero_fwd_kernel<true, false>);
   } else {
     if (img != nullptr) launch(gatv2_hetero_fwd_kernel<false, true>); else launch(gatv2_hetero_fwd_kernel<false, false>);
