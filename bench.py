@@ -315,7 +315,7 @@ def cpu_baseline(n, M, dist_name, T_s=2, B_fixed=64):
                 sec_per_cycle=sweep[best]["sec_per_cycle_median"])
 
 
-def end_to_end(learner, a, device, mode="random", cycles=2):
+def end_to_end(learner, a, device, mode="random", cycles=3):
     """SURVEY 8f rows f1 + f2 + f3 inside the timed region (reported NEXT TO the headline, whose graphs are synthetic as
     BASELINE.json asks): B environments of the batched device simulator (csrc/env_sim.hip; exp3 'DenseHotSpot' physics,
     maps.py:82-111, at n x M) are rolled out for T steps - simulator step, device graph construction, act, replay push
@@ -399,16 +399,23 @@ def end_to_end(learner, a, device, mode="random", cycles=2):
     gc.collect()
     th.cuda.empty_cache()        # every leg starts from a clean caching allocator: the blocks the previous legs left behind (the
     cycle()                      # rho leg's 32 chunks, the staging buffers) cost the hotspot leg 28 ms per cycle otherwise
+    cycle()                      # (two warm-up cycles: the first one regrows the allocator's pools)
     th.cuda.synchronize()
     vis.clear()
-    t0 = time.perf_counter()
+    # every cycle timed on its own, the MEDIAN reported: single cycles of this leg were seen at 3-5x the others (365 ms vs 123
+    # over two runs of the same build on one box - pool regrowth / host hiccups of a leg that steps a simulator from Python); the
+    # mean of two cycles made the figure a coin toss
+    per_cycle = []
     for _ in range(cycles):
+        t0 = time.perf_counter()
         out = cycle()
-    th.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / cycles
+        th.cuda.synchronize()
+        per_cycle.append(time.perf_counter() - t0)
+    dt = sorted(per_cycle)[len(per_cycle) // 2]
     served = float((env.out["gt_ubs"] >= 0).float().mean())
     seen = float(th.stack(vis).mean())            # over every step of the timed cycles, not just the last one
-    return dict(value=B * T / dt, unit="env-steps/s", ms_per_cycle=1e3 * dt, cycles=cycles, loss=float(out["LossQ"]),
+    return dict(value=B * T / dt, unit="env-steps/s", ms_per_cycle=1e3 * dt, cycles=cycles,
+                ms_per_cycle_all=[round(1e3 * t, 2) for t in per_cycle], statistic="median of the timed cycles", loss=float(out["LossQ"]),
                 mode=mode, policy=("uniformly random actions (epsilon = 1)" if mode == "random" else
                                    "policy forward + selection run, simulator stepped with the hover action"),
                 includes="batched device simulator (f3) + device graph construction (f1) + tensor replay (f2) + act + update",
