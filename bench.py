@@ -425,6 +425,32 @@ def end_to_end(learner, a, device, mode="random", cycles=3):
                 mean_gt_visibility=seen, mean_d_seen=seen * M, mean_gt_served=served)
 
 
+_SPAN_FLOOR = None
+
+
+def event_span_floor_us():
+    """What a HIP-event pair reports around (a) nothing and (b) the smallest kernel (one 4-byte fill) on this box and stream: the
+    bias of `avg_launch_ms` - an event span contains the dispatch gap in front of the kernel it brackets, a rocprofv3 kernel
+    duration does not (profiles/*_by_grid.txt: p50 of the K1 launches vs `by_launch_class.rollout.avg_launch_ms`).  `achieved` is
+    computed from the raw spans (pessimistic by this much per launch).  Median of 25."""
+    global _SPAN_FLOOR
+    if _SPAN_FLOOR is None:
+        x = th.zeros(1, device="cuda")
+        res = {}
+        for name, fn in (("empty", lambda: None), ("tiny_kernel", lambda: x.fill_(1.0))):
+            ts = []
+            for _ in range(28):
+                e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                e1.synchronize()
+                ts.append(1e3 * e0.elapsed_time(e1))
+            res[name] = round(sorted(ts[3:])[len(ts[3:]) // 2], 2)
+        _SPAN_FLOOR = res
+    return _SPAN_FLOOR
+
+
 def k1_roofline(k, a, dist_name, clock_mhz):
     """``roofline`` object of the fused K1 forward from the HIP-event spans `k` of a timed region (every launch of it:
     rollout launches over N_a destinations, the two time-batched encoder launches of an update over (T+1) N_a / T N_a
@@ -470,6 +496,7 @@ def k1_roofline(k, a, dist_name, clock_mhz):
             "ms_per_env_step_batch": k["total_ms"] / n_units,
             "by_launch_class": by_class,
             "pipe_bound": pipe_bound(dist_name, by_class.get("rollout", {}).get("avg_launch_ms"), clock_mhz, a.B, a.n, a.M),
+            "event_span_floor_us": event_span_floor_us(),
             "note": ("D-dense: AI ~ 86 FLOP/B (SURVEY 8d) is 4x the machine balance, so the roof SURVEY 8d prices the kernel against "
                      "is the fp32 MFMA / vector peak (157.3 TF); even there it could move only ~23 % of the HBM peak.  `frac` is "
                      "that throughput ratio and NOT a bound the kernel lives under: the score GEMM (2048 of the 3360 FLOP per "

@@ -25,11 +25,13 @@ def main(path, min_total_us=300.0):
     tot = sum(sum(v) for v in groups.values())
     print(f"# per (kernel, grid) summary of {path.split('/')[-1]}  (microseconds; grid = work-items in x, wg = workgroup size)")
     print(f"# total GPU kernel time {tot / 1e3:.3f} ms; groups below {min_total_us:.0f} us total are omitted")
-    print(f"{'calls':>6} {'total_us':>11} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'%':>6} {'grid':>10} {'wg':>5}  name")
+    print("# p50 = median: a persistent kernel launches the same grid for its rollout-size and its time-batched calls (K1 forward: 200 + 4"
+          " per four cycles), so the median is the rollout launch and the mean is not")
+    print(f"{'calls':>6} {'total_us':>11} {'avg_us':>10} {'p50_us':>10} {'min_us':>10} {'max_us':>10} {'%':>6} {'grid':>10} {'wg':>5}  name")
     for (name, g, w), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
         if sum(v) < min_total_us:
             continue
-        print(f"{len(v):6d} {sum(v):11.1f} {sum(v) / len(v):10.2f} {min(v):10.2f} {max(v):10.2f} {100 * sum(v) / tot:6.2f} "
+        print(f"{len(v):6d} {sum(v):11.1f} {sum(v) / len(v):10.2f} {sorted(v)[len(v) // 2]:10.2f} {min(v):10.2f} {max(v):10.2f} {100 * sum(v) / tot:6.2f} "
               f"{g:10d} {w:5d}  {name[:110]}")
 
 

@@ -25,7 +25,8 @@
 // 128 x 32 tiles with four waves and 16x16x32 MFMAs (200 us: three independent accumulators between dependent 16x16x32
 // MFMAs issue at half rate, profiles/r02_ubench_mfma_bf16.txt), the same with 32x32x16 MFMAs (215 us), loads two slices
 // ahead through a fully unrolled slice loop (-4 us), a start skew between co-resident workgroups (0), persistent workgroups
-// that load the next tile's first slice during the epilogue (207 us).
+// that load the next tile's first slice during the epilogue (207 us), the epilogue's h tile and biases requested in front of the
+// slice loop and held in registers (round 4, same-box A/B: 202.5 vs 193.8 us and 175.1 vs 167.2 us - slower: 22 more live registers).
 #include <type_traits>
 
 #include "bf16x3.h"
@@ -210,14 +211,6 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
   gload();
   lstore(0);
   gload();
-  // The workgroup's own tile of h (the epilogue's z h term) is requested HERE and waits in registers: loaded behind the slice
-  // loop it was a memory round trip on the critical path of every workgroup (one workgroup per CU: nothing overlaps it).
-  float4 h_tile[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = tid + NT * q, row = idx >> 4, cc = idx & 15;
-    h_tile[q] = *reinterpret_cast<const float4*>(h + static_cast<size_t>(min(m0 + row, N - 1)) * H + j0 + 4 * cc);
-  }
   __syncthreads();
   // Software pipeline over the halves: the fragment reads of a half are issued one MFMA group (18 MFMAs = 576 cycles) before
   // their use - f1 = (slice t, second half) under the MFMAs of f0, f0 = (slice t + 1, first half) right after the barrier
@@ -317,7 +310,8 @@ __global__ __launch_bounds__(w8::NT) void gru_cell_fwd_x3w8_kernel(
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int idx = tid + NT * q, row = idx >> 4, cc = idx & 15;
-    *reinterpret_cast<float4*>(sH + row * ST + 4 * cc) = h_tile[q];
+    *reinterpret_cast<float4*>(sH + row * ST + 4 * cc) =
+        *reinterpret_cast<const float4*>(h + static_cast<size_t>(min(m0 + row, N - 1)) * H + j0 + 4 * cc);
   }
   __syncthreads();
   // D layout of the 32 x 32 tile: lane l holds column l % 32, register i holds row 8 (i / 4) + 4 (l / 32) + i % 4
