@@ -1270,7 +1270,7 @@ def test_bench_step_under_force_dist_equals_the_plain_run():
 
 @pytest.mark.parametrize("B,n,M,dist,seed", [(16, 8, 80, "dense", 0), (64, 8, 80, "env", 1), (9, 5, 40, "ragged", 2),
                                              (7, 16, 30, "ragged", 3), (1, 1, 12, "ragged", 4), (33, 3, 100, "env", 5),
-                                             (5, 20, 10, "ragged", 6), (4400, 8, 12, "env", 7)])
+                                             (5, 20, 10, "ragged", 6), (4400, 8, 12, "env", 7), (2, 3, 600, "dense", 8)])
 def test_fused_hetero_k1_equals_per_relation_kernels(B, n, M, dist, seed):
     """gatv2_hetero.hip (both relations, one launch; `near` on blocks of 16 destinations, one score tile per edge slot with
     [x_u ; x_v] in the contraction) against the per-relation kernels on the same inputs: outputs, saved attention weights and
@@ -1278,7 +1278,8 @@ def test_fused_hetero_k1_equals_per_relation_kernels(B, n, M, dist, seed):
     degrees above 8 and above 16 (n = 16 / 20: two / three passes through the online softmax, raw scores re-normalised in
     place), isolated `near` destinations, destinations isolated in `seen` with / without a hand-out order, and - 35 200
     destinations = 2 200 blocks for 2 048 wavefronts - the several-blocks-per-wavefront path of the time-batched launches
-    (next block's inputs prefetched, opposite part order on the two wavefronts of a SIMD)."""
+    (next block's inputs prefetched, opposite part order on the two wavefronts of a SIMD); 600 `seen` in-edges per destination =
+    38 row tiles: more raw scores than the wavefront's LDS row buffer parks (33 tiles), the rest go through a_save itself."""
     from uav_bs_ctrl_amd import ops
     from uav_bs_ctrl_amd.agents.gnn_agents import GraphObservationEncoder
     import types
