@@ -1147,7 +1147,7 @@ def test_rccl_path_at_world_size_one_equals_the_non_distributed_step():
     pr = ctx.Process(target=_nccl_ws1_worker, args=(port, q))
     pr.start()
     try:
-        res = q.get(timeout=300)
+        res = q.get(timeout=900)
     finally:
         pr.join(timeout=60)
         if pr.is_alive():
@@ -1226,7 +1226,7 @@ def test_graphed_update_is_cut_at_the_rccl_collective_and_equals_eager_updates()
     pr = ctx.Process(target=_nccl_graphed_worker, args=(port, q))
     pr.start()
     try:
-        res = q.get(timeout=300)
+        res = q.get(timeout=900)
     finally:
         pr.join(timeout=60)
         if pr.is_alive():
