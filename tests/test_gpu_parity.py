@@ -1607,6 +1607,63 @@ def test_low_degree_k1_backward_pair_kernel_agrees_with_generic(N, maxdeg, seed)
         assert_close(a, b, 2e-5, f"{nm}: pair vs generic", floor=1e-5 * max(1.0, float(N) ** 0.5 * 1e-2))
 
 
+@pytest.mark.parametrize("N,lo,hi,seed,order", [(4096, 64, 64, 0, False), (8192, 100, 128, 1, False), (6001, 0, 140, 2, True),
+                                                (32768, 20, 60, 3, False), (300, 16, 16, 4, True)])
+def test_dense_k1_backward_on_the_matrix_cores_agrees_with_generic_and_is_bit_reproducible(N, lo, hi, seed, order):
+    """The matrix-core K1 backward (csrc/gatv2_bwd_mfma.hip: destinations with 16 .. 128 in-edges take the per-(edge, channel)
+    sums through bf16x3 MFMAs, the others a second launch of the packed-FMA kernel) against the generic backward on the same
+    inputs, every parameter gradient, and bit-exact repeatability over ten launches.  Sizes put several destinations on
+    every wavefront and two workgroups on every CU - the regime in which the first build of this kernel was irreproducible
+    (a compiler-packed v_pk_fma_f32 with an operand select next to bf16 MFMAs: tools/ubench/mfma_pk_hazard.hip).
+    The two kernels evaluate z = W_s x + c in different arithmetic (fp32 FMA chain / exact bf16 triple products), so the sign
+    of a z within rounding of zero can differ: about one (edge, channel) pair in 3e7, each moving one gradient element by
+    2 |de|.  Hence the rule: everything within 2e-5 of max|ref|, except at most 8 elements per tensor within 1e-3."""
+    from uav_bs_ctrl_amd import _lib as L
+    gen = th.Generator().manual_seed(seed)
+    deg = th.randint(lo, hi + 1, (N,), generator=gen)
+    off = th.zeros(N + 1, dtype=th.int32)
+    off[1:] = th.cumsum(deg, 0)
+    E = int(off[-1])
+    assert E >= 16 * N, "the matrix-core path is chosen for a mean in-degree of 16 or more"
+    dev = "cuda"
+    x_src = (th.rand(E, 4, generator=gen) * 2 - 1).to(dev)
+    x_dst = th.rand(N, 2, generator=gen).to(dev)
+    H = 256
+    prm = [(0.5 * th.randn(s, generator=gen)).to(dev) for s in ((H, 4), (H,), (H, 2), (H,), (H,), (H, 2), (H,))]
+    out = th.empty(N, 512, device=dev)
+    a_save = th.empty(E, 4, device=dev)
+    lib, st, offd = L.lib(), L.stream(), off.to(dev)
+    perm = th.argsort(deg, descending=True, stable=True).to(th.int32).to(dev) if order else None
+    pp = perm.data_ptr() if order else None
+    rc = lib.uavgnn_gatv2_fwd(x_src.data_ptr(), E, 4, x_dst.data_ptr(), 2, offd.data_ptr(), pp, N, *[t.data_ptr() for t in prm],
+                              4, 64, 0.2, out.data_ptr(), 512, a_save.data_ptr(), st)
+    assert rc == 0
+    d_out = th.randn(N, 512, generator=gen).to(dev)
+    wsb = lib.uavgnn_gatv2_bwd_workspace_bytes(4, H)
+    ws = th.empty(wsb // 4, device=dev)
+
+    def run(fn):
+        g = [th.full_like(t, float("nan")) for t in prm]
+        rc = fn(x_src.data_ptr(), E, 4, x_dst.data_ptr(), 2, offd.data_ptr(), pp, N, *[t.data_ptr() for t in prm[:5]], 4, 64, 0.2,
+                out.data_ptr(), d_out.data_ptr(), 512, a_save.data_ptr(), *[t.data_ptr() for t in g], ws.data_ptr(), wsb, st)
+        assert rc == 0, rc
+        th.cuda.synchronize()
+        return g
+    g_mf, g_gen = run(lib.uavgnn_gatv2_bwd), run(lib.uavgnn_gatv2_bwd_generic)
+    names = ["dW_s", "db_s", "dW_d", "db_d", "dattn", "dW_r", "db_r"]
+    for rep in range(10):
+        again = run(lib.uavgnn_gatv2_bwd)
+        for a, c, nm in zip(g_mf, again, names):
+            assert th.equal(a, c), f"{nm}: matrix-core backward not bit-reproducible (launch {rep + 2})"
+    for a, b, nm in zip(g_mf, g_gen, names):
+        assert bool(th.isfinite(a).all()), nm
+        scale = float(b.abs().max())
+        err = (a - b).abs()
+        loose = int((err > 2e-5 * scale).sum())
+        assert loose <= 8 and float(err.max()) <= 1e-3 * scale, (
+            f"{nm}: {loose} elements beyond 2e-5 of max|ref|, worst {float(err.max()) / scale:.3e} of max|ref|")
+
+
 @pytest.mark.parametrize("N,K_in,H", [(1000, 320, 256), (128, 256, 256), (77, 384, 256), (3, 32, 32), (4099, 96, 64)])
 def test_fused_gru_cell_kernel_vs_oracle(N, K_in, H):
     """K4 as one kernel (csrc/gru_fused.hip: both GEMMs on fp32 MFMA into shared r / z and separate n accumulators, gates

@@ -22,6 +22,8 @@ OBJ = os.path.join(CSRC, "build")
 OUT = os.path.join(CSRC, "libuavgnn.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-source flags: kernels that mix 16-bit-operand MFMAs with fp32 VALU work the compiler would pack (see the source's header)
+EXTRA_CFLAGS = {"gatv2_bwd_mfma.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
 
 
 def sources():
@@ -30,7 +32,7 @@ def sources():
 
 def headers():
     return (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc"))
-            + glob.glob(os.path.join(ROOT, "include", "*.h")))
+            + glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.join(CSRC, "gatv2.hip")])   # included by gatv2_bwd_mfma.hip
 
 
 def _obj(src: str) -> str:
@@ -62,7 +64,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
     def compile_one(src):
-        cmd = [HIPCC, *CFLAGS, *inc, "-c", src, "-o", _obj(src)]
+        cmd = [HIPCC, *CFLAGS, *EXTRA_CFLAGS.get(os.path.basename(src), []), *inc, "-c", src, "-o", _obj(src)]
         if verbose:
             print("[uav_bs_ctrl_amd.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -13,11 +13,21 @@
 // Backward produces parameter gradients only (observations are leaves), accumulates them in registers per wave
 // (lane <-> channel), folds the 4 waves of a workgroup in fixed order through LDS and leaves one partial row per
 // workgroup; a second launch sums the rows in fixed order (deterministic, no float atomics).
+//
+// This file is compiled TWICE (build.py): as itself, and through gatv2_bwd_mfma.hip with UAVGNN_GATV2_BWD_MFMA_TU defined and
+// packed fp32 instructions disabled for the whole translation unit.  The second pass emits only the matrix-core instantiation
+// of the backward kernel and its launcher; see gatv2_bwd_mfma.hip for why that instantiation may not contain v_pk_*_f32.
 #include <cstdlib>
 
 #include "common.h"
+#include "k1_x3.h"
 
 namespace uavgnn {
+// defined in gatv2_bwd_mfma.hip (the other pass over this file): launches gatv2_bwd_kernel<4, 4, 64, true, true>, cls = 1
+int gatv2_bwd_mfma_launch(const float* x_src, const float* x_dst, const int32_t* seg_off, const int32_t* dst_order, int N,
+                          const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn, float slope,
+                          const float* out, const float* d_out, int ld_out, const float* a_save, float* partial,
+                          int onepass_max_deg, int grid, hipStream_t st);
 namespace {
 
 constexpr int kWavesPerBlock = 4;
@@ -194,14 +204,19 @@ __global__ __launch_bounds__(kThreads) void gatv2_fwd_kernel(
 template <int FS>
 __host__ __device__ constexpr int partial_len(int H) { return H * (FS + 8); }
 
-template <int FS, int NH, int D, bool CHUNK>
+// MF (F_src = 4, nh = 4, D = 64 only; launched with cls = 1): the per-(edge, channel) sums S1, S2 of destinations with kMfMinDeg ..
+// onepass_max_deg in-edges on the bf16 matrix cores (run_edges_mfma below) instead of the packed-FMA loop of run_edges.
+typedef float bwd_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMfMinDeg = 16;
+
+template <int FS, int NH, int D, bool CHUNK, bool MF = false>
 __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
     const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off,
     const int32_t* __restrict__ dst_order, int N,
     const float* __restrict__ W_s, const float* __restrict__ b_s, const float* __restrict__ W_d,
     const float* __restrict__ b_d, const float* __restrict__ attn, float slope, const float* __restrict__ out,
     const float* __restrict__ d_out, int ld_out, const float* __restrict__ a_save, float* __restrict__ partial,
-    int onepass_max_deg) {
+    int onepass_max_deg, int cls) {
   // Per destination v (one wavefront), head k, channel n = (k,d), in-edges u with attention a_uk:
   //   g = d_out * [out > 0];  G[k] = sum_d g[n] W_s[n,:];  de_uk = a_uk (G[k].x_u - T[k]),  T[k] = sum_u a_uk G[k].x_u
   // With lrelu'(z) = c_lin + c_abs sgn(z), c_lin = (1+s)/2, c_abs = (1-s)/2 (SURVEY A.3 i) everything that is linear in
@@ -220,12 +235,22 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
   constexpr int P = partial_len<FS>(H);
   constexpr int ES = FS + 2 * NH;  // staged floats per edge: x[FS], de[NH], a[NH]
 
-  __shared__ float sW[H * FS];
-  __shared__ float sG[kWavesPerBlock][H];
-  __shared__ float sGk[kWavesPerBlock][KF];
-  __shared__ float sPS[kWavesPerBlock][2 * KF];   // P[k][f] | Sb[k][f]
-  __shared__ float sE[kWavesPerBlock][2 * kWave * ES];   // up to 128 staged edges (two 64-edge chunks)
-  __shared__ float sRed[P];
+  // LDS, carved by hand from one array
+  static_assert(!MF || (FS == 4 && NH == 4 && D == 64), "matrix-core backward: F_src = 4, nh = 4, D = 64");
+  constexpr int szG = kWavesPerBlock * H * 4, szGk = kWavesPerBlock * KF * 4, szPS = kWavesPerBlock * 2 * KF * 4;
+  constexpr int szE = kWavesPerBlock * 2 * kWave * ES * 4;      // up to 128 staged edges per wavefront (two 64-edge chunks)
+  constexpr int szV = MF ? kWavesPerBlock * NH * kWave * 16 : 0;   // MF: A operands of the accumulation products of one pair of edge tiles, [head][lane], 4 KB per wavefront
+  constexpr int szW = H * FS * 4, szRed = P * 4;
+  constexpr int szWop = MF ? (H / 16) * kWave * 16 : 0;         // MF: B operands of the score products (rows of W_s as exact bf16 triples, [channel tile][lane]: 16 KB)
+  constexpr int oG = 0, oGk = oG + szG, oPS = oGk + szGk, oE = (oPS + szPS + 15) & ~15, oV = oE + szE, oW = oV + szV;
+  constexpr int oWop = oW + szW;
+  constexpr int oRed = MF ? oWop : oWop + szWop;   // MF: the fold buffer of the last phase takes the place of the score operands (barrier in between)
+  static_assert(!MF || szRed <= szWop, "fold buffer aliases the score operands");
+  constexpr int kLdsBytes = MF ? oWop + szWop : oRed + szRed;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
+  float* const sW = reinterpret_cast<float*>(lds + oW);
+  float* const sRed = reinterpret_cast<float*>(lds + oRed);
+  k1_u32x4* const sWop = reinterpret_cast<k1_u32x4*>(lds + oWop);
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -233,6 +258,14 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
   const float c_lin = 0.5f * (1.f + slope), c_abs = 0.5f * (1.f - slope);
 
   for (int i = tid; i < H * FS; i += kThreads) sW[i] = W_s[i];
+  if constexpr (MF) {
+    for (int i = tid; i < (H / 16) * kWave; i += kThreads) {   // lane (j = channel of the tile, kg = feature)
+      const int ct = i >> 6, l = i & 63;
+      sWop[i] = k1_a_operand(W_s[(16 * ct + (l & 15)) * FS + (l >> 4)], 0.f, 0);
+    }
+    for (int i = lane; i < NH * kWave; i += kWave)   // the zero row of every operand is never written again
+      (reinterpret_cast<k1_u32x4*>(lds + oV) + (tid >> 6) * NH * kWave)[i] = k1_u32x4{0u, 0u, 0u, 0u};
+  }
 
   float Ws[J][FS], att[J], wd0[J], wd1[J], bc[J];
   int kj[J];
@@ -257,10 +290,11 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
   const int pk = (lane < KF) ? lane / FS : 0, pf = (lane < KF) ? lane % FS : 0;
   __syncthreads();
 
-  float* __restrict__ gw = sG[wave];
-  float* __restrict__ gk = sGk[wave];
-  float* __restrict__ ps = sPS[wave];
-  float* __restrict__ ew = sE[wave];
+  float* __restrict__ gw = reinterpret_cast<float*>(lds + oG) + wave * H;
+  float* __restrict__ gk = reinterpret_cast<float*>(lds + oGk) + wave * KF;
+  float* __restrict__ ps = reinterpret_cast<float*>(lds + oPS) + wave * 2 * KF;
+  float* __restrict__ ew = reinterpret_cast<float*>(lds + oE) + wave * 2 * kWave * ES;
+  k1_u32x4* __restrict__ vw_base = reinterpret_cast<k1_u32x4*>(lds + oV) + (MF ? wave * NH * kWave : 0);
 
   // rows of the forward output and of its gradient for destination v (lane <-> channel)
   auto load_rows = [&](const int v, float (&o)[J], float (&gr)[J]) {
@@ -340,6 +374,134 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
         accSb = fmaf(ew[i * ES + FS + NH + pk], xpf, accSb);
       }
     };
+    // ---- the same sums on the bf16 matrix cores (MF; staged edges 0 .. deg - 1, deg <= 128) --------------------------------------
+    auto run_edges_mfma = [&](const int deg_) {
+      if constexpr (MF) {
+        constexpr int CT = H / 16;
+        bwd_f32x4 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = bwd_f32x4{0.f, 0.f, 0.f, 0.f};
+        const bwd_f32x4 czero = {0.f, 0.f, 0.f, 0.f};
+        unsigned k_sign = 0x80008000u, k_one = 0x3F803F80u;
+        asm volatile("" : "+v"(k_sign), "+v"(k_one));
+        const int j16 = lane & 15, g4 = lane >> 4;
+        k1_u32x4* __restrict__ vw = vw_base;
+        {
+          const int kf = lane & 15, part = lane >> 4, k = kf >> 2, f = kf & 3;
+          float p = 0.f, sb = 0.f;
+          const int e_end = (deg_ + 15) & ~15;
+#pragma unroll 2
+          for (int e = part; e < e_end; e += 16) {
+            float x[4], d4[4], a4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              x[u] = ew[(e + 4 * u) * ES + f];
+              d4[u] = ew[(e + 4 * u) * ES + FS + k];
+              a4[u] = ew[(e + 4 * u) * ES + FS + NH + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              p = fmaf(d4[u], x[u], p);
+              sb = fmaf(a4[u], x[u], sb);
+            }
+          }
+          p += __shfl_xor(p, 16);
+          sb += __shfl_xor(sb, 16);
+          p += __shfl_xor(p, 32);
+          sb += __shfl_xor(sb, 32);
+          accP = p;
+          accSb = sb;
+        }
+        for (int tp = 0; 32 * tp < deg_; ++tp) {
+          {
+            const int ep = lane & 15, h = lane >> 4;
+            const int e_a = 2 * ep, i16 = e_a & 15;
+            const float* er = ew + (32 * tp + e_a) * ES;
+            const bwd_f32x4 xa = *reinterpret_cast<const bwd_f32x4*>(er), xb = *reinterpret_cast<const bwd_f32x4*>(er + ES);
+            const float da = er[FS + h], db = er[ES + FS + h];
+            const float va[5] = {da, da * xa[0], da * xa[1], da * xa[2], da * xa[3]};
+            const float vb[5] = {db, db * xb[0], db * xb[1], db * xb[2], db * xb[3]};
+            const int skew = (i16 >> 2) + 4 * h;
+            unsigned* dst = reinterpret_cast<unsigned*>(vw) + (h * kWave + (i16 >> 2) * 16) * 4 + (((i16 & 3) + 4 * (e_a >> 4)) >> 1);
+#pragma unroll
+            for (int f = 0; f < 5; ++f) {
+              const K1Split sa = k1_split(va[f]), sb2 = k1_split(vb[f]);
+              dst[((0 * 5 + f + skew) & 15) * 4] = (sa.h1 & 0xffffu) | (sb2.h1 & 0xffff0000u);
+              dst[((1 * 5 + f + skew) & 15) * 4] = (sa.h2 & 0xffffu) | (sb2.h2 & 0xffff0000u);
+              dst[((2 * 5 + f + skew) & 15) * 4] = (sa.h3 & 0xffffu) | (sb2.h3 & 0xffff0000u);
+            }
+          }
+          k1_bf16x8 xop[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) xop[t] = k1_b_operand(ew[(32 * tp + 16 * t + j16) * ES + g4], 0u);
+          wave_sync_lds();
+          k1_u32x4 vop = vw[16 * g4 + ((j16 + g4) & 15)], vop_n = vw[kWave + 16 * g4 + ((j16 + g4 + 4) & 15)];
+          k1_bf16x8 w_nn = __builtin_bit_cast(k1_bf16x8, sWop[kWave + lane]);
+          float nc = gw[j16], nc_n = gw[16 + j16];
+          bwd_f32x4 d0, d1;
+          {
+            const k1_bf16x8 w0 = __builtin_bit_cast(k1_bf16x8, sWop[lane]);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xop[0], w0, czero, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xop[1], w0, czero, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            bwd_f32x4 e0 = d0, e1 = d1;
+            float nc_nn = nc_n;
+            if (ct + 1 < CT) {
+              e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xop[0], w_nn, czero, 0, 0, 0);
+              e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xop[1], w_nn, czero, 0, 0, 0);
+              if (ct + 2 < CT) {
+                w_nn = __builtin_bit_cast(k1_bf16x8, sWop[(ct + 2) * kWave + lane]);
+                nc_nn = gw[16 * (ct + 2) + j16];
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            k1_u32x4 sg;
+            const k1_f32x2 nc2 = {nc, nc};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const k1_f32x2 t0 = nc2 - k1_f32x2{d0[2 * q], d0[2 * q + 1]}, t1 = nc2 - k1_f32x2{d1[2 * q], d1[2 * q + 1]};
+              const unsigned p0 = __builtin_amdgcn_perm(__float_as_uint(t0[1]), __float_as_uint(t0[0]), 0x07060302u);
+              const unsigned p1 = __builtin_amdgcn_perm(__float_as_uint(t1[1]), __float_as_uint(t1[0]), 0x07060302u);
+              sg[q] = (p0 & k_sign) | (k_one & ~k_sign);
+              sg[2 + q] = (p1 & k_sign) | (k_one & ~k_sign);
+            }
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k1_bf16x8, vop), __builtin_bit_cast(k1_bf16x8, sg),
+                                                              acc[ct], 0, 0, 0);
+            if ((ct & 3) == 3 && ct + 1 < CT) {
+              vop = vop_n;
+              if (ct + 5 < CT) vop_n = vw[((ct + 5) >> 2) * kWave + 16 * g4 + ((j16 + g4 + 4 * ((ct + 5) >> 2)) & 15)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            d0 = e0;
+            d1 = e1;
+            nc = nc_n;
+            nc_n = nc_nn;
+          }
+          wave_sync_lds();
+        }
+        constexpr int kCvLd = 20;
+        float* __restrict__ cv = ew;
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) *reinterpret_cast<bwd_f32x4*>(cv + (c4 * 16 + j16) * kCvLd + 4 * g4) = acc[4 * k + c4];
+          wave_sync_lds();
+          float r[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bwd_f32x4 t4 = *reinterpret_cast<const bwd_f32x4*>(cv + lane * kCvLd + 4 * q);
+            r[4 * q] = t4[0]; r[4 * q + 1] = t4[1]; r[4 * q + 2] = t4[2]; r[4 * q + 3] = t4[3];
+          }
+          S1[k] = -((r[0] + r[5]) + r[10]);
+#pragma unroll
+          for (int f = 0; f < FS; ++f) S2[k][f] = -((r[1 + f] + r[6 + f]) + r[11 + f]);
+          wave_sync_lds();
+        }
+      }
+    };
     // T[k] = sum_u a_uk (G[k].x_u): one wave reduction per head
     float T[NH];
     if (deg <= onepass_max_deg) {
@@ -393,10 +555,17 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
             ew[slot * ES + FS + k] = ew[slot * ES + FS + NH + k] * (ew[slot * ES + FS + k] - T[k]);
         }
       }
+      if constexpr (MF) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) gw[lane + kWave * j] = 0.f - c[j];
+        wave_sync();
+        run_edges_mfma(deg);
+      } else {
+        wave_sync();
+        run_edges(0, deg);
+      }
       wave_sync();
-      run_edges(0, deg);
-      wave_sync();
-    } else {
+    } else if constexpr (!MF) {
       {
         float t[NH];
 #pragma unroll
@@ -489,20 +658,30 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
       const int m_e1 = mine ? seg_off[m_v + 1] : 0;
       const float2 m_xv = mine ? *reinterpret_cast<const float2*>(x_dst + 2 * m_v) : make_float2(0.f, 0.f);
       const int cnt = min(kWave, (N - it0 - kb * stride + stride - 1) / stride);
+      auto in_cls = [&](const int i) {
+        const int dg = __builtin_amdgcn_readlane(m_e1, i) - __builtin_amdgcn_readlane(m_e0, i);
+        const bool mf = dg >= kMfMinDeg && dg <= onepass_max_deg;
+        return cls == 0 || (mf == (cls == 1));
+      };
       float on[J], gn[J];                       // rows of the NEXT destination are in flight while this one computes
-      load_rows(__builtin_amdgcn_readlane(m_v, 0), on, gn);
-      for (int ii = 0; ii < cnt; ++ii) {
+      int ii = 0;
+      while (ii < cnt && !in_cls(ii)) ++ii;
+      if (ii < cnt) load_rows(__builtin_amdgcn_readlane(m_v, ii), on, gn);
+      while (ii < cnt) {
         float oc[J], gc[J];
 #pragma unroll
         for (int j = 0; j < J; ++j) {
           oc[j] = on[j];
           gc[j] = gn[j];
         }
-        if (ii + 1 < cnt) load_rows(__builtin_amdgcn_readlane(m_v, ii + 1), on, gn);
+        int nx = ii + 1;
+        while (nx < cnt && !in_cls(nx)) ++nx;
+        if (nx < cnt) load_rows(__builtin_amdgcn_readlane(m_v, nx), on, gn);
         const int e0 = __builtin_amdgcn_readlane(m_e0, ii);
         process(oc, gc, e0, __builtin_amdgcn_readlane(m_e1, ii) - e0,
                 __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(m_xv.x), ii)),
                 __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(m_xv.y), ii)));
+        ii = nx;
       }
     }
   } else {
@@ -529,6 +708,7 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
   }
 
   // fold the 4 waves in fixed order through LDS, then one partial row per workgroup
+  if constexpr (MF) __syncthreads();   // the fold buffer aliases the score operands
   for (int w = 0; w < kWavesPerBlock; ++w) {
     if (wave == w) {
 #pragma unroll
@@ -560,6 +740,20 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
   float* __restrict__ prow = partial + static_cast<size_t>(blockIdx.x) * P;
   for (int i = tid; i < P; i += kThreads) prow[i] = sRed[i];
 }
+
+#ifdef UAVGNN_GATV2_BWD_MFMA_TU
+}  // namespace
+
+int gatv2_bwd_mfma_launch(const float* x_src, const float* x_dst, const int32_t* seg_off, const int32_t* dst_order, int N,
+                          const float* W_s, const float* b_s, const float* W_d, const float* b_d, const float* attn, float slope,
+                          const float* out, const float* d_out, int ld_out, const float* a_save, float* partial,
+                          int onepass_max_deg, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((gatv2_bwd_kernel<4, 4, 64, true, true>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off, dst_order,
+                     N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, partial, onepass_max_deg, 1);
+  return launch_status();
+}
+}  // namespace uavgnn
+#else   // everything below belongs to the first pass only
 
 // Sums `rows` partial rows of length P in a fixed order: block = 64 columns x 16 row-groups.
 struct GradPtrs {
@@ -895,18 +1089,32 @@ int launch_bwd(const float* x_src, const float* x_dst, const int32_t* seg_off, c
                const float* W_s,
                const float* b_s, const float* W_d, const float* b_d, const float* attn, float slope, const float* out,
                const float* d_out, int ld_out, const float* a_save, const GradPtrs& gp, float* ws, bool sparse_hint,
-               hipStream_t st) {
+               bool mfma, hipStream_t st) {
   constexpr int H = NH * D;
   constexpr int P = partial_len<FS>(H);
   const int grid = bwd_blocks(N);
   // A/B switch: UAVGNN_BWD_ONEPASS=0 sends every destination through the general two-pass path (same bits out)
   static const int onepass = (getenv("UAVGNN_BWD_ONEPASS") && getenv("UAVGNN_BWD_ONEPASS")[0] == '0') ? 0 : 2 * kWave;
+  if constexpr (FS == 4 && NH == 4 && D == 64) {
+    if (mfma && onepass > 0) {
+      const int g = capped_grid(N, kWavesPerBlock, kMaxBwdBlocks / 2);
+      int rc = gatv2_bwd_mfma_launch(x_src, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out,
+                                     a_save, ws, onepass, g, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL((gatv2_bwd_kernel<FS, NH, D, true, false>), dim3(g), dim3(kThreads), 0, st, x_src, x_dst, seg_off, dst_order,
+                         N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws + static_cast<size_t>(g) * P, onepass, 2);
+      rc = launch_status();
+      if (rc) return rc;
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + kWave - 1) / kWave), dim3(1024), 0, st, ws, 2 * g, P, gp);
+      return launch_status();
+    }
+  }
   if (sparse_hint)
     hipLaunchKernelGGL((gatv2_bwd_kernel<FS, NH, D, true>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off,
-                       dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws, onepass);
+                       dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws, onepass, 0);
   else
     hipLaunchKernelGGL((gatv2_bwd_kernel<FS, NH, D, false>), dim3(grid), dim3(kThreads), 0, st, x_src, x_dst, seg_off,
-                       dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws, onepass);
+                       dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out, ld_out, a_save, ws, onepass, 0);
   int rc = launch_status();
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + kWave - 1) / kWave), dim3(1024), 0, st, ws, grid, P, gp);
@@ -1039,8 +1247,13 @@ static int gatv2_bwd_checked(int variant, const float* x_src, int E, int F_src, 
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((Pn + kWave - 1) / kWave), dim3(1024), 0, st, ws, grid, Pn, gp);
     return launch_status();
   }
+  // dense batches (mean in-degree >= 16) of the flagship shape: destinations with 16 .. 128 in-edges on the matrix cores, the
+  // rest in a second launch of the packed-FMA kernel.  A/B switch: UAVGNN_K1_BWD_MFMA=0 (same results up to sign ties of z).
+  static const bool mfma_on = !(getenv("UAVGNN_K1_BWD_MFMA") && getenv("UAVGNN_K1_BWD_MFMA")[0] == '0');
+  const bool use_mfma = variant == 1 && mfma_on && !sparse_hint && (reinterpret_cast<uintptr_t>(x_src) & 15) == 0;
   UAVGNN_DISPATCH_ALL((launch_bwd<FS_, NH_, D_>(x_src, x_dst, seg_off, dst_order, N, W_s, b_s, W_d, b_d, attn, slope, out, d_out,
-                                                 ld_out, attn_save, gp, ws, sparse_hint, st)))
+                                                 ld_out, attn_save, gp, ws, sparse_hint,
+                                                 use_mfma, st)))
   return UAVGNN_EUNSUPPORTED;
 }
 
@@ -1066,3 +1279,4 @@ extern "C" int uavgnn_gatv2_bwd_generic(const float* x_src, int E, int F_src, co
                            d_out, ld_out, attn_save, dW_s, db_s, dW_d, db_d, dattn, dW_r, db_r, workspace, workspace_bytes,
                            stream);
 }
+#endif  // UAVGNN_GATV2_BWD_MFMA_TU
