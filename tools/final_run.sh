@@ -23,7 +23,12 @@ rm -rf gpurun_out/prof_bench
 python tools/gru_probe.py > gpurun_out/${R}_final_gru_probe.txt 2>&1
 python tools/gemm_x3_probe.py > gpurun_out/${R}_final_gemm_x3_probe.txt 2>&1
 python tools/gemm_tn_big_probe.py > gpurun_out/${R}_gemm_tn_big_probe.txt 2>&1
-# K1 backward (`seen`, the VALU kernel): counter passes of one time-batched update launch
+# K1 backward `seen`: counter passes of the kernel bench, matrix-core kernel (default) and packed-FMA kernel
 bash tools/pmc.sh /root/repo/gpurun_out/pmc_bwd gatv2_bwd_kernel -- python /root/repo/tools/kbench.py --dists dense --reps 2 > /dev/null 2>&1
+cp gpurun_out/pmc_bwd/pmc_summary.txt gpurun_out/${R}_k1_bwd_mfma_pmc.txt; rm -rf gpurun_out/pmc_bwd
+UAVGNN_K1_BWD_MFMA=0 bash tools/pmc.sh /root/repo/gpurun_out/pmc_bwd gatv2_bwd_kernel -- python /root/repo/tools/kbench.py --dists dense --reps 2 > /dev/null 2>&1
 cp gpurun_out/pmc_bwd/pmc_summary.txt gpurun_out/${R}_k1_bwd_pmc.txt; rm -rf gpurun_out/pmc_bwd
+# the packed-fp32 operand-select / bf16-MFMA hazard in isolation, and the K1 backward's repeatability at sizes with two workgroups per CU
+tools/ubench/bin/mfma_pk_hazard 2>&1 | python tools/hazard_report.py > gpurun_out/${R}_mfma_pk_hazard.txt
+REPS=100 REL=1 CASES="[(4096,64,64),(8192,100,128),(8192,16,130),(32768,20,60)]" python tools/k1_bwd_repro.py > gpurun_out/${R}_k1_bwd_repro.txt 2>&1
 tail -2 gpurun_out/${R}_final_tests.txt

@@ -186,6 +186,19 @@ __global__ __launch_bounds__(256) void own_gap(const s16x8* a_in, const s16x8* b
       if (KIND == 1)   // the fp32 MFMA (one VGPR per operand)
         asm volatile("v_mfma_f32_16x16x4_f32 %1, %2, %3, %1\n .rept %c6\n s_nop 0\n .endr\n v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]"
                      : "+v"(x), "+v"(own) : "v"(fa), "v"(fb), "v"(sel2), "v"(inc2), "n"(NOPS));
+      if (KIND == 3)   // the MFMA BETWEEN the two dependent packed FMAs, every step
+        asm volatile("v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n .rept %c6\n s_nop 0\n .endr\n v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]"
+                     : "+v"(x), "+v"(own) : "v"(oa), "v"(ob), "v"(sel2), "v"(inc2), "n"(NOPS));
+      if (KIND == 5)   // the wait states between the FIRST packed FMA and the MFMA that follows it
+        asm volatile("v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n .rept %c6\n s_nop 0\n .endr\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n s_nop 7\n s_nop 7\n v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n s_nop 7"
+                     : "+v"(x), "+v"(own) : "v"(oa), "v"(ob), "v"(sel2), "v"(inc2), "n"(NOPS));
+      if (KIND == 4) {  // ... on every fourth step only (three plain steps of two packed FMAs in between)
+        if ((k & 3) == 0)
+          asm volatile("v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n .rept %c6\n s_nop 0\n .endr\n v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]"
+                       : "+v"(x), "+v"(own) : "v"(oa), "v"(ob), "v"(sel2), "v"(inc2), "n"(NOPS));
+        else
+          asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0]\n v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0]" : "+v"(x) : "v"(sel2), "v"(inc2));
+      }
       if (KIND == 2)   // the older bf16 MFMA with 64-bit operands
         asm volatile("v_mfma_f32_16x16x16_bf16 %1, %2, %3, %1\n .rept %c6\n s_nop 0\n .endr\n v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]"
                      : "+v"(x), "+v"(own) : "v"(inc2), "v"(sel2), "v"(sel2), "v"(inc2), "n"(NOPS));
@@ -200,13 +213,15 @@ __global__ __launch_bounds__(256) void own_gap(const s16x8* a_in, const s16x8* b
 
 template <int NOPS, int KIND>
 static void run_gap(const s16x8* a, const s16x8* b, unsigned* bad, float* sink) {
-  static const char* kinds[] = {"v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x4_f32", "v_mfma_f32_16x16x16_bf16"};
+  static const char* kinds[] = {"v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x4_f32", "v_mfma_f32_16x16x16_bf16",
+                                "pk ; v_mfma_f32_16x16x32_bf16 (every step)", "pk ; v_mfma_f32_16x16x32_bf16 (every 4th step)",
+                                "pk ; N x s_nop 0 ; v_mfma_f32_16x16x32_bf16 ; 16 wait states"};
   HIP_OK(hipMemset(bad, 0, 16 * sizeof(unsigned)));
   own_gap<NOPS, KIND><<<256, 256>>>(a, b, bad, sink, 500);
   HIP_OK(hipDeviceSynchronize());
   unsigned h[16];
   HIP_OK(hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost));
-  printf("same wave: %s ; %2d x s_nop 0 ; 2 dependent v_pk_fma_f32 op_sel:[0,1,0]: misses by [lane group] x [lo hi]:", kinds[KIND], NOPS);
+  printf("same wave: %s ; %2d x s_nop 0 ; %s v_pk_fma_f32 op_sel:[0,1,0]: misses by [lane group] x [lo hi]:", kinds[KIND], NOPS, KIND == 5 ? "(N counts the nops in FRONT of the MFMA) the dependent" : KIND >= 3 ? "the dependent" : "2 dependent");
   for (int g = 0; g < 4; ++g) printf(" | %u %u", h[g * 4], h[g * 4 + 1]);
   printf("\n");
 }
@@ -353,6 +368,7 @@ int main() {
   HIP_OK(hipMemcpy(want, hw.data(), 64 * 16, hipMemcpyHostToDevice));
   float* sink; HIP_OK(hipMalloc(&sink, 64));
   sweep_gap<0>(a, b, bad, sink); sweep_gap<1>(a, b, bad, sink); sweep_gap<2>(a, b, bad, sink);
+  sweep_gap<3>(a, b, bad, sink); sweep_gap<4>(a, b, bad, sink); sweep_gap<5>(a, b, bad, sink);
   if (getenv("GAP_ONLY")) return 0;
   sweep_cross<0>(a, b, bad, sink); sweep_cross<1>(a, b, bad, sink); sweep_cross<2>(a, b, bad, sink);
   sweep_cross<3>(a, b, bad, sink); sweep_cross<4>(a, b, bad, sink); sweep_cross<5>(a, b, bad, sink);
