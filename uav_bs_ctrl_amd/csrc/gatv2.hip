@@ -246,7 +246,12 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
   constexpr int oWop = oW + szW;
   constexpr int oRed = MF ? oWop : oWop + szWop;   // MF: the fold buffer of the last phase takes the place of the score operands (barrier in between)
   static_assert(!MF || szRed <= szWop, "fold buffer aliases the score operands");
-  constexpr int kLdsBytes = MF ? oWop + szWop : oRed + szRed;
+  // MF: the destination term -c of the score as the bias words of the W operands: per wavefront [channel tile][K group 0, 1][16
+  // channels] dwords (2 KB), and one all-zero table of the same shape for the lanes of K groups 2 and 3 (2 KB per workgroup)
+  constexpr int szC = MF ? (kWavesPerBlock + 1) * (H / 16) * 32 * 4 : 0;
+  constexpr int oC = oWop + szWop;
+  constexpr int kLdsBytes = MF ? oC + szC : oRed + szRed;
+  static_assert(kLdsBytes <= 80 * 1024, "two workgroups per CU");
   __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
   float* const sW = reinterpret_cast<float*>(lds + oW);
   float* const sRed = reinterpret_cast<float*>(lds + oRed);
@@ -261,8 +266,9 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
   if constexpr (MF) {
     for (int i = tid; i < (H / 16) * kWave; i += kThreads) {   // lane (j = channel of the tile, kg = feature)
       const int ct = i >> 6, l = i & 63;
-      sWop[i] = k1_a_operand(W_s[(16 * ct + (l & 15)) * FS + (l >> 4)], 0.f, 0);
+      sWop[i] = k1_a_operand(0.f - W_s[(16 * ct + (l & 15)) * FS + (l >> 4)], 0.f, 0);   // -W: the score MFMA yields -(z + c)
     }
+    for (int i = tid; i < (H / 16) * 32; i += kThreads) reinterpret_cast<unsigned*>(lds + oC)[kWavesPerBlock * (H / 16) * 32 + i] = 0u;
     for (int i = lane; i < NH * kWave; i += kWave)   // the zero row of every operand is never written again
       (reinterpret_cast<k1_u32x4*>(lds + oV) + (tid >> 6) * NH * kWave)[i] = k1_u32x4{0u, 0u, 0u, 0u};
   }
@@ -433,14 +439,21 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
           }
           k1_bf16x8 xop[2];
 #pragma unroll
-          for (int t = 0; t < 2; ++t) xop[t] = k1_b_operand(ew[(32 * tp + 16 * t + j16) * ES + g4], 0u);
+          for (int t = 0; t < 2; ++t) xop[t] = k1_b_operand(ew[(32 * tp + 16 * t + j16) * ES + g4], 0x3F803F80u);
           wave_sync_lds();
           k1_u32x4 vop = vw[16 * g4 + ((j16 + g4) & 15)], vop_n = vw[kWave + 16 * g4 + ((j16 + g4 + 4) & 15)];
-          k1_bf16x8 w_nn = __builtin_bit_cast(k1_bf16x8, sWop[kWave + lane]);
-          float nc = gw[j16], nc_n = gw[16 + j16];
+          // lane (channel j16, K group g4): W planes of feature g4 from the shared image, bias word from the wavefront's table
+          const unsigned* __restrict__ cwl = reinterpret_cast<const unsigned*>(lds + oC) +
+              (g4 < 2 ? wave * (H / 16) * 32 + 16 * g4 + j16 : kWavesPerBlock * (H / 16) * 32 + (lane & 31));
+          auto w_operand = [&](const int ct_) {
+            k1_u32x4 w = sWop[ct_ * kWave + lane];
+            w[3] = cwl[ct_ * 32];
+            return __builtin_bit_cast(k1_bf16x8, w);
+          };
+          k1_bf16x8 w_nn = w_operand(1);
           bwd_f32x4 d0, d1;
           {
-            const k1_bf16x8 w0 = __builtin_bit_cast(k1_bf16x8, sWop[lane]);
+            const k1_bf16x8 w0 = w_operand(0);
             d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xop[0], w0, czero, 0, 0, 0);
             d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xop[1], w0, czero, 0, 0, 0);
           }
@@ -448,23 +461,17 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
             bwd_f32x4 e0 = d0, e1 = d1;
-            float nc_nn = nc_n;
             if (ct + 1 < CT) {
               e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xop[0], w_nn, czero, 0, 0, 0);
               e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xop[1], w_nn, czero, 0, 0, 0);
-              if (ct + 2 < CT) {
-                w_nn = __builtin_bit_cast(k1_bf16x8, sWop[(ct + 2) * kWave + lane]);
-                nc_nn = gw[16 * (ct + 2) + j16];
-              }
+              if (ct + 2 < CT) w_nn = w_operand(ct + 2);
               __builtin_amdgcn_sched_barrier(0);
             }
             k1_u32x4 sg;
-            const k1_f32x2 nc2 = {nc, nc};
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              const k1_f32x2 t0 = nc2 - k1_f32x2{d0[2 * q], d0[2 * q + 1]}, t1 = nc2 - k1_f32x2{d1[2 * q], d1[2 * q + 1]};
-              const unsigned p0 = __builtin_amdgcn_perm(__float_as_uint(t0[1]), __float_as_uint(t0[0]), 0x07060302u);
-              const unsigned p1 = __builtin_amdgcn_perm(__float_as_uint(t1[1]), __float_as_uint(t1[0]), 0x07060302u);
+            for (int q = 0; q < 2; ++q) {   // d = -(z + c): the sign bits of two edges' values side by side over 1.0
+              const unsigned p0 = __builtin_amdgcn_perm(__float_as_uint(d0[2 * q + 1]), __float_as_uint(d0[2 * q]), 0x07060302u);
+              const unsigned p1 = __builtin_amdgcn_perm(__float_as_uint(d1[2 * q + 1]), __float_as_uint(d1[2 * q]), 0x07060302u);
               sg[q] = (p0 & k_sign) | (k_one & ~k_sign);
               sg[2 + q] = (p1 & k_sign) | (k_one & ~k_sign);
             }
@@ -477,8 +484,6 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
             __builtin_amdgcn_sched_barrier(0);
             d0 = e0;
             d1 = e1;
-            nc = nc_n;
-            nc_n = nc_nn;
           }
           wave_sync_lds();
         }
@@ -556,8 +561,16 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
         }
       }
       if constexpr (MF) {
+        {
+          unsigned* __restrict__ cwt = reinterpret_cast<unsigned*>(lds + oC) + wave * (H / 16) * 32;
 #pragma unroll
-        for (int j = 0; j < J; ++j) gw[lane + kWave * j] = 0.f - c[j];
+          for (int j = 0; j < J; ++j) {   // channel lane + 64 j = tile (lane >> 4) + 4 j, column lane & 15
+            const K1Split sc = k1_split(0.f - c[j]);
+            unsigned* q = cwt + ((lane >> 4) + 4 * j) * 32 + (lane & 15);
+            q[0] = (sc.h1 & 0xffffu) | (sc.h2 & 0xffff0000u);
+            q[16] = sc.h3 & 0xffffu;
+          }
+        }
         wave_sync();
         run_edges_mfma(deg);
       } else {
