@@ -161,12 +161,20 @@ def test_slice_agents_views_and_relation_order():
     assert big.relation_order("seen") is None          # fewer destinations than persistent wavefronts: no order needed
     N = 3000
     deg = th.as_tensor(rng.integers(0, 40, N))
+    deg[th.as_tensor(rng.random(N) < 0.5)] = 0         # sparse: mean in-degree below 16, isolated destinations to skip
     off = th.zeros(N + 1, dtype=th.int32)
     off[1:] = th.cumsum(deg, 0)
     wide = HeteroBatch.from_arrays(x_a=th.zeros(N, 2), x_gt=th.zeros(int(off[-1]), 4), seen_off=off)
     order = wide.relation_order("seen")
     d = deg[order.long()]
     assert sorted(order.tolist()) == list(range(N)) and bool((d[1:] <= d[:-1]).all())
+    # dense relations (mean in-degree >= 16) are handed out in natural order: the round robin over the persistent wavefronts
+    # balances by itself, the order's indirection and its four launches only cost (graph.py: relation_order)
+    deg = th.as_tensor(rng.integers(20, 40, N))
+    off = th.zeros(N + 1, dtype=th.int32)
+    off[1:] = th.cumsum(deg, 0)
+    dense = HeteroBatch.from_arrays(x_a=th.zeros(N, 2), x_gt=th.zeros(int(off[-1]), 4), seen_off=off)
+    assert dense.relation_order("seen") is None
     assert big.graph_off.tolist() == [0, 4, 8, 12]
 
 
