@@ -201,6 +201,35 @@ __global__ __launch_bounds__(kThreads) void gatv2_fwd_kernel(
 
 // ---------------------------------------------------------------------------------------------------------------
 // Partial-gradient row layout (floats): dW_s[H*FS] | db_s[H] | dW_d[2H] | db_d[H] | dattn[H] | dW_r[2H] | db_r[H]
+constexpr int kRowRorCtl = 0x120, kQuadXor1Ctl = 0xB1, kQuadXor2Ctl = 0x4E, kHalfMirrorCtl = 0x141;
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_allsum(float v) {
+  v += dpp_f<kRowRorCtl + 8>(v);
+  v += dpp_f<kRowRorCtl + 4>(v);
+  v += dpp_f<kRowRorCtl + 2>(v);
+  v += dpp_f<kRowRorCtl + 1>(v);
+  return v;
+}
+__device__ __forceinline__ float half8_allsum(float v) {
+  v += dpp_f<kQuadXor1Ctl>(v);
+  v += dpp_f<kQuadXor2Ctl>(v);
+  v += dpp_f<kHalfMirrorCtl>(v);
+  return v;
+}
+// total over the 64 lanes, the same value in every lane, without the LDS crossbar (__shfl_xor = ds_bpermute_b32: six dependent
+// round trips of ~100 cycles each): row sums by four DPP adds, rows 1 and 3 take lane 15 / 47 of the row below (row_bcast:15),
+// rows 2 and 3 lane 31 (row_bcast:31) - the last row then holds ((r2 + r3) + (r0 + r1)) - and lane 63 is read back through an
+// SGPR.  Seven instructions per value; deterministic (a fixed tree).
+__device__ __forceinline__ float wave_total_dpp(float v) {
+  v = row16_allsum(v);
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x142, 0xa, 0xf, false));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x143, 0xc, 0xf, false));
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
+}
+
 template <int FS>
 __host__ __device__ constexpr int partial_len(int H) { return H * (FS + 8); }
 
@@ -328,6 +357,17 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
     if (deg == 0) return;
 
     // G[k][f] = sum_d g[k,d] W_s[k,d,f]
+    if constexpr (D == kWave) {   // head k = register j: NH * FS wave totals straight from the registers, no LDS round trip
+      float gkf = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int f = 0; f < FS; ++f) {
+          const float tot = wave_total_dpp(g[j] * Ws[j][f]);
+          gkf = (lane == j * FS + f) ? tot : gkf;
+        }
+      if (lane < KF) gk[lane] = gkf;
+    } else {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const int n = lane + kWave * j;
@@ -345,6 +385,7 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
 #pragma unroll
       for (int o = PARTS / 2; o > 0; o >>= 1) gp += __shfl_xor(gp, o);
       if (part == 0) gk[kf] = gp;
+    }
     }
     wave_sync();
     float S1[J], S2[J][FS];
@@ -550,7 +591,7 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
         }
       }
 #pragma unroll
-      for (int k = 0; k < NH; ++k) T[k] = wave_sum(t[k]);
+      for (int k = 0; k < NH; ++k) T[k] = wave_total_dpp(t[k]);
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch) {
         const int slot = ch * kWave + lane;
@@ -598,7 +639,7 @@ __global__ __launch_bounds__(kThreads, UAVGNN_BWD_OCC) void gatv2_bwd_kernel(
           }
         }
 #pragma unroll
-        for (int k = 0; k < NH; ++k) T[k] = wave_sum(t[k]);
+        for (int k = 0; k < NH; ++k) T[k] = wave_total_dpp(t[k]);
       }
       for (int base = 0; base < deg; base += kWave) {
         {  // stage x_u, de_uk, a_uk of up to 64 edges in LDS (lane <-> edge)
@@ -823,24 +864,6 @@ inline int bwd_blocks(int N) { return capped_grid(N, kWavesPerBlock, kMaxBwdBloc
 //     lanes; degrees above 8 take further passes (any degree is correct);
 //   * same arithmetic, same partial-row layout and the same fixed-order two-stage reduction as the generic kernel
 //     (deterministic).
-constexpr int kRowRorCtl = 0x120, kQuadXor1Ctl = 0xB1, kQuadXor2Ctl = 0x4E, kHalfMirrorCtl = 0x141;
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row16_allsum(float v) {
-  v += dpp_f<kRowRorCtl + 8>(v);
-  v += dpp_f<kRowRorCtl + 4>(v);
-  v += dpp_f<kRowRorCtl + 2>(v);
-  v += dpp_f<kRowRorCtl + 1>(v);
-  return v;
-}
-__device__ __forceinline__ float half8_allsum(float v) {
-  v += dpp_f<kQuadXor1Ctl>(v);
-  v += dpp_f<kQuadXor2Ctl>(v);
-  v += dpp_f<kHalfMirrorCtl>(v);
-  return v;
-}
 
 __global__ __launch_bounds__(kThreads) void gatv2_bwd_pair_kernel(
     const float* __restrict__ x_src, const float* __restrict__ x_dst, const int32_t* __restrict__ seg_off, int N,
