@@ -379,6 +379,13 @@ int uavgnn_gemm_tn_x3(const float* dY, int ldy, int Mo, const float* X, int ldx,
                       int S, int accumulate, uavgnn_stream_t stream);
 int uavgnn_gru_gates_bwd_fused(const float* pre, const float* h, const float* d_hout, int N, int H, float* d_gi, float* d_gh,
                                float* d_h, uavgnn_stream_t stream);
+/* The same with the Q head's input gradient folded in: the gradient of h' is d_hout (NULL = 0) + dq W_out, dq [N, n_out] the
+ * gradient of q = h' W_out^T + b_out (reference: algos/madrqn/agents/gnn_agents.py:56 `self.f_out(h)` on the GRU output), W_out
+ * [n_out, H] row-major and 16-byte aligned, n_out <= 64.  Replaces `d_hout + dq @ W_out` followed by the call above: the [N, H]
+ * sum never reaches HBM.  UAVGNN_EUNSUPPORTED for H % 4 != 0, n_out > 64 or an unaligned W_out. */
+int uavgnn_gru_gates_bwd_fused_head(const float* pre, const float* h, const float* d_hout, const float* dq, int n_out,
+                                    const float* W_out, int N, int H, float* d_gi, float* d_gh, float* d_h,
+                                    uavgnn_stream_t stream);
 
 /* Backward of the fused GRU cell as ONE call (csrc/gru_bwd.hip; reference: autograd of nn.GRUCell at gnn_agents.py:246,:270
  * under learner.py:157): gate gradients from the pre-activation sets saved by the forward (pre [N, 4H]), d_inp [N, K_in]

@@ -2071,6 +2071,33 @@ def test_plane_cache_never_serves_a_recycled_weight_address():
     assert th.equal(g0, g1)
 
 
+@pytest.mark.parametrize("N,H,n_out,with_dh", [(1000, 256, 9, True), (333, 64, 5, False), (4099, 256, 16, True), (7, 32, 1, True)])
+def test_gate_gradient_kernel_with_the_head_gradient_folded_in(N, H, n_out, with_dh):
+    """uavgnn_gru_gates_bwd_fused_head(pre, h, d_hout, dq, W_out) == uavgnn_gru_gates_bwd_fused(pre, h, d_hout + dq W_out):
+    the gradient of h' formed inside the kernel (float64 reference for the sum), with and without an incoming d_hout."""
+    from uav_bs_ctrl_amd import _lib as L
+    gen = th.Generator().manual_seed(N + n_out)
+    dev = "cuda"
+    pre, h = th.randn(N, 4 * H, generator=gen).to(dev), th.randn(N, H, generator=gen).to(dev)
+    dq, W = th.randn(N, n_out, generator=gen).to(dev), (0.3 * th.randn(n_out, H, generator=gen)).to(dev)
+    d_hout = th.randn(N, H, generator=gen).to(dev) if with_dh else None
+    tot = (dq.double() @ W.double() + (d_hout.double() if with_dh else 0.0)).float().contiguous()
+    lib, st = L.lib(), L.stream()
+    ref = [th.empty(N, 3 * H, device=dev), th.empty(N, 3 * H, device=dev), th.empty(N, H, device=dev)]
+    got = [th.full_like(t, float("nan")) for t in ref]
+    assert lib.uavgnn_gru_gates_bwd_fused(pre.data_ptr(), h.data_ptr(), tot.data_ptr(), N, H, *[t.data_ptr() for t in ref], st) == 0
+    assert lib.uavgnn_gru_gates_bwd_fused_head(pre.data_ptr(), h.data_ptr(), L.ptr(d_hout), dq.data_ptr(), n_out, W.data_ptr(), N, H,
+                                               *[t.data_ptr() for t in got], st) == 0
+    th.cuda.synchronize()
+    for a, b, nm in zip(got, ref, ("d_gi", "d_gh", "d_h")):
+        assert_close(a, b, 2e-6, nm)
+    # argument errors: a head without dq, too many outputs
+    assert lib.uavgnn_gru_gates_bwd_fused_head(pre.data_ptr(), h.data_ptr(), None, None, n_out, W.data_ptr(), N, H,
+                                               *[t.data_ptr() for t in got], st) == L.UAVGNN_EINVAL
+    assert lib.uavgnn_gru_gates_bwd_fused_head(pre.data_ptr(), h.data_ptr(), None, dq.data_ptr(), 65, W.data_ptr(), N, H,
+                                               *[t.data_ptr() for t in got], st) != 0
+
+
 @pytest.mark.gpu
 def test_gru_cell_backward_as_one_c_abi_call_equals_the_host_sequence():
     """uavgnn_gru_cell_bwd ("uavgnn_gru_cell_{fwd,bwd}"): gate gradients + d_inp = d_gi W_ih + d_h += d_gh W_hh in

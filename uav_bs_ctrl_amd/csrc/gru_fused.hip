@@ -173,10 +173,14 @@ __global__ __launch_bounds__(256, 2) void gru_cell_fwd_kernel(
 }
 
 // pointwise backward from the saved pre-activation sets: d_gi [N,3H], d_gh [N,3H], d_h [N,H] (layout of gru.hip's kernel)
+// HEAD: the gradient of h' is d_hout (or 0) + dq W_out, the head's input gradient formed on the fly (n_out <= 16 FMAs per element
+// against rows of W_out that stay in L1): the [N, H] sum never goes through HBM and the rank-n_out GEMM launch disappears.
+template <bool HEAD>
 __global__ __launch_bounds__(256) void gru_gates_bwd_fused_kernel(const float* __restrict__ pre, const float* __restrict__ h,
                                                                   const float* __restrict__ d_hout, long long total, int H,
                                                                   float* __restrict__ d_gi, float* __restrict__ d_gh,
-                                                                  float* __restrict__ d_h) {
+                                                                  float* __restrict__ d_h, const float* __restrict__ dq,
+                                                                  int n_out, const float* __restrict__ W_out) {
   const int HV = H / 4;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
     const long long row = i / HV;
@@ -185,7 +189,18 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_fused_kernel(const float* _
     const float4 pr = *reinterpret_cast<const float4*>(p), pz = *reinterpret_cast<const float4*>(p + H);
     const float4 gin = *reinterpret_cast<const float4*>(p + 2 * H), ghn = *reinterpret_cast<const float4*>(p + 3 * H);
     const float4 hh = *reinterpret_cast<const float4*>(h + row * H + col);
-    const float4 dho = *reinterpret_cast<const float4*>(d_hout + row * H + col);
+    float4 dho = d_hout != nullptr ? *reinterpret_cast<const float4*>(d_hout + row * H + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (HEAD) {
+      const float* __restrict__ qr = dq + row * n_out;
+      for (int a = 0; a < n_out; ++a) {
+        const float qa = qr[a];
+        const float4 w = *reinterpret_cast<const float4*>(W_out + static_cast<size_t>(a) * H + col);
+        dho.x = fmaf(qa, w.x, dho.x);
+        dho.y = fmaf(qa, w.y, dho.y);
+        dho.z = fmaf(qa, w.z, dho.z);
+        dho.w = fmaf(qa, w.w, dho.w);
+      }
+    }
     const float a_pr[4] = {pr.x, pr.y, pr.z, pr.w}, a_pz[4] = {pz.x, pz.y, pz.z, pz.w};
     const float a_gi[4] = {gin.x, gin.y, gin.z, gin.w}, a_gh[4] = {ghn.x, ghn.y, ghn.z, ghn.w};
     const float a_h[4] = {hh.x, hh.y, hh.z, hh.w}, a_d[4] = {dho.x, dho.y, dho.z, dho.w};
@@ -248,7 +263,19 @@ extern "C" int uavgnn_gru_gates_bwd_fused(const float* pre, const float* h, cons
   if (H % 4) return UAVGNN_EUNSUPPORTED;
   if (N == 0) return 0;
   const long long total = static_cast<long long>(N) * (H / 4);
-  hipLaunchKernelGGL(gru_gates_bwd_fused_kernel, dim3(capped_grid(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     pre, h, d_hout, total, H, d_gi, d_gh, d_h);
+  hipLaunchKernelGGL(gru_gates_bwd_fused_kernel<false>, dim3(capped_grid(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     pre, h, d_hout, total, H, d_gi, d_gh, d_h, nullptr, 0, nullptr);
+  return launch_status();
+}
+
+extern "C" int uavgnn_gru_gates_bwd_fused_head(const float* pre, const float* h, const float* d_hout, const float* dq, int n_out,
+                                               const float* W_out, int N, int H, float* d_gi, float* d_gh, float* d_h,
+                                               uavgnn_stream_t stream) {
+  if (N < 0 || H <= 0 || n_out <= 0 || !pre || !h || !dq || !W_out || !d_gi || !d_gh || !d_h) return UAVGNN_EINVAL;
+  if (H % 4 || n_out > 64 || (reinterpret_cast<uintptr_t>(W_out) & 15)) return UAVGNN_EUNSUPPORTED;
+  if (N == 0) return 0;
+  const long long total = static_cast<long long>(N) * (H / 4);
+  hipLaunchKernelGGL(gru_gates_bwd_fused_kernel<true>, dim3(capped_grid(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     pre, h, d_hout, total, H, d_gi, d_gh, d_h, dq, n_out, W_out);
   return launch_status();
 }

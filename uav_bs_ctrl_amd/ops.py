@@ -431,7 +431,13 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save, inp2=None, h2_out=Non
     return h2, pre
 
 
-def _gru_gates_bwd_from_pre(pre, h, d_hout, d_gi=None, d_gh=None):
+# A/B switch: UAVGNN_HEAD_FUSED_BWD=0 forms d h' = d_hout + dq W_out with a vendor GEMM in front of the gate kernel
+HEAD_FUSED_BWD = os.environ.get("UAVGNN_HEAD_FUSED_BWD", "1") != "0"
+
+
+def _gru_gates_bwd_from_pre(pre, h, d_hout, d_gi=None, d_gh=None, head=None):
+    """Gate gradients from the saved pre-activation sets.  ``head`` = (dq [N, n_out], W_out [n_out, H]): the gradient of h' is
+    d_hout (None = 0) + dq W_out, formed inside the kernel (uavgnn_gru_gates_bwd_fused_head)."""
     N, H = h.shape
     if d_gi is None:
         d_gi = th.empty((N, 3 * H), dtype=th.float32, device=h.device)
@@ -439,8 +445,14 @@ def _gru_gates_bwd_from_pre(pre, h, d_hout, d_gi=None, d_gh=None):
         d_gh = th.empty_like(d_gi)
     dh = th.empty_like(h)
     with KERNEL_TIMER.span("gru_gates_bwd"):
-        rc = L.lib().uavgnn_gru_gates_bwd_fused(pre.data_ptr(), h.data_ptr(), d_hout.data_ptr(), N, H, d_gi.data_ptr(),
-                                                d_gh.data_ptr(), dh.data_ptr(), L.stream())
+        if head is not None:
+            dq, W_out = head
+            rc = L.lib().uavgnn_gru_gates_bwd_fused_head(pre.data_ptr(), h.data_ptr(), L.ptr(d_hout), dq.data_ptr(), dq.shape[1],
+                                                         W_out.data_ptr(), N, H, d_gi.data_ptr(), d_gh.data_ptr(), dh.data_ptr(),
+                                                         L.stream())
+        else:
+            rc = L.lib().uavgnn_gru_gates_bwd_fused(pre.data_ptr(), h.data_ptr(), d_hout.data_ptr(), N, H, d_gi.data_ptr(),
+                                                    d_gh.data_ptr(), dh.data_ptr(), L.stream())
     L.check(rc, "uavgnn_gru_gates_bwd_fused")
     return d_gi, d_gh, dh
 
@@ -949,7 +961,16 @@ class _TarmacStep(th.autograd.Function):
             raise L.UavGnnError("tarmac_step: backward through a forward that saved no pre-activations (train=False)")
         sink = GRAD_SINK
         dq = L.f32c(dq) if dq is not None else th.zeros((N, W_out.shape[0]), dtype=th.float32, device=x.device)
-        if dh2 is None:
+        # d h' = d_hout + dq W_out inside the gate kernel when the cell ran fused (its pre-activation sets are what that kernel reads)
+        head = None
+        if (HEAD_FUSED_BWD and ctx.fused_gru and H % 4 == 0 and W_out.shape[0] <= 64 and W_out.is_contiguous()
+                and W_out.dtype == th.float32 and W_out.data_ptr() % 16 == 0
+                and (dh2 is None or (dh2.is_contiguous() and dh2.dtype == th.float32 and dh2.shape == (N, H)))):
+            head = (dq, W_out.detach())
+            dh2_tot = dh2
+            if sink is not None:
+                sink.owned.clear()
+        elif dh2 is None:
             dh2_tot = th.mm(dq, W_out)
         elif (sink is not None and dh2.is_contiguous() and dh2.dtype == th.float32 and dh2.shape == (N, H)
               and sink.owned.get(dh2.data_ptr()) is not None):
@@ -964,9 +985,10 @@ class _TarmacStep(th.autograd.Function):
         seq = ctx.seq if (sink is not None and ctx.seq is not None and sink.seq is ctx.seq) else None
         if seq is not None:      # staged sequence: the gate gradients go straight into the time-batched buffers
             t = ctx.seq_t
-            d_gi, d_gh, dh = _gru_gates_bwd_from_pre(gi, h, dh2_tot, seq.slot("d_gi", t, 3 * H), seq.slot("d_gh", t, 3 * H))
+            d_gi, d_gh, dh = _gru_gates_bwd_from_pre(gi, h, dh2_tot, seq.slot("d_gi", t, 3 * H), seq.slot("d_gh", t, 3 * H),
+                                                     head=head)
         elif ctx.fused_gru:
-            d_gi, d_gh, dh = _gru_gates_bwd_from_pre(gi, h, dh2_tot)      # gi holds the saved pre-activation sets
+            d_gi, d_gh, dh = _gru_gates_bwd_from_pre(gi, h, dh2_tot, head=head)      # gi holds the saved pre-activation sets
         else:
             d_gi, d_gh, dh = th.empty_like(gi), th.empty_like(gh), th.empty_like(h)
             with KERNEL_TIMER.span("gru_gates_bwd"):
