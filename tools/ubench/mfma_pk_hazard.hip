@@ -14,6 +14,7 @@
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
@@ -174,6 +175,8 @@ __global__ __launch_bounds__(256) void own_gap(const s16x8* a_in, const s16x8* b
   const int lane = threadIdx.x & 63;
   const s16x8 oa = a_in[lane], ob = b_in[lane];
   f32x4 own = {0.f, 0.f, 0.f, 0.f};
+  f32x16 own16;
+  for (int i = 0; i < 16; ++i) own16[i] = 0.f;
   const f32x2 inc2 = {1.f, 2.f}, sel2 = {0.f, 1.f};
   const float fa = 1.f, fb = 0.5f;
   unsigned miss[2] = {0u, 0u};
@@ -192,6 +195,15 @@ __global__ __launch_bounds__(256) void own_gap(const s16x8* a_in, const s16x8* b
       if (KIND == 5)   // the wait states between the FIRST packed FMA and the MFMA that follows it
         asm volatile("v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n .rept %c6\n s_nop 0\n .endr\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n s_nop 7\n s_nop 7\n v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n s_nop 7"
                      : "+v"(x), "+v"(own) : "v"(oa), "v"(ob), "v"(sel2), "v"(inc2), "n"(NOPS));
+      if (KIND == 6)   // the 32x32x16 bf16 MFMA (the GRU cell's / the GEMMs') right behind the packed FMA
+        asm volatile("v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n .rept %c6\n s_nop 0\n .endr\n v_mfma_f32_32x32x16_bf16 %1, %2, %3, %1\n s_nop 7\n s_nop 7\n v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n s_nop 7"
+                     : "+v"(x), "+v"(own16) : "v"(oa), "v"(ob), "v"(sel2), "v"(inc2), "n"(NOPS));
+      if (KIND == 7)   // fp8 16x16x128 is not used here; the f16 16x16x32 MFMA
+        asm volatile("v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n .rept %c6\n s_nop 0\n .endr\n v_mfma_f32_16x16x32_f16 %1, %2, %3, %1\n s_nop 7\n s_nop 7\n v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n s_nop 7"
+                     : "+v"(x), "+v"(own) : "v"(oa), "v"(ob), "v"(sel2), "v"(inc2), "n"(NOPS));
+      if (KIND == 8)   // the fp32 16x16x4 MFMA right behind the packed FMA (control)
+        asm volatile("v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n .rept %c6\n s_nop 0\n .endr\n v_mfma_f32_16x16x4_f32 %1, %2, %3, %1\n s_nop 7\n s_nop 7\n v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n s_nop 7"
+                     : "+v"(x), "+v"(own) : "v"(fa), "v"(fb), "v"(sel2), "v"(inc2), "n"(NOPS));
       if (KIND == 4) {  // ... on every fourth step only (three plain steps of two packed FMAs in between)
         if ((k & 3) == 0)
           asm volatile("v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]\n v_mfma_f32_16x16x32_bf16 %1, %2, %3, %1\n .rept %c6\n s_nop 0\n .endr\n v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0]"
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(256) void own_gap(const s16x8* a_in, const s16x8* b
     miss[0] += (x[0] != static_cast<float>(lane + 128)) ? 1u : 0u;
     miss[1] += (x[1] != static_cast<float>(2 * lane + 256)) ? 1u : 0u;
   }
-  if (own[0] + own[1] + own[2] + own[3] == 123.456f) sink[1] = own[0];
+  if (own[0] + own[1] + own[2] + own[3] + own16[0] + own16[7] == 123.456f) sink[1] = own[0];
   for (int r = 0; r < 2; ++r)
     if (miss[r]) atomicAdd(&bad[(lane >> 4) * 4 + r], miss[r]);
 }
@@ -215,13 +227,15 @@ template <int NOPS, int KIND>
 static void run_gap(const s16x8* a, const s16x8* b, unsigned* bad, float* sink) {
   static const char* kinds[] = {"v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x4_f32", "v_mfma_f32_16x16x16_bf16",
                                 "pk ; v_mfma_f32_16x16x32_bf16 (every step)", "pk ; v_mfma_f32_16x16x32_bf16 (every 4th step)",
-                                "pk ; N x s_nop 0 ; v_mfma_f32_16x16x32_bf16 ; 16 wait states"};
+                                "pk ; N x s_nop 0 ; v_mfma_f32_16x16x32_bf16 ; 16 wait states",
+                                "pk ; N x s_nop 0 ; v_mfma_f32_32x32x16_bf16 ; 16 wait states", "pk ; N x s_nop 0 ; v_mfma_f32_16x16x32_f16 ; 16 wait states",
+                                "pk ; N x s_nop 0 ; v_mfma_f32_16x16x4_f32 ; 16 wait states"};
   HIP_OK(hipMemset(bad, 0, 16 * sizeof(unsigned)));
   own_gap<NOPS, KIND><<<256, 256>>>(a, b, bad, sink, 500);
   HIP_OK(hipDeviceSynchronize());
   unsigned h[16];
   HIP_OK(hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost));
-  printf("same wave: %s ; %2d x s_nop 0 ; %s v_pk_fma_f32 op_sel:[0,1,0]: misses by [lane group] x [lo hi]:", kinds[KIND], NOPS, KIND == 5 ? "(N counts the nops in FRONT of the MFMA) the dependent" : KIND >= 3 ? "the dependent" : "2 dependent");
+  printf("same wave: %s ; %2d x s_nop 0 ; %s v_pk_fma_f32 op_sel:[0,1,0]: misses by [lane group] x [lo hi]:", kinds[KIND], NOPS, KIND >= 5 ? "(N counts the nops in FRONT of the MFMA) the dependent" : KIND >= 3 ? "the dependent" : "2 dependent");
   for (int g = 0; g < 4; ++g) printf(" | %u %u", h[g * 4], h[g * 4 + 1]);
   printf("\n");
 }
@@ -369,6 +383,7 @@ int main() {
   float* sink; HIP_OK(hipMalloc(&sink, 64));
   sweep_gap<0>(a, b, bad, sink); sweep_gap<1>(a, b, bad, sink); sweep_gap<2>(a, b, bad, sink);
   sweep_gap<3>(a, b, bad, sink); sweep_gap<4>(a, b, bad, sink); sweep_gap<5>(a, b, bad, sink);
+  sweep_gap<6>(a, b, bad, sink); sweep_gap<7>(a, b, bad, sink); sweep_gap<8>(a, b, bad, sink);
   if (getenv("GAP_ONLY")) return 0;
   sweep_cross<0>(a, b, bad, sink); sweep_cross<1>(a, b, bad, sink); sweep_cross<2>(a, b, bad, sink);
   sweep_cross<3>(a, b, bad, sink); sweep_cross<4>(a, b, bad, sink); sweep_cross<5>(a, b, bad, sink);
