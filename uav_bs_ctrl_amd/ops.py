@@ -431,6 +431,7 @@ def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save, inp2=None, h2_out=Non
     return h2, pre
 
 
+DINP_SPLIT = os.environ.get("UAVGNN_DINP_SPLIT", "1") != "0"   # _TarmacStep.backward: d x and d c of the GRU input as two products
 # A/B switch: UAVGNN_HEAD_FUSED_BWD=0 forms d h' = d_hout + dq W_out with a vendor GEMM in front of the gate kernel
 HEAD_FUSED_BWD = os.environ.get("UAVGNN_HEAD_FUSED_BWD", "1") != "0"
 
@@ -995,7 +996,20 @@ class _TarmacStep(th.autograd.Function):
                 rc = L.lib().uavgnn_gru_gates_bwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), dh2_tot.data_ptr(), N, H,
                                                   d_gi.data_ptr(), d_gh.data_ptr(), dh.data_ptr(), L.stream())
             L.check(rc, "uavgnn_gru_gates_bwd")
-        d_inp = _mm_nn(d_gi, W_ih)                                         # [N, H + M]: d x | d c
+        # d_inp = d_gi W_ih is [N, H + M]: d x | d c.  When the bf16x3 GEMM has the H-column shape, the two halves are separate
+        # products: d x lands where the caller wants it (the slice of the time-split gradient buffer) and the projection term is
+        # accumulated into it in place - no [N, H] copy in front of the addmm, and 256 of the 320 columns leave the vendor's
+        # 64 x 32-tile solution (134 us) for the matrix-core kernel (A/B: UAVGNN_DINP_SPLIT=0)
+        split_dinp = (DINP_SPLIT and M > 0 and W_ih.stride(1) == 1 and gemm_x3_supported(d_gi, H, W_ih.shape[0])
+                      and (ctx.dx_out is None or (ctx.dx_out.stride(1) == 1 and ctx.dx_out.dtype == th.float32)))
+        if split_dinp:
+            dx = ctx.dx_out if ctx.dx_out is not None else th.empty((N, H), dtype=th.float32, device=x.device)
+            _mm_nn(d_gi, W_ih[:, :H], out=dx)
+            d_c = th.mm(d_gi, W_ih[:, H:])                                 # [N, M]
+            d_c_ptr, d_c_ld = d_c.data_ptr(), M
+        else:
+            d_inp = _mm_nn(d_gi, W_ih)
+            d_c_ptr, d_c_ld = d_inp.data_ptr() + 4 * H, H + M
         _mm_nn(d_gh, W_hh, out=dh, accumulate=True)
         if sink is not None:
             sink.owned.clear()
@@ -1003,14 +1017,17 @@ class _TarmacStep(th.autograd.Function):
         ld = M + 2 * K
         d_proj = th.empty((N, ld), dtype=th.float32, device=x.device) if seq is None else seq.slot("d_proj", ctx.seq_t, ld)
         _launch_talk_bwd(ctx.env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld,
-                         K, M, talk_off, talk_src, (t_off, t_dst, t_pos), N, 1.0 / K, a_save, d_inp.data_ptr() + 4 * H,
-                         H + M, d_proj.data_ptr() + 4 * M, ld, d_proj.data_ptr() + 4 * (M + K), ld, d_proj.data_ptr(),
+                         K, M, talk_off, talk_src, (t_off, t_dst, t_pos), N, 1.0 / K, a_save, d_c_ptr,
+                         d_c_ld, d_proj.data_ptr() + 4 * M, ld, d_proj.data_ptr() + 4 * (M + K), ld, d_proj.data_ptr(),
                          ld)
-        dx = ctx.dx_out                                                    # slice of the time-split gradient buffer
-        if dx is not None:
-            th.addmm(d_inp[:, :H], d_proj, Wp[:, :H], out=dx)
+        if split_dinp:
+            dx.addmm_(d_proj, Wp[:, :H])                                   # h enters the projections stop-gradded
         else:
-            dx = th.addmm(d_inp[:, :H], d_proj, Wp[:, :H])                # h enters the projections stop-gradded
+            dx = ctx.dx_out                                                # slice of the time-split gradient buffer
+            if dx is not None:
+                th.addmm(d_inp[:, :H], d_proj, Wp[:, :H], out=dx)
+            else:
+                dx = th.addmm(d_inp[:, :H], d_proj, Wp[:, :H])
         if seq is not None:      # reduced once per sequence (WeightGradSink.end_sequence)
             seq.slot("dq", ctx.seq_t, dq.shape[1]).copy_(dq)
             seq.bwd_steps.append(ctx.seq_t)
