@@ -29,6 +29,7 @@ import argparse
 import gc
 import json
 import os
+import re
 import sys
 import time
 import types
@@ -515,6 +516,134 @@ def k1_roofline(k, a, dist_name, clock_mhz):
                      "5.2-6.2 TB/s on this part, profiles/r04_k1_standalone.txt)")}
 
 
+def k1_env_standalone(learner, g, a, reps=50, rounds=5):
+    """The graded kernel ALONE and back to back, inside the driver's run: `reps` launches of the fused K1 forward (prepared
+    parameter image, `uavgnn_gatv2_hetero_fwd_image`: the launch every rollout step of `learner.act` makes) on ONE D-env rollout
+    batch, recorded into a hipGraph and replayed between ONE HIP-event pair - so the span holds `reps` kernels + their `reps - 1`
+    dependent-launch boundaries and ONE event floor (4.5-6.3 us / `reps`), instead of one floor per launch as in
+    `by_launch_class.rollout` (events around every launch of the cycle).  What tools/ubench/k1_env_bench.hip measures on the
+    builder's side (profiles/r0*_k1_standalone.txt), here through the product's own op (`ops.hetero_gatv2`) and C-ABI entry.
+    Median of `rounds` replays after two warm-up replays; algorithmic bytes as `alg_k1_fwd`."""
+    from uav_bs_ctrl_amd import ops
+    enc = learner.policy_net.enc
+    x_a = g.agent_feat()
+    rels = []
+    for et in ("seen", "near"):
+        x_src, off = g.relation_segments(et)
+        rels.append((x_src, off, g.relation_order(et), enc.f_conv[et]))
+    E_s, E_n, N = rels[0][0].shape[0], rels[1][0].shape[0], x_a.shape[0]
+    store = {}
+    graph = th.cuda.CUDAGraph()
+    with th.no_grad(), ops.frozen_weights(store):
+        ops.hetero_gatv2(x_a, enc._n_heads, rels)           # builds the image + any derived index outside the capture
+        th.cuda.synchronize()
+        with th.cuda.graph(graph):
+            for _ in range(reps):
+                out = ops.hetero_gatv2(x_a, enc._n_heads, rels)
+    took_image = any(k[0] == "k1img" for k in store)
+    ms = []
+    for i in range(rounds + 2):
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        e0.record()
+        graph.replay()
+        e1.record()
+        e1.synchronize()
+        if i >= 2:
+            ms.append(e0.elapsed_time(e1))
+    del graph, out
+    med = sorted(ms)[len(ms) // 2]
+    by, fl = alg_k1_fwd(E_s, E_n, N, False, False)
+    us = 1e3 * med / reps
+    return {"launches_per_span": reps, "spans": rounds, "us_per_launch": us, "us_per_launch_all": [round(1e3 * m / reps, 3) for m in ms],
+            "alg_bytes_per_launch": by, "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "tflops": fl / (us * 1e-6) / 1e12,
+            "prepared_image": took_image, "destinations": N, "seen_edges": E_s, "near_edges": E_n,
+            "how": f"{reps} launches recorded into a hipGraph and replayed between ONE HIP-event pair (launch boundaries included, "
+                   "one event floor per span), no-grad rollout launch through ops.hetero_gatv2 -> uavgnn_gatv2_hetero_fwd_image"}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(a):
+    """``python3 bench.py --gpus N`` started PLAIN (no RANK / WORLD_SIZE in the environment - the way the driver starts the N = 1
+    run) starts its N ranks itself: it re-executes this file under ``python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>`` - one process per GPU over RCCL, exactly the
+    documented launch form, which keeps working unchanged (a process that finds RANK in its environment is a rank and never
+    re-launches).  The reference's counterpart is ``mpi_fork`` (utils/mpi_tools.py:6-36: re-exec under ``mpirun -np n``).
+    Returns the exit code of the launcher; rank 0's ONE JSON line goes to this process's stdout untouched."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")                # torch.distributed.run would set 1 and say so on stderr
+    env["UAVGNN_BENCH_SELF_LAUNCHED"] = "1"
+    print(f"[bench] --gpus {a.gpus} without RANK/WORLD_SIZE: launching {a.gpus} ranks via torch.distributed.run", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def rccl_transport_summary(path):
+    """What RCCL said about its transports in this rank's NCCL_DEBUG=INFO log (set by this file before the communicator is
+    created when the caller did not choose a debug level): `Channel .. via <transport>` lines counted per transport, plus the
+    lines that name the topology / xGMI.  None when the log is missing (gloo test hook, or a caller-owned NCCL_DEBUG)."""
+    try:
+        lines = open(path, errors="replace").read().splitlines()
+    except OSError:
+        return None
+    via, topo = {}, []
+    for ln in lines:
+        m = re.search(r"\bvia\s+([A-Za-z0-9_/+ -]+?)(?:\s*$|\s+comm|\s*\[)", ln)
+        if m and "Channel" in ln:
+            via[m.group(1).strip()] = via.get(m.group(1).strip(), 0) + 1
+        if re.search(r"xgmi|XGMI|Connected all|nRanks|topology|Trees|Rings? ", ln) and len(topo) < 12:
+            topo.append(ln.split("NCCL INFO", 1)[-1].strip()[:200])
+    return {"channel_transports": via, "lines": topo, "log_lines": len(lines), "source": "NCCL_DEBUG=INFO log of rank 0"}
+
+
+def dry_launch_main(a, world, rank):
+    """Test hook UAVGNN_BENCH_DRY=1 (tests/test_bench_launch.py, CPU container: no GPU): everything of the launch contract that
+    does not need a device - rank discovery, process-group rendezvous (gloo), barrier-bracketed timing of K trivial steps,
+    MAX over ranks, ONE JSON line from rank 0 - so that both launch forms (plain ``python3 bench.py --gpus N`` and
+    ``torch.distributed.run``) are exercised where the kernels cannot run.  The line says ``dry_run``; it is not a measurement."""
+    if world > 1:
+        dist.init_process_group("gloo")
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    el = th.tensor([time.perf_counter() - t0], dtype=th.float64)
+    ck = th.tensor([1.0, 2.0], dtype=th.float64)
+    same = True
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        lo, hi = ck.clone(), ck.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same = bool(th.equal(lo, hi))
+    if rank == 0:
+        print(json.dumps({"metric": metric_name(a), "value": 0.0, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": 1e3 * float(el) / max(a.steps, 1), "dry_run": True,
+                          "replicas_identical": same, "rccl_ranks": world,
+                          "self_launched": os.environ.get("UAVGNN_BENCH_SELF_LAUNCHED") == "1",
+                          "config": {"global_batch": world * a.B, "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def metric_name(a):
+    """BASELINE.json's metric with the sizes of THIS run (the headline run is 8 UBS x 80 GT)."""
+    return f"env-steps/sec (MADRQN, {a.n} UBS x {a.M} GT)"
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -537,10 +666,18 @@ def main():
                     help="skip the second timing with the bf16x3 kernels off (fp32-MFMA GRU cell, vendor fp32 GEMMs)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # plain `python3 bench.py --gpus N`: this process is the launcher, not a rank
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but this rank was started with WORLD_SIZE={world} (RANK={rank}); start it as "
+                 f"`python3 bench.py --gpus {a.gpus}` (it launches its ranks itself) or as `python -m torch.distributed.run "
+                 f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {a.gpus} ...`")
+    if os.environ.get("UAVGNN_BENCH_DRY") == "1":
+        return dry_launch_main(a, world, rank)
     # test hooks (tests/test_dp_gpu.py): all ranks on ONE device over gloo, so that the world-size-2 code path of this file
     # runs on a one-GPU box (RCCL refuses two ranks on one device).  Never set by the driver: one rank per GPU over RCCL.
     backend = os.environ.get("UAVGNN_BENCH_BACKEND", "nccl")
@@ -549,9 +686,14 @@ def main():
     th.cuda.set_device(local)
     device = th.device("cuda", local)
     use_dist = world > 1 or (a.force_dist and "RANK" in os.environ)
+    rccl_log = None
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
+            if "NCCL_DEBUG" not in os.environ:   # the run explains its own transport: INFO log of the communicator set-up, per rank
+                import tempfile
+                rccl_log = os.path.join(tempfile.gettempdir(), f"uavgnn_rccl_rank{rank}_{os.getpid()}.log")
+                os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,P2P", NCCL_DEBUG_FILE=rccl_log)
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
@@ -632,14 +774,19 @@ def main():
         lo, hi = ck.clone(), ck.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        assert th.equal(lo, hi), "parameter replicas diverged"
+        replicas_identical = bool(th.equal(lo, hi))
+        assert replicas_identical, "parameter replicas diverged"
+    else:
+        replicas_identical = True
 
     if rank == 0:
         env_steps = world * a.B * a.T * a.steps
         # SURVEY 8d names: C3 = BASELINE configs[2] (8 x 80, B = 4096); anything else is labelled by its own sizes
         label = {(8, 80, 4096): "C3", (4, 40, 1024): "C2", (16, 200, 1024): "C5 (per-GPU shard)"}.get((a.n, a.M, a.B), "custom")
         res = {
-            "metric": "env-steps/sec (MADRQN, 8 UBS x 80 GT)", "value": env_steps / elapsed, "unit": "env-steps/s",
+            "metric": metric_name(a), "value": env_steps / elapsed, "unit": "env-steps/s",
+            "replay_ratio": 1,                 # the headline cycle trains each stored sequence once; the reference's own operating point
+                                               # (run.py:55-57,:97: rho = 32) is `value_rho32` below, from the `replay_ratio_leg`
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}: {a.n} UBS x {a.M} GT, exp3 MADRQN (GATv2 obs-encoder + TarMAC), "
@@ -651,6 +798,9 @@ def main():
             "tuned_gemms": bool(tuned),        # recorded vendor-GEMM solutions (uav_bs_ctrl_amd/tuned/gemm_gfx950.csv) accepted by this box's hipBLASLt
             "shader_clock": clock_info,        # sustained clock of the timed region (the part runs at its power limit: DESIGN.md section 6)
             "rccl_ranks": (dist.get_world_size() if use_dist else 1),
+            "replicas_identical": replicas_identical,   # parameter checksums (sum, sum of squares) min == max over the ranks after the timed steps
+            "self_launched": os.environ.get("UAVGNN_BENCH_SELF_LAUNCHED") == "1",   # plain `python3 bench.py --gpus N` started its own ranks
+            "rccl_transport": rccl_transport_summary(rccl_log) if rccl_log else None,
             "collective_backend": (None if not use_dist else
                                    {"backend": dist.get_backend(), "rccl_version": ".".join(map(str, th.cuda.nccl.version())),
                                     "NCCL_DEBUG": os.environ.get("NCCL_DEBUG"),
@@ -761,6 +911,10 @@ def main():
                               "env_steps_per_s": a.B * a.T * a.env_steps / e1, "shader_clock": ce,
                               "workload": f"the same cycle on D-env degrees (B={a.B}, {a.n} x {a.M}): {a.env_steps} timed steps after "
                                           "one warm-up, K1 forward between HIP events as in the timed region"})
+                try:
+                    r_env["standalone"] = k1_env_standalone(learner, env_batch["obs"][0].fresh(), a)
+                except Exception as e:   # noqa: BLE001 - a diagnostic leg never breaks the bench line
+                    r_env["standalone"] = {"error": repr(e)}
                 res["roofline_env"] = r_env
             del env_batch
         if world == 1 and not a.no_rho_leg:
@@ -783,6 +937,7 @@ def main():
             th.cuda.synchronize()
             e1 = time.perf_counter() - t1
             gc.enable()
+            res["value_rho32" if rho == 32 else f"value_rho{rho}"] = a.B * a.T / e1    # env-steps/s at the reference's replay ratio
             res["replay_ratio_leg"] = {"rho": rho, "value": a.B * a.T / e1, "unit": "env-steps/s", "steps": 1,
                                        "ms_per_step": 1e3 * e1, "sequences_per_update": rho * a.B,
                                        "transitions_trained_per_s": rho * a.B * a.T / e1,

@@ -143,7 +143,7 @@ def test_dp2_hip_agent_gradient_and_step_equal_single_process_on_concatenated_ba
     assert float((res["target"] - targ).abs()[resolved].max()) <= 2e-6
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1500)
 def test_bench_at_world_size_two_on_one_device():
     """bench.py launched as the driver launches it for N = 2 (torch.distributed.run, two ranks, --gpus 2), both ranks mapped to
     cuda:0 over gloo by the file's test hooks: per-rank shards (seed 1234 + rank), barrier-bracketed timing with the max over
@@ -166,6 +166,18 @@ def test_bench_at_world_size_two_on_one_device():
     assert r2["scaling"] == "weak" and r2["steps"] == 2 and r2["warmup"] == 1
     assert abs(r2["value"] - 2 * 64 * 4 * 2 / (r2["ms_per_step"] * 2e-3)) <= 1e-6 * r2["value"]
     assert "roofline" in r2 and "cpu_baseline" not in r2 and "end_to_end" not in r2
+    assert r2["replicas_identical"] is True and r2["self_launched"] is False and r2["rccl_ranks"] == 2
+    # the PLAIN form: `python3 bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment launches its own two ranks and gives
+    # the same job (same shards, same arithmetic: identical parameter checksum and loss)
+    plain_env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    plain = subprocess.run([sys.executable, "bench.py", "--gpus", "2", *small], cwd=root, env=plain_env, capture_output=True,
+                           text=True, timeout=800)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    lines = [ln for ln in plain.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, plain.stdout[-2000:]
+    rp = json.loads(lines[0])
+    assert rp["n_gpus"] == 2 and rp["self_launched"] is True and rp["replicas_identical"] is True
+    assert rp["params_checksum"] == r2["params_checksum"] and rp["loss"] == r2["loss"]
     one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", *small, "--no-cpu-baseline", "--no-end-to-end",
                           "--no-fp32-leg", "--no-rho-leg"], cwd=root, env=dict(os.environ), capture_output=True, text=True,
                          timeout=800)

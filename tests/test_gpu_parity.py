@@ -2250,17 +2250,20 @@ def test_fused_hetero_k1_prepared_image_is_bit_identical_and_follows_the_paramet
 
 
 @pytest.mark.gpu
-def test_rollout_weight_cache_of_the_learner_is_invalidated_by_every_parameter_change(monkeypatch):
+@pytest.mark.parametrize("key_size", [16, 32])
+def test_rollout_weight_cache_of_the_learner_is_invalidated_by_every_parameter_change(monkeypatch, key_size):
     """MultiAgentQLearner.act keeps weight planes and the K1 parameter image between optimiser steps (ops.frozen_weights store
     owned by the learner).  Rollout -> update -> rollout with the cache gives the same actions / hidden states as the same
-    sequence with the cache switched off; load_state_dict (version counters) and load_checkpoint are seen as well."""
+    sequence with the cache switched off; load_state_dict (version counters) and load_checkpoint are seen as well.
+    key_size 32: msg + 2 key = 128 projection columns at 4096 rows - the one shape where TarMAC's STACKED projection weight (a
+    `.data` view with its own version counter) goes through the bf16x3 GEMM and its plane cache (a stale hit there)."""
     import copy
     from uav_bs_ctrl_amd import ops
     import bench
 
     def episode(cache_on):
         monkeypatch.setattr(ops, "K1_IMAGE", cache_on)
-        learner, batch = _small_learner_and_batch(B=512, n=8, M=20, T=2, seed=5)
+        learner, batch = _small_learner_and_batch(B=512, n=8, M=20, T=2, seed=5, key_size=key_size)
         if not cache_on:       # no persistent store at all: every call rebuilds its planes
             monkeypatch.setattr(learner, "_rollout_planes", None)
         gen = th.Generator(device="cuda")
@@ -2281,6 +2284,10 @@ def test_rollout_weight_cache_of_the_learner_is_invalidated_by_every_parameter_c
         for k in sd:
             sd[k] = sd[k] * 0.5
         learner.policy_net.load_state_dict(sd)        # behind the learner's back, but through torch: version counters
+        acts, h = learner.act(obs, h, 0.0)
+        outs += [acts.clone(), h.clone()]
+        with th.no_grad():                            # an in-place edit of ONE member of the stacked projection weight
+            dict(learner.policy_net.named_parameters())[[k for k in sd if k.endswith("f_que.weight")][0]].mul_(-3.0)
         acts, h = learner.act(obs, h, 0.0)
         outs += [acts.clone(), h.clone()]
         return outs

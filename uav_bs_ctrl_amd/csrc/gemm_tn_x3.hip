@@ -155,10 +155,12 @@ extern "C" int uavgnn_gemm_tn_x3_chunks(long long n_rows, int Mo, int Ko) {
   const int tiles = ((Mo + BM - 1) / BM) * ((Ko + BN - 1) / BN);
   long long S = 512 / tiles;
   if (S < 1) S = 1;
-  const long long max_s = (n_rows + 255) / 256;
-  if (S > max_s) S = max_s;
   if (S > 256) S = 256;                      // few-tile outputs (a 96- or 9-row weight): enough chunks to fill the chip
-  if (S >= 8) S = (S + 7) / 8 * 8;           // whole rounds over the 8 XCDs (the kernel's tile order relies on it)
+#if GEMM_TN_XCD_ORDER
+  if (S >= 8) S = (S + 7) / 8 * 8;           // whole rounds over the 8 XCDs (the kernel's XCD-local tile order relies on it)
+#endif
+  const long long max_s = (n_rows + 255) / 256;   // clamped LAST: no empty row chunks, no partial buffers larger than the rows justify
+  if (S > max_s) S = max_s;
   return static_cast<int>(S);
 }
 

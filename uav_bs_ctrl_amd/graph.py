@@ -397,6 +397,8 @@ def _union_hints(graphs: Sequence[HeteroBatch]) -> Dict[str, int]:
         vals = [g.hints.get(key) for g in graphs]
         if all(v is not None for v in vals):
             out[key] = max(vals)
+    if any(g.hints.get("static") for g in graphs):   # capacity-sized edge arrays: row counts are not edge counts (relation_order)
+        out["static"] = 1
     return out
 
 

@@ -142,6 +142,8 @@ class MultiAgentQLearner:
             self.lr_scheduler = th.optim.lr_scheduler.LambdaLR(self.optimizer,
                                                                lr_lambda=lambda epoch: max(0.4, 1 - epoch / 100))
         self._rollout_planes = {}     # ops.frozen_weights store of `act`
+        self._policy_params_for_fingerprint = tuple(self.policy_net.parameters())
+        self._rollout_fingerprint = None
         self._gen = th.Generator(device=self.device)
         self._gen.manual_seed(int(getattr(args, "seed", 0)) + 7919 * (dist.get_rank() if dist.is_initialized() else 0))
 
@@ -166,6 +168,15 @@ class MultiAgentQLearner:
         obs, h = obs.to(self.device), h.to(self.device)
         # between two optimiser steps the policy's parameters stand still: weight planes / the K1 parameter image are built by
         # the first rollout step and reused by the others (cleared by apply / load_checkpoint / invalidate_weight_cache)
+        # The store is keyed by device addresses (+ the version counter of the tensor a kernel is handed), but TarMAC's stacked
+        # projection weight is a `.data` view with its OWN counter: an in-place write to f_val / f_sign / f_que (load_state_dict,
+        # p.copy_()) bumps the parameters' counters and not the view's.  So the store is additionally guarded by the version
+        # counters of ALL policy parameters (30 attribute reads per act): any torch-visible in-place write empties it.
+        if self._rollout_planes is not None:
+            fp = tuple(p._version for p in self._policy_params_for_fingerprint)
+            if fp != self._rollout_fingerprint:
+                self._rollout_planes.clear()
+                self._rollout_fingerprint = fp
         with ops.frozen_weights(self._rollout_planes):
             logits, h = self.policy_net(obs, h)
         N = logits.shape[0]
@@ -330,10 +341,13 @@ class MultiAgentQLearner:
     def invalidate_weight_cache(self) -> None:
         """Drops what ``act`` derived from the policy's parameters (bf16 weight planes, the K1 parameter image).  The learner
         calls it wherever IT changes them (apply, load_checkpoint; graphs.GraphedUpdate after a replay); code that writes
-        ``policy_net`` parameters behind the learner's back (``p.data`` writes, raw-pointer kernels) must call it too -
-        ``load_state_dict`` / in-place torch ops are caught by the version counters in the cache keys."""
+        ``policy_net`` parameters behind the learner's back (``p.data`` writes - they bump no version counter -, raw-pointer
+        kernels) must call it too.  ``load_state_dict`` / in-place torch ops ON THE PARAMETERS are caught by ``act`` itself: it
+        compares the version counters of every policy parameter with those the store was filled under (the cache keys alone
+        would not do - TarMAC's stacked projection weight is a ``.data`` view whose own counter never moves)."""
         if self._rollout_planes is not None:     # None: no store across calls (every `act` builds its own)
             self._rollout_planes.clear()
+        self._rollout_fingerprint = None
 
     def apply(self) -> None:
         """clip_grad_value_(policy_net.parameters(), 1) (the mixer is NOT clipped, learner.py:159) + AdamW step + polyak

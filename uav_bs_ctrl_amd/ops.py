@@ -376,14 +376,20 @@ def _cached_planes(key, nbytes, device, build, keep=()):
     step would otherwise let the next policy step's temporary of the same shape land on the same address and pick up the
     TARGET network's planes.)"""
     if _PLANES is not None:
-        hit = _PLANES.get(key)
+        hit = _PLANES.pop(key, None)
         if hit is not None:
+            _PLANES[key] = hit              # most recently used last (dicts keep insertion order)
             return hit[0]
     planes = th.empty(nbytes, dtype=th.uint8, device=device)
     build(planes)
     if _PLANES is not None:
-        if len(_PLANES) >= _PLANES_MAX:     # a long-lived store fed with temporaries (weights built by th.cat per call) must not grow without bound
-            _PLANES.clear()
+        # a long-lived store fed with temporaries (weights built by th.cat per call) must not grow without bound: the least
+        # recently used entries go, one by one - never the whole store in the middle of a scope, and never the K1 parameter image
+        while len(_PLANES) >= _PLANES_MAX:
+            victim = next((k for k in _PLANES if k[0] != "k1img"), None)
+            if victim is None:
+                break
+            del _PLANES[victim]
         _PLANES[key] = (planes, tuple(keep))
     return planes
 
@@ -919,6 +925,11 @@ class _TarmacStep(th.autograd.Function):
             if seq is not None and (seq.t_fwd >= seq.T1 or N != seq.N or seq.x_all.shape[1] != H or
                                     x.data_ptr() != seq.x_all.data_ptr() + 4 * H * N * seq.t_fwd):
                 seq = None           # not a step of the sequence that was announced (or more steps than announced)
+            if seq is not None and seq.t_fwd > 0 and h.data_ptr() != seq.slot("h", seq.t_fwd, H, extra=1).data_ptr():
+                # end_sequence() reduces W_hh / Wp_h / W_out from the h SLOTS: a caller that masks or copies h between two steps
+                # hands over another tensor than the slot the previous step wrote - this step (and, through the x check above,
+                # every later one) reduces per step instead
+                seq = None
             if seq is not None:
                 seq_t = seq.t_fwd
                 seq.t_fwd += 1
@@ -944,6 +955,12 @@ class _TarmacStep(th.autograd.Function):
                 with KERNEL_TIMER.span("gru_gates_fwd"):
                     rc = L.lib().uavgnn_gru_gates_fwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), N, H, h2.data_ptr(), L.stream())
                 L.check(rc, "uavgnn_gru_gates_fwd")
+            if seq is not None and not fused:
+                # an accepted step that ran unfused wrote h' elsewhere: the NEXT staged step reads slot t + 1 as its h, so the
+                # slot is filled here and handed on (this step itself reduces per step: ctx.seq stays None)
+                slot = seq.slot("h", seq_t + 1, H, extra=1)
+                slot.copy_(h2)
+                h2 = slot
         q = th.addmm(b_out, h2, W_out.t())
         ctx.dims = (M, K)
         ctx.split, ctx.env, ctx.dx_out, ctx.fused_gru = split, env, dx_out, fused
