@@ -248,6 +248,32 @@ int uavgnn_talk_attn_env_bwd(const float* s, int ld_s, const float* q, int ld_q,
                              int n_max, float scale, const float* a_save, const float* d_c, int ld_dc, float* d_s,
                              int ld_ds, float* d_q, int ld_dq, float* d_v, int ld_dv, uavgnn_stream_t stream);
 
+/* ---- K3a + K3b in one launch (csrc/tarmac_msg.hip) ----------------------------------------------------------------
+ * The TarMAC message of a batch of small graphs with a UNIFORM number of agents (gnn_agents.py:254-267):
+ *   proj = [x || h] Wp^T + bp   (Wp = [f_val; f_sign; f_que].weight stacked: M value, K signature, K query columns),
+ *   c_v = sum_{u -> v} softmax_u(<sign_u, query_v> * scale) value_u over `talk`.
+ * Replaces the two projection GEMMs (ATen addmm behind gnn_agents.py:258-260) + uavgnn_talk_attn_env_fwd; the projections never
+ * reach HBM on no-grad calls.  fp32 in / out; the projection GEMM runs on the bf16 matrix cores as six exact bf16 products per
+ * fp32 product (csrc/bf16x3.h).
+ *   uavgnn_tarmac_msg_supported  H % 32 == 0, M + 2K <= 128, K <= 64, n_ag in {1, 2, 4, 8, 16};
+ *   uavgnn_tarmac_msg_prepare    the stacked weight [M + 2K, 2H] (row stride ld) -> bf16 plane tiles
+ *                                (uavgnn_tarmac_msg_weight_bytes(H, M, K) bytes, 16-byte aligned); once per weight version;
+ *   uavgnn_tarmac_msg_fwd        c_out [N, M] (row stride ld_c) always; training outputs, each optional (NULL): a_save [E]
+ *                                attention weight per CSC position, proj_out [N, M + 2K], x_copy [N, H] (the x half of the GRU
+ *                                input [x || c]); planes_out (NULL or uavgnn_tarmac_msg_planes_bytes(N, H, M) bytes): the GEMM
+ *                                operand [x || c || h] of uavgnn_gru_cell_fwd_planes as bf16 planes in that kernel's tile order.
+ * Preconditions: every graph has exactly n_ag agents (rows i n_ag .. (i + 1) n_ag - 1; N % n_ag == 0; 16 % n_ag == 0: no graph
+ * straddles two 16-row tiles, the unit a wavefront works on); the rows of a tile have at most 256 in-edges, all from rows of the
+ * same tile - a violating tile gets NaN messages, never a silent fallback. */
+int uavgnn_tarmac_msg_supported(int H, int M, int K, int n_ag);
+long long uavgnn_tarmac_msg_weight_bytes(int H, int M, int K);
+long long uavgnn_tarmac_msg_planes_bytes(int N, int H, int M);
+int uavgnn_tarmac_msg_prepare(const float* Wp, int ld, int H, int M, int K, void* tiles, uavgnn_stream_t stream);
+int uavgnn_tarmac_msg_fwd(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles,
+                          const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src, float scale,
+                          float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p, float* x_copy, int ld_xc,
+                          void* planes_out, uavgnn_stream_t stream);
+
 /* ---- derived indexes of a batch --------------------------------------------------------------------------------
  * What the reference gets from DGL's lazy format materialisation (CSR/CSC created inside the first message-passing
  * call on every new graph - reached from gnn_agents.py:103-104, :264-267) is explicit here and deterministic.
@@ -349,6 +375,21 @@ int uavgnn_gru_cell_fwd_x3_cat(const float* inp, int ld_inp, int K1, const float
 int uavgnn_gru_cell_fwd_x3_opts(const float* inp, int ld_inp, int K1, const float* inp2, int ld_inp2, int K2, const float* h,
                                 int N, int H, const void* planes, const float* b_ih, const float* b_hh, float* h_out,
                                 float* pre_save, int flags, uavgnn_stream_t stream);
+/* The same cell from PREPARED operand planes (csrc/gru_x3p.hip): bit-identical results to uavgnn_gru_cell_fwd_x3 with no operand
+ * split inside the kernel - staging a K slice is a linear LDS-DMA copy.  `planes`: the operand [inp || h] of the N rows as bf16
+ * plane tiles, written by uavgnn_tarmac_msg_fwd (planes_out; K_in = H + M there); `h`: the same hidden state in fp32 (read by the
+ * convex update); `tiles`: [W_ih | W_hh] as bf16 plane tiles per (64-unit column block, K slice), built once per weight version by
+ * uavgnn_gru_split_weight_tiles (uavgnn_gru_weight_tiles_bytes(K_in, H) bytes, 16-byte aligned).  K_in % 32 == 0, H % 64 == 0. */
+long long uavgnn_gru_weight_tiles_bytes(int K_in, int H);
+int uavgnn_gru_split_weight_tiles(const float* W_ih, int K_in, const float* W_hh, int H, void* tiles, uavgnn_stream_t stream);
+int uavgnn_gru_cell_fwd_planes(const void* planes, int K_in, const float* h, int N, int H, const void* tiles, const float* b_ih,
+                               const float* b_hh, float* h_out, float* pre_save, uavgnn_stream_t stream);
+/* ... with a per-call variant word `opt` in 0 .. 7 (0 = uavgnn_gru_cell_fwd_planes; the schedules tools/cell_probe.py compares -
+ * bit 0: second-half fragment reads behind the first MFMAs, bit 1: activation DMA two slices ahead (three LDS buffers), bit 2: the
+ * epilogue's h tile requested inside the last slice; results are bit-identical for every value). */
+int uavgnn_gru_cell_fwd_planes_opts(const void* planes, int K_in, const float* h, int N, int H, const void* tiles,
+                                    const float* b_ih, const float* b_hh, float* h_out, float* pre_save, int opt,
+                                    uavgnn_stream_t stream);
 /* Dense layers on the bf16 matrix cores (csrc/gemm_x3.hip; reference: the nn.Linear layers of
  * algos/madrqn/agents/gnn_agents.py - f_aggr :101-102, :106, TarMAC projections :227-236 - and the input-gradient GEMMs of
  * loss.backward(), learner.py:157): Y[M, N] = X[M, K] B[N, K]^T (+ bias[N]) (+ Y) (then ReLU), fp32 in / out, each fp32 product

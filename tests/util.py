@@ -42,7 +42,7 @@ def assert_close(actual, ref, rel=1e-5, what="", floor=0.0):
     atol = max(rel * (float(ref.abs().max()) if ref.numel() else 0.0), floor, 1e-30)
     err = (actual - ref).abs()
     bound = atol + rel * ref.abs()
-    bad = err > bound
+    bad = (err > bound) | (th.isnan(err) & ~th.isnan(ref))      # a NaN where the reference is a number is a failure, not "not greater"
     if bool(bad.any()):
         i = int(th.argmax(err - bound))
         raise AssertionError(f"{what}: {int(bad.sum())}/{ref.numel()} out of tolerance (rel={rel}); worst err "

@@ -76,6 +76,13 @@ SIGNATURES = {
                                       ctypes.c_size_t, _c_st]),
     "uavgnn_csc_transpose_env": (_c_int, [_c_ip, _c_ip, _c_ip, _c_int, _c_int, _c_ip, _c_ip, _c_ip, _c_st]),
     "uavgnn_talk_attn_env_supported": (_c_int, [_c_int, _c_int, _c_int]),
+    "uavgnn_tarmac_msg_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
+    "uavgnn_tarmac_msg_weight_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
+    "uavgnn_tarmac_msg_planes_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
+    "uavgnn_tarmac_msg_prepare": (_c_int, [_c_fp, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_st]),
+    "uavgnn_tarmac_msg_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_int, _c_int,
+                                       _c_ip, _c_ip, _c_f32, _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_fp, _c_int, ctypes.c_void_p,
+                                       _c_st]),
     "uavgnn_talk_attn_env_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_ip, _c_ip,
                                           _c_ip, _c_int, _c_int, _c_f32, _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_int,
                                           _c_st]),
@@ -99,6 +106,12 @@ SIGNATURES = {
                                             _c_fp, _c_fp, _c_st]),
     "uavgnn_gru_cell_fwd_x3_opts": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_fp,
                                              _c_fp, _c_fp, _c_int, _c_st]),
+    "uavgnn_gru_weight_tiles_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
+    "uavgnn_gru_split_weight_tiles": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, ctypes.c_void_p, _c_st]),
+    "uavgnn_gru_cell_fwd_planes": (_c_int, [ctypes.c_void_p, _c_int, _c_fp, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_fp, _c_fp, _c_fp,
+                                            _c_st]),
+    "uavgnn_gru_cell_fwd_planes_opts": (_c_int, [ctypes.c_void_p, _c_int, _c_fp, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_fp, _c_fp,
+                                                 _c_fp, _c_int, _c_st]),
     "uavgnn_gru_cell_bwd_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
     "uavgnn_gru_split_weights_bwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, ctypes.c_void_p, _c_st]),
     "uavgnn_gru_cell_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_fp, _c_fp, _c_int, _c_fp,

@@ -882,6 +882,37 @@ def time_split(x_all, T1):
     return xs, list(holder[0].unbind(0))
 
 
+MSG_FUSED = os.environ.get("UAVGNN_MSG_FUSED", "1") != "0"   # K3a + K3b in one launch (csrc/tarmac_msg.hip); A/B switch
+
+
+def _tarmac_msg_plan(x, h, Wp, bp, M, K, env, N, H):
+    """(weight tiles, agents per graph) when the fused K3a + K3b launch covers this call, else None: graphs with a uniform number
+    of agents (every graph <= n_max and N == B n_max), aligned row-major operands, a contiguous stacked projection weight."""
+    if not MSG_FUSED or env is None or N == 0:
+        return None
+    _, B, n_ag = env
+    if N != B * n_ag or (H + M) % 4 or not L.lib().uavgnn_tarmac_msg_supported(H, M, K, n_ag):
+        return None
+    if (Wp.shape != (M + 2 * K, 2 * H) or not Wp.is_contiguous() or Wp.data_ptr() % 16 or not bp.is_contiguous()
+            or x.data_ptr() % 16 or h.data_ptr() % 16 or x.dtype != th.float32 or Wp.dtype != th.float32):
+        return None
+    lib = L.lib()
+    tiles = _cached_planes(("msgw", Wp.data_ptr(), Wp._version, H, M, K), lib.uavgnn_tarmac_msg_weight_bytes(H, M, K), x.device,
+                           lambda buf: L.check(lib.uavgnn_tarmac_msg_prepare(Wp.data_ptr(), Wp.stride(0), H, M, K, buf.data_ptr(),
+                                                                            L.stream()), "uavgnn_tarmac_msg_prepare"),
+                           keep=(Wp,))
+    return tiles, n_ag
+
+
+def _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, c_ptr, ld_c, a_save, proj, ld_p, x_copy, ld_xc, planes=None):
+    tiles, n_ag = msg
+    with KERNEL_TIMER.span("tarmac_msg_fwd", (N, H, M + 2 * K)):
+        rc = L.lib().uavgnn_tarmac_msg_fwd(x.data_ptr(), x.stride(0), h.data_ptr(), h.stride(0), N, H, n_ag, tiles.data_ptr(),
+                                           bp.data_ptr(), M, K, L.ptr(talk_off), L.ptr(talk_src), 1.0 / K, c_ptr, ld_c, a_save, proj,
+                                           ld_p, x_copy, ld_xc, L.ptr(planes), L.stream())
+    L.check(rc, "uavgnn_tarmac_msg_fwd")
+
+
 class _TarmacStep(th.autograd.Function):
     """q, h' = head(GRU([x || c], h)), c = targeted attention over `talk` of the projections of [x || stopgrad(h)]
     (gnn_agents.py:248-271 with n_rounds = 1, then :56).  Forward: 5 vendor GEMMs + K3b + K4, the projection of the two
@@ -894,7 +925,12 @@ class _TarmacStep(th.autograd.Function):
         L.require_gpu(x, h, Wp, W_ih, talk_off)
         N, H = x.shape
         x, h = L.f32c(x), L.f32c(h)
-        if gemm_x3_supported(x, Wp.shape[0], H) and gemm_x3_supported(h, Wp.shape[0], H) and bp.is_contiguous():
+        # K3a + K3b as ONE launch (csrc/tarmac_msg.hip) when the batch is made of graphs with a uniform number of agents: the
+        # projections stay on the chip on no-grad calls (two vendor GEMMs + K3b: 52 us per C3 step; traffic floor ~13 us)
+        msg = _tarmac_msg_plan(x, h, Wp, bp, M, K, env, N, H)
+        if msg is not None:
+            proj = None
+        elif gemm_x3_supported(x, Wp.shape[0], H) and gemm_x3_supported(h, Wp.shape[0], H) and bp.is_contiguous():
             proj = gemm_x3(x, Wp[:, :H], bias=bp)
             gemm_x3(h, Wp[:, H:], out=proj, accumulate=True)
         else:
@@ -913,8 +949,11 @@ class _TarmacStep(th.autograd.Function):
         if c_only is not None:
             # no-grad call (rollout, target network): nothing keeps [x || c] for a backward, so K3b writes c alone and the cell
             # reads its input from the two buffers - the 2 x 4 H bytes per agent of the concatenating copy disappear
-            _launch_talk_fwd(env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld, K, M,
-                             talk_off, talk_src, N, 1.0 / K, c_only.data_ptr(), M, a_save.data_ptr(), None, 0, 0)
+            if msg is not None:
+                _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, c_only.data_ptr(), M, None, None, 0, None, 0)
+            else:
+                _launch_talk_fwd(env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld, K, M,
+                                 talk_off, talk_src, N, 1.0 / K, c_only.data_ptr(), M, a_save.data_ptr(), None, 0, 0)
             h2, _ = _gru_cell_launch(x, h, W_ih, b_ih, W_hh, b_hh, save=False, inp2=c_only)
             inp, fused = c_only, True
             gi = gh = h2                                           # placeholders keep save_for_backward's arity
@@ -938,9 +977,14 @@ class _TarmacStep(th.autograd.Function):
                     seq.slot("h", 0, H, extra=1).copy_(h)
             else:
                 inp = th.empty((N, H + M), dtype=th.float32, device=x.device)     # [x || c], both halves filled by K3b
-            _launch_talk_fwd(env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld, K, M,
-                             talk_off, talk_src, N, 1.0 / K, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(), x.data_ptr(),
-                             x.stride(0), H)
+            if msg is not None:     # proj, the attention weights and the x half of [x || c] are the launch's training outputs
+                proj = th.empty((N, ld), dtype=th.float32, device=x.device)
+                _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(),
+                                   proj.data_ptr(), ld, inp.data_ptr(), H + M)
+            else:
+                _launch_talk_fwd(env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld, K, M,
+                                 talk_off, talk_src, N, 1.0 / K, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(), x.data_ptr(),
+                                 x.stride(0), H)
             fused = gru_cell_supported(inp, h) and aligned
             if fused:      # K4 in one launch: gi / gh never reach HBM; training forwards keep the [N, 4H] pre-activation sets
                 h2, pre = _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save=bool(train),
@@ -955,13 +999,11 @@ class _TarmacStep(th.autograd.Function):
                 with KERNEL_TIMER.span("gru_gates_fwd"):
                     rc = L.lib().uavgnn_gru_gates_fwd(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), N, H, h2.data_ptr(), L.stream())
                 L.check(rc, "uavgnn_gru_gates_fwd")
-            if seq is not None and not fused:
-                # an accepted step that ran unfused wrote h' elsewhere: the NEXT staged step reads slot t + 1 as its h, so the
-                # slot is filled here and handed on (this step itself reduces per step: ctx.seq stays None)
-                slot = seq.slot("h", seq_t + 1, H, extra=1)
-                slot.copy_(h2)
-                h2 = slot
+            # (an accepted step that ran unfused wrote h' into a tensor of its own, not into slot t + 1: the next step's h then
+            # fails the slot check above and reduces per step, like this one - ctx.seq stays None)
         q = th.addmm(b_out, h2, W_out.t())
+        if proj is None:
+            proj = h2                                              # no-grad call through the fused message launch: placeholder
         ctx.dims = (M, K)
         ctx.split, ctx.env, ctx.dx_out, ctx.fused_gru = split, env, dx_out, fused
         ctx.have_pre = bool(train) or not fused
