@@ -538,8 +538,10 @@ def k1_env_standalone(learner, g, a, reps=50, rounds=5):
         ops.hetero_gatv2(x_a, enc._n_heads, rels)           # builds the image + any derived index outside the capture
         th.cuda.synchronize()
         with th.cuda.graph(graph):
+            out = None
             for _ in range(reps):
-                out = ops.hetero_gatv2(x_a, enc._n_heads, rels)
+                del out     # the previous launch's [N, 2H] rows go back to the pool first: every launch writes the SAME 67 MB, as the
+                out = ops.hetero_gatv2(x_a, enc._n_heads, rels)   # rollout does (the allocator hands act() the block f_aggr just freed)
     took_image = any(k[0] == "k1img" for k in store)
     ms = []
     for i in range(rounds + 2):

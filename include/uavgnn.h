@@ -273,6 +273,11 @@ int uavgnn_tarmac_msg_fwd(const float* x, int ld_x, const float* h, int ld_h, in
                           const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src, float scale,
                           float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p, float* x_copy, int ld_xc,
                           void* planes_out, uavgnn_stream_t stream);
+/* timing ablations of tools/msg_probe.py (`dbg` != 0 skips parts of the GEMM loop: the outputs are then WRONG) */
+int uavgnn_tarmac_msg_fwd_dbg(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles,
+                              const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src, float scale,
+                              float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p, float* x_copy, int ld_xc,
+                              void* planes_out, int dbg, uavgnn_stream_t stream);
 
 /* ---- derived indexes of a batch --------------------------------------------------------------------------------
  * What the reference gets from DGL's lazy format materialisation (CSR/CSC created inside the first message-passing

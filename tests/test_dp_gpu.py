@@ -177,7 +177,10 @@ def test_bench_at_world_size_two_on_one_device():
     assert len(lines) == 1, plain.stdout[-2000:]
     rp = json.loads(lines[0])
     assert rp["n_gpus"] == 2 and rp["self_launched"] is True and rp["replicas_identical"] is True
-    assert rp["params_checksum"] == r2["params_checksum"] and rp["loss"] == r2["loss"]
+    # (two processes share the one GPU of the box in both runs: the same job to fp32 rounding - the vendor GEMMs' split-K order
+    # is not pinned under that contention; the one-process determinism tests are test_gpu_parity.py's)
+    assert all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(rp["params_checksum"], r2["params_checksum"]))
+    assert abs(rp["loss"] - r2["loss"]) <= 1e-5 * abs(r2["loss"])
     one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", *small, "--no-cpu-baseline", "--no-end-to-end",
                           "--no-fp32-leg", "--no-rho-leg"], cwd=root, env=dict(os.environ), capture_output=True, text=True,
                          timeout=800)

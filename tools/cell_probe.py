@@ -4,7 +4,8 @@ import sys
 
 import torch as th
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uav_bs_ctrl_amd import _lib as L  # noqa: E402
 
 N, H, M = 32768, 256, 64

@@ -35,6 +35,15 @@ cases = [("f_aggr forward (rollout)      x[N,512] W[256,512]^T", N, 256, 512, Fa
          ("GRU dh += d_gh W_hh          dy[N,768] W[768,256] ", N, 256, 768, True),
          ("f_aggr d_x (time-batched/51) dy[N,256] W[256,512] ", N, 512, 256, True),
          ("f_aggr forward, T+1 = 51 steps", 51 * N, 256, 512, False)]
+# the accumulating launch of the GRU backward (Y += X W): the epilogue reads Y
+_a = th.randn(N, 768, device=dev)
+_W = th.randn(768, 256, device=dev) * 0.06
+_y = th.randn(N, 256, device=dev)
+for flags, what in ((8, "4-wave"), (0, "8-wave")):
+    ops.GEMM_X3_FLAGS = flags
+    print(f"GRU dh += d_gh W_hh WITH the accumulate epilogue ({what}): {time_us(lambda: ops.gemm_x3(_a, _W, True, out=_y, accumulate=True)):7.1f} us"
+          f" | without: {time_us(lambda: ops.gemm_x3(_a, _W, True, out=_y)):7.1f} us")
+ops.GEMM_X3_FLAGS = 0
 for name, M, n_out, K, tr in cases:
     a = th.randn(M, K, device=dev)
     W = (th.randn(K, n_out, device=dev) if tr else th.randn(n_out, K, device=dev)) * 0.06

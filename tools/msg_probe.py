@@ -4,7 +4,8 @@ import sys
 
 import torch as th
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from uav_bs_ctrl_amd import _lib as L, ops  # noqa: E402
 
@@ -80,6 +81,12 @@ def msg_noedges():
 
 
 print(f"# fused launch on a batch WITHOUT talk edges (GEMM loop + outputs only): {timeit(msg_noedges):.1f} us")
+for dbg, what in ((1, "no weight-slice traffic"), (2, "no MFMAs"), (4, "no activation loads"), (8, "no barriers"), (3, "no weights, no MFMAs"),
+                  (7, "no weights / MFMAs / activation loads"), (15, "nothing but the split and the tail")):
+    def f(dbg=dbg):
+        assert lib.uavgnn_tarmac_msg_fwd_dbg(x.data_ptr(), H, h.data_ptr(), H, N, H, n, tiles.data_ptr(), bp.data_ptr(), M, K, off_none.data_ptr(),
+                                             src.data_ptr(), 1.0 / K, c.data_ptr(), M, None, None, 0, None, 0, None, dbg, L.stream()) == 0
+    print(f"#   ablation (no edges) dbg={dbg:2d} {what:42s}: {timeit(f):6.1f} us")
 print(f"# N = {N} rows ({B} graphs of {n}), H {H}, M {M}, K {K}; us per call, 30 back-to-back calls between one event pair")
 for train in (False, True):
     t_old = timeit(old(train))

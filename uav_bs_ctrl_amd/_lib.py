@@ -80,6 +80,9 @@ SIGNATURES = {
     "uavgnn_tarmac_msg_weight_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
     "uavgnn_tarmac_msg_planes_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
     "uavgnn_tarmac_msg_prepare": (_c_int, [_c_fp, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_st]),
+    "uavgnn_tarmac_msg_fwd_dbg": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_int, _c_int,
+                                           _c_ip, _c_ip, _c_f32, _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_fp, _c_int, ctypes.c_void_p,
+                                           _c_int, _c_st]),
     "uavgnn_tarmac_msg_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_int, _c_int,
                                        _c_ip, _c_ip, _c_f32, _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_fp, _c_int, ctypes.c_void_p,
                                        _c_st]),

@@ -26,7 +26,15 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 # The host pass of hipcc prints "'-packed-fp32-ops' is not a recognized feature for this target (ignoring feature)" - harmless;
 # `-Xarch_device -mno-packed-fp32-ops` is accepted silently and does NOT disable the instructions (checked in the disassembly),
 # tools/isa_audit.py / tests/test_isa_audit.py is what proves the flag took effect.
-EXTRA_CFLAGS = {"gatv2_bwd_mfma.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
+_NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+EXTRA_CFLAGS = {"gatv2_bwd_mfma.hip": _NO_PK}
+# Round 5: the fp32 backward kernels (csrc/gatv2.hip) and K5 (csrc/disc_comm.hip) held 8-40 operand-selected packed fp32
+# instructions each - safe only while no matrix-core kernel shares a SIMD with them (ANOTHER wavefront's 128-bit-operand MFMA
+# triggers the hazard too), i.e. under a one-stream calling convention.  Compiled without packed fp32 the pattern cannot occur at
+# all, whatever the host application runs on its other streams (UAVGNN_PK_BWD=1 restores the packed build for the A/B of
+# profiles/r05_pk_bwd_ab.txt).
+if os.environ.get("UAVGNN_PK_BWD", "0") != "1":
+    EXTRA_CFLAGS.update({"gatv2.hip": _NO_PK, "disc_comm.hip": _NO_PK})
 
 
 def sources():

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kMsgThreads, CT == 8 ? 2 : 3) void tarmac_msg_fwd_k
     const float* __restrict__ x, int ld_x, const float* __restrict__ h, int ld_h, int N, int H, int n_ag,
     const u32x4* __restrict__ Wt, const float* __restrict__ bias, int M, int K, const int32_t* __restrict__ talk_off,
     const int32_t* __restrict__ talk_src, float scale, float* __restrict__ c_out, int ld_c, float* __restrict__ a_save,
-    float* __restrict__ proj_out, int ld_p, float* __restrict__ x_copy, int ld_xc, u32x4* __restrict__ planes_out) {
+    float* __restrict__ proj_out, int ld_p, float* __restrict__ x_copy, int ld_xc, u32x4* __restrict__ planes_out, int dbg) {
   constexpr int RP = 16 * CT;                       // padded projection columns
   constexpr int BCH = 3 * RP * 4;                   // 16-byte chunks of one weight slice (3 planes)
   constexpr int BPT = (BCH + kMsgThreads - 1) / kMsgThreads;
@@ -188,19 +188,23 @@ __global__ __launch_bounds__(kMsgThreads, CT == 8 ? 2 : 3) void tarmac_msg_fwd_k
     LO = *reinterpret_cast<const float4*>(p_);                \
     HI = *reinterpret_cast<const float4*>(p_ + 16);           \
   }
+  // Prologue, ordered so that nothing waits behind the activation stream (loads return in issue order: a wait for one of them
+  // waits for every older one): the talk offsets and the first weight slice go out FIRST, then four slices of activations; the
+  // dependent loads of the talk relation (sources of up to 256 in-edges: the second of two round trips that would otherwise
+  // start after the GEMM loop) follow as soon as the offsets are back.
+  const int toff = talk_off[min(row0 + min(lane, 16), N)];
+  load_b(0);
+  __builtin_amdgcn_sched_barrier(0);
   UAVGNN_MSG_LOAD_A(a0_lo, a0_hi, 0)
   UAVGNN_MSG_LOAD_A(a1_lo, a1_hi, 1)
   UAVGNN_MSG_LOAD_A(a2_lo, a2_hi, 2)
   UAVGNN_MSG_LOAD_A(a3_lo, a3_hi, 3)
-  load_b(0);
-  store_b(0);
-  load_b(1);
-  // the talk relation of the wavefront's 16 rows, requested now (two dependent round trips that would otherwise start after the
-  // GEMM loop): offsets lane <-> row, then the sources of up to 256 in-edges
-  const int toff = talk_off[min(row0 + min(lane, 16), N)];
+  __builtin_amdgcn_sched_barrier(0);
   const int e_lo = __shfl(toff, 0);
   const int E = __shfl(toff, 16) - e_lo;
   const bool ok = E <= EMAX && E >= 0;
+  store_b(0);
+  load_b(1);
   int fsrc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) fsrc[i] = (ok && lane + kWave * i < E) ? talk_src[e_lo + lane + kWave * i] : 0;
@@ -225,16 +229,20 @@ __global__ __launch_bounds__(kMsgThreads, CT == 8 ? 2 : 3) void tarmac_msg_fwd_k
       *reinterpret_cast<float4*>(d + 16) = HI;                                                       \
     }                                                                                                \
     store_planes(t_ < nsx ? t_ : t_ - nsx + nsl_cell - nsx, pa);                                     \
-    UAVGNN_MSG_LOAD_A(LO, HI, t_ + 4)                                                                \
+    if (!(dbg & 4)) UAVGNN_MSG_LOAD_A(LO, HI, t_ + 4)                                                \
     const bf16x8 fa0 = as_frag(pa.p[0]), fa1 = as_frag(pa.p[1]), fa2 = as_frag(pa.p[2]);            \
     const u32x4* sb = sB[t_ & 1];                                                                    \
-    _Pragma("unroll") for (int cp = 0; cp < CT; cp += 2) {                                           \
-      UAVGNN_MSG_TERM(fa0, 2) UAVGNN_MSG_TERM(fa2, 0) UAVGNN_MSG_TERM(fa1, 1) UAVGNN_MSG_TERM(fa0, 1) \
-      UAVGNN_MSG_TERM(fa1, 0) UAVGNN_MSG_TERM(fa0, 0)                                                \
+    if (!(dbg & 2)) {                                                                                \
+      _Pragma("unroll") for (int cp = 0; cp < CT; cp += 2) {                                         \
+        UAVGNN_MSG_TERM(fa0, 2) UAVGNN_MSG_TERM(fa2, 0) UAVGNN_MSG_TERM(fa1, 1) UAVGNN_MSG_TERM(fa0, 1) \
+        UAVGNN_MSG_TERM(fa1, 0) UAVGNN_MSG_TERM(fa0, 0)                                              \
+      }                                                                                              \
     }                                                                                                \
-    store_b((t_ + 1) & 1);   /* its readers passed the barrier of iteration t - 1 */                 \
-    load_b(t_ + 2);                                                                                  \
-    lds_barrier();                                                                                   \
+    if (!(dbg & 1)) {                                                                                \
+      store_b((t_ + 1) & 1);   /* its readers passed the barrier of iteration t - 1 */               \
+      load_b(t_ + 2);                                                                                \
+    }                                                                                                \
+    if (!(dbg & 8)) lds_barrier();                                                                   \
   }
   for (int t = 0; t < ns; t += 4) {
     UAVGNN_MSG_STEP(a0_lo, a0_hi, t)
@@ -407,10 +415,12 @@ extern "C" int uavgnn_tarmac_msg_prepare(const float* Wp, int ld, int H, int M, 
 // planes_out: NULL or uavgnn_tarmac_msg_planes_bytes(N, H, M) bytes.  Every graph has exactly n_ag agents (N % n_ag == 0; 16 %
 // n_ag == 0, so no graph straddles two 16-row tiles); the rows of a tile have at most 256 in-edges, all from rows of the same tile -
 // a violating tile gets NaN messages, never a silent fallback.
-extern "C" int uavgnn_tarmac_msg_fwd(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles,
-                                     const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src,
-                                     float scale, float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p,
-                                     float* x_copy, int ld_xc, void* planes_out, uavgnn_stream_t stream) {
+// dbg (timing ablations of tools/msg_probe.py; results are WRONG for dbg != 0): bit 0 no weight-slice traffic after the first two
+// slices, bit 1 no MFMAs, bit 2 no activation loads after the first four slices, bit 3 no workgroup barriers
+extern "C" int uavgnn_tarmac_msg_fwd_dbg(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles,
+                                         const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src,
+                                         float scale, float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p,
+                                         float* x_copy, int ld_xc, void* planes_out, int dbg, uavgnn_stream_t stream) {
   if (N < 0 || !x || !h || !tiles || !bias || !talk_off || !c_out || ld_x < H || ld_h < H || ld_c < M) return UAVGNN_EINVAL;
   if (proj_out && ld_p < M + 2 * K) return UAVGNN_EINVAL;
   if (x_copy && ld_xc < H) return UAVGNN_EINVAL;
@@ -428,7 +438,7 @@ extern "C" int uavgnn_tarmac_msg_fwd(const float* x, int ld_x, const float* h, i
   u32x4* po = static_cast<u32x4*>(planes_out);
 #define UAVGNN_MSG_LAUNCH(NA_, CT_, TR_, PL_)                                                                              \
   hipLaunchKernelGGL((tarmac_msg_fwd_kernel<CT_, TR_, PL_>), grid, block, 0, st, x, ld_x, h, ld_h, N, H, n_ag, Wt, bias, M, \
-                     K, talk_off, talk_src, scale, c_out, ld_c, a_save, proj_out, ld_p, x_copy, ld_xc, po)
+                     K, talk_off, talk_src, scale, c_out, ld_c, a_save, proj_out, ld_p, x_copy, ld_xc, po, dbg)
 #define UAVGNN_MSG_BY_FLAGS(NA_, CT_)                                    \
   {                                                                      \
     if (train && planes) UAVGNN_MSG_LAUNCH(NA_, CT_, true, true);        \
@@ -447,4 +457,12 @@ extern "C" int uavgnn_tarmac_msg_fwd(const float* x, int ld_x, const float* h, i
 #undef UAVGNN_MSG_BY_FLAGS
 #undef UAVGNN_MSG_LAUNCH
   return launch_status();
+}
+
+extern "C" int uavgnn_tarmac_msg_fwd(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles,
+                                     const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src,
+                                     float scale, float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p,
+                                     float* x_copy, int ld_xc, void* planes_out, uavgnn_stream_t stream) {
+  return uavgnn_tarmac_msg_fwd_dbg(x, ld_x, h, ld_h, N, H, n_ag, tiles, bias, M, K, talk_off, talk_src, scale, c_out, ld_c, a_save,
+                                   proj_out, ld_p, x_copy, ld_xc, planes_out, 0, stream);
 }
