@@ -842,6 +842,19 @@ def main():
                         "fp32_equivalent_tflops": tf, "achieved": 6.0 * tf, "peak": BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s (bf16 MFMA: six products per fp32 product)", "frac": 6.0 * tf / BF16_PEAK_TFLOPS,
                         "share_of_step": kg["total_ms"] / (1e3 * instr_s)})
+        km = kfull.get("tarmac_msg_fwd")
+        if km and km["work"]:
+            # K3a + K3b in one launch (csrc/tarmac_msg.hip): x and h read once, c written (+ proj and the x half of [x || c] on
+            # training forwards); algorithmic bytes / launch time against the HBM peak
+            by = sum(Nn * (2 * Hh * 4 + Mm * 4) + tr * Nn * (Mm + 2 * Kk) * 4 + xc * Nn * Hh * 4 for (Nn, Hh, Mm, Kk, tr, xc) in km["work"])
+            g = by / (km["total_ms"] * 1e-3) / 1e9
+            sec.append({"kernel": "tarmac_msg_fwd_kernel (K3a + K3b: projection GEMM on the bf16 matrix cores + per-tile attention, one launch)",
+                        "bound": "hbm", "launches": km["count"], "avg_launch_ms": km["avg_ms"], "achieved": g, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": g / HBM_PEAK_GBS, "alg_bytes_per_launch": by / km["count"],
+                        "share_of_step": km["total_ms"] / (1e3 * instr_s),
+                        "note": "replaces two vendor GEMMs + talk_attn_env_fwd (52-56 us per C3 step); its phases - prologue, activation "
+                                "stream, MFMAs, weight-slice traffic, attention tail - run one after the other in every workgroup "
+                                "(tools/msg_probe.py ablations), so it sits at ~0.25 of the HBM peak, not at the ~13 us its traffic allows"})
         if sec:
             res["roofline_secondary"] = sec
         res["kernel_ms_per_launch"] = {n: round(v["avg_ms"], 4) for n, v in kfull.items()}

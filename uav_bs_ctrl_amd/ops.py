@@ -906,7 +906,7 @@ def _tarmac_msg_plan(x, h, Wp, bp, M, K, env, N, H):
 
 def _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, c_ptr, ld_c, a_save, proj, ld_p, x_copy, ld_xc, planes=None):
     tiles, n_ag = msg
-    with KERNEL_TIMER.span("tarmac_msg_fwd", (N, H, M + 2 * K)):
+    with KERNEL_TIMER.span("tarmac_msg_fwd", (N, H, M, K, int(proj is not None), int(x_copy is not None))):
         rc = L.lib().uavgnn_tarmac_msg_fwd(x.data_ptr(), x.stride(0), h.data_ptr(), h.stride(0), N, H, n_ag, tiles.data_ptr(),
                                            bp.data_ptr(), M, K, L.ptr(talk_off), L.ptr(talk_src), 1.0 / K, c_ptr, ld_c, a_save, proj,
                                            ld_p, x_copy, ld_xc, L.ptr(planes), L.stream())
