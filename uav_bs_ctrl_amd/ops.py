@@ -544,6 +544,9 @@ GEMM_X3_FLAGS = {"8": 0, "9": 4, "4": 8}.get(os.environ.get("UAVGNN_GEMM_X3_VARI
 GRU_X3_FLAGS = 1 if os.environ.get("UAVGNN_GRU_X3_VARIANT", "1") == "0" else 0
 
 
+GEMM_X3_SMALL_GRID = 128   # fewer 256 x 128 tiles than this: 128 x 128 tiles instead
+
+
 def gemm_x3_supported(a, n_out, k) -> bool:
     return bool(GEMM_X3 and a.is_cuda and a.dtype == th.float32 and a.dim() == 2 and a.stride(1) == 1
                 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and n_out % 128 == 0 and a.shape[0] >= 4096
@@ -566,8 +569,13 @@ def gemm_x3(a, W, transpose_w=False, bias=None, out=None, accumulate=False, relu
                                 lambda p: L.check(lib.uavgnn_split_bf16x3(W.data_ptr(), W.stride(0), R, C, int(transpose_w),
                                                                           p.data_ptr(), L.stream()), "uavgnn_split_bf16x3"),
                                 keep=(W,))
+        flags = GEMM_X3_FLAGS
+        if not (flags & 8) and ((M + 255) // 256) * ((n_out + 127) // 128) < GEMM_X3_SMALL_GRID:
+            # C2-size batches (N_a = 4096): the 256 x 128 tiles of the eight-wave kernel are 32 workgroups on 256 CUs (58 us for
+            # [4096, 768] x [768, 256]); the four-wave kernel's 128 x 128 tiles double the workgroups (UAVGNN_GEMM_TILE_128)
+            flags |= 8
         rc = lib.uavgnn_gemm_nt_x3(a.data_ptr(), a.stride(0), M, K, planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(),
-                                   out.stride(0), (1 if accumulate else 0) | (2 if relu else 0) | GEMM_X3_FLAGS, L.stream())
+                                   out.stride(0), (1 if accumulate else 0) | (2 if relu else 0) | flags, L.stream())
     L.check(rc, "uavgnn_gemm_nt_x3")
     return out
 
