@@ -73,3 +73,23 @@ def test_metric_string_follows_the_configuration():
     assert bench.metric_name(types.SimpleNamespace(n=8, M=80)) == "env-steps/sec (MADRQN, 8 UBS x 80 GT)"
     assert bench.metric_name(types.SimpleNamespace(n=4, M=40)) == "env-steps/sec (MADRQN, 4 UBS x 40 GT)"
     assert bench.metric_name(types.SimpleNamespace(n=16, M=200)) == "env-steps/sec (MADRQN, 16 UBS x 200 GT)"
+
+
+def test_rccl_transport_summary_reads_an_nccl_debug_log(tmp_path):
+    """`rccl_transport` of the bench line: transports counted from the `Channel ... via <transport>` lines of an NCCL_DEBUG=INFO log."""
+    sys.path.insert(0, ROOT)
+    import bench
+    log = tmp_path / "rccl.log"
+    log.write_text("\n".join([
+        "box:101:201 [0] NCCL INFO NET/Plugin: Failed to find ncclNetPlugin_v8 symbol.",
+        "box:101:201 [0] NCCL INFO comm 0x55 rank 0 nRanks 8 nNodes 1 localRanks 8 localRank 0 MNNVL 0",
+        "box:101:201 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC comm 0x55 nRanks 08",
+        "box:101:201 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC comm 0x55 nRanks 08",
+        "box:101:201 [0] NCCL INFO Channel 00 : 0[c000] -> 7[e000] via P2P/direct pointer",
+        "box:101:201 [0] NCCL INFO Connected all rings",
+        "box:101:201 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1 [1] 1/-1/-1->0->-1",
+    ]))
+    s = bench.rccl_transport_summary(str(log))
+    assert s["channel_transports"] == {"P2P/IPC": 2, "P2P/direct pointer": 1}
+    assert s["log_lines"] == 7 and any("Connected all rings" in ln for ln in s["lines"])
+    assert bench.rccl_transport_summary(str(tmp_path / "missing.log")) is None
