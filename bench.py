@@ -612,6 +612,17 @@ def rccl_transport_summary(path):
     return {"channel_transports": via, "lines": topo, "log_lines": len(lines), "source": "NCCL_DEBUG=INFO log of rank 0"}
 
 
+def peer_access_summary(world):
+    """Which of the node's first `world` devices can address each other's memory directly (hipDeviceCanAccessPeer through torch):
+    what RCCL's P2P / xGMI transports need.  Cheap, silent, and independent of any debug log."""
+    try:
+        n = min(world, th.cuda.device_count())
+        ok = [[bool(i == j or th.cuda.can_device_access_peer(i, j)) for j in range(n)] for i in range(n)]
+        return {"devices": n, "all_pairs": all(all(r) for r in ok), "pairs_without_peer_access": [[i, j] for i in range(n) for j in range(n) if not ok[i][j]]}
+    except Exception as e:   # noqa: BLE001 - a diagnostic never breaks the bench line
+        return {"error": repr(e)}
+
+
 def dry_launch_main(a, world, rank):
     """Test hook UAVGNN_BENCH_DRY=1 (tests/test_bench_launch.py, CPU container: no GPU): everything of the launch contract that
     does not need a device - rank discovery, process-group rendezvous (gloo), barrier-bracketed timing of K trivial steps,
@@ -695,10 +706,15 @@ def main():
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            if "NCCL_DEBUG" not in os.environ:   # the run explains its own transport: INFO log of the communicator set-up, per rank
-                import tempfile
-                rccl_log = os.path.join(tempfile.gettempdir(), f"uavgnn_rccl_rank{rank}_{os.getpid()}.log")
-                os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,P2P", NCCL_DEBUG_FILE=rccl_log)
+            # The transport RCCL picked is read from the caller's OWN debug log when there is one (NCCL_DEBUG=INFO together with
+            # NCCL_DEBUG_FILE=<path with %p / %h>).  The file never switches the log on by itself: at NCCL_DEBUG=INFO this RCCL
+            # (2.26.6) prints a version banner to STDOUT whatever NCCL_DEBUG_FILE says - five lines in front of the ONE JSON
+            # line a driver parses (seen with --force-dist on the GPU box).  Without a log the line carries the peer-access
+            # matrix of the node instead (`peer_access`).
+            dbg_file = os.environ.get("NCCL_DEBUG_FILE")
+            if os.environ.get("NCCL_DEBUG", "").upper() == "INFO" and dbg_file:
+                import socket
+                rccl_log = dbg_file.replace("%p", str(os.getpid())).replace("%h", socket.gethostname())
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
@@ -805,7 +821,8 @@ def main():
             "rccl_ranks": (dist.get_world_size() if use_dist else 1),
             "replicas_identical": replicas_identical,   # parameter checksums (sum, sum of squares) min == max over the ranks after the timed steps
             "self_launched": os.environ.get("UAVGNN_BENCH_SELF_LAUNCHED") == "1",   # plain `python3 bench.py --gpus N` started its own ranks
-            "rccl_transport": rccl_transport_summary(rccl_log) if rccl_log else None,
+            "rccl_transport": rccl_transport_summary(rccl_log) if rccl_log else None,   # only from a caller-provided NCCL_DEBUG=INFO log
+            "peer_access": peer_access_summary(world) if use_dist else None,
             "collective_backend": (None if not use_dist else
                                    {"backend": dist.get_backend(), "rccl_version": ".".join(map(str, th.cuda.nccl.version())),
                                     "NCCL_DEBUG": os.environ.get("NCCL_DEBUG"),
