@@ -567,6 +567,15 @@ def k1_env_standalone(learner, g, a, reps=50, rounds=15):
                    "one event floor per span), no-grad rollout launch through ops.hetero_gatv2 -> uavgnn_gatv2_hetero_fwd_image"}
 
 
+_REAL_STDOUT = None
+
+
+def emit(line: str) -> None:
+    """The ONE JSON line of the run, to the process's original stdout (see main)."""
+    out = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
+    print(line, file=out, flush=True)
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -645,11 +654,11 @@ def dry_launch_main(a, world, rank):
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         same = bool(th.equal(lo, hi))
     if rank == 0:
-        print(json.dumps({"metric": metric_name(a), "value": 0.0, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
+        emit(json.dumps({"metric": metric_name(a), "value": 0.0, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": 1e3 * float(el) / max(a.steps, 1), "dry_run": True,
                           "replicas_identical": same, "rccl_ranks": world,
                           "self_launched": os.environ.get("UAVGNN_BENCH_SELF_LAUNCHED") == "1",
-                          "config": {"global_batch": world * a.B, "parallelism": f"dp{world}"}}), flush=True)
+                          "config": {"global_batch": world * a.B, "parallelism": f"dp{world}"}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -692,6 +701,13 @@ def main():
         sys.exit(f"bench.py: --gpus {a.gpus} but this rank was started with WORLD_SIZE={world} (RANK={rank}); start it as "
                  f"`python3 bench.py --gpus {a.gpus}` (it launches its ranks itself) or as `python -m torch.distributed.run "
                  f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {a.gpus} ...`")
+    # ONE line on stdout, whatever the libraries print: the descriptor of the real stdout is kept for the JSON line and fd 1 is
+    # pointed at stderr for everything else (the GPU box sets NCCL_DEBUG=VERSION, at which RCCL writes a five-line version banner
+    # to the C-level stdout of every rank that creates a communicator).
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if os.environ.get("UAVGNN_BENCH_DRY") == "1":
         return dry_launch_main(a, world, rank)
     # test hooks (tests/test_dp_gpu.py): all ranks on ONE device over gloo, so that the world-size-2 code path of this file
@@ -985,7 +1001,7 @@ def main():
             res["end_to_end_hotspot"] = end_to_end(learner, a, device, "hotspot")
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.n, a.M, a.dist)
-        print(json.dumps(res), flush=True)
+        emit(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()
 
