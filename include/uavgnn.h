@@ -389,9 +389,10 @@ long long uavgnn_gru_weight_tiles_bytes(int K_in, int H);
 int uavgnn_gru_split_weight_tiles(const float* W_ih, int K_in, const float* W_hh, int H, void* tiles, uavgnn_stream_t stream);
 int uavgnn_gru_cell_fwd_planes(const void* planes, int K_in, const float* h, int N, int H, const void* tiles, const float* b_ih,
                                const float* b_hh, float* h_out, float* pre_save, uavgnn_stream_t stream);
-/* ... with a per-call variant word `opt` in 0 .. 7 (0 = uavgnn_gru_cell_fwd_planes; the schedules tools/cell_probe.py compares -
- * bit 0: second-half fragment reads behind the first MFMAs, bit 1: activation DMA two slices ahead (three LDS buffers), bit 2: the
- * epilogue's h tile requested inside the last slice; results are bit-identical for every value). */
+/* ... with a per-call variant word `opt` (0 = uavgnn_gru_cell_fwd_planes; the schedules tools/cell_probe.py compares - bit 0:
+ * second-half fragment reads behind the first MFMAs, bit 1: activation DMA two slices ahead (three LDS buffers), bit 2: the
+ * epilogue's h tile requested inside the last slice, bit 3 (not with bit 1): the DMA of slice t + 2 issued behind the barrier of
+ * slice t; results are bit-identical for every value; UAVGNN_EINVAL outside 0 .. 9, 12, 13). */
 int uavgnn_gru_cell_fwd_planes_opts(const void* planes, int K_in, const float* h, int N, int H, const void* tiles,
                                     const float* b_ih, const float* b_hh, float* h_out, float* pre_save, int opt,
                                     uavgnn_stream_t stream);

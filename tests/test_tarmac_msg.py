@@ -217,7 +217,7 @@ def test_gru_cell_from_operand_planes_is_bit_identical_to_the_in_kernel_split(N,
         assert th.equal(h_a, h_b), f"h' differs: {float((h_a - h_b).abs().max())}"
         if save:
             assert th.equal(pre_a, pre_b)
-        for opt in range(1, 8):          # every schedule of the kernel: the same bits
+        for opt in (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13):          # every schedule of the kernel: the same bits
             h_c = th.full((N, H), float("nan"), device=dev)
             pre_c = th.full((N, 4 * H), float("nan"), device=dev) if save else None
             L.check(lib.uavgnn_gru_cell_fwd_planes_opts(planes.data_ptr(), H + M, h.data_ptr(), N, H, w_tiles.data_ptr(), b_ih.data_ptr(),

@@ -52,8 +52,8 @@ for save in (False, True):
     for rep in range(2):
         t_a = timeit(lambda: lib.uavgnn_gru_cell_fwd_x3_cat(x.data_ptr(), H, H, c.data_ptr(), M, M, h.data_ptr(), N, H, w_planes.data_ptr(),
                                                             b_ih.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), p, L.stream()))
-        line = f"save={int(save)} pass {rep}: in-kernel split {t_a:6.1f} us ({6 * fl / t_a / 1e6 / 2500:.3f}) | operand planes, opt 0..7:"
-        for opt in range(8):
+        line = f"save={int(save)} pass {rep}: in-kernel split {t_a:6.1f} us ({6 * fl / t_a / 1e6 / 2500:.3f}) | operand planes, opt 0..7, 8, 9, 12, 13:"
+        for opt in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13):
             t_b = timeit(lambda: lib.uavgnn_gru_cell_fwd_planes_opts(planes.data_ptr(), H + M, h.data_ptr(), N, H, w_tiles.data_ptr(),
                                                                      b_ih.data_ptr(), b_hh.data_ptr(), h2.data_ptr(), p, opt, L.stream()))
             line += f" {t_b:6.1f}"

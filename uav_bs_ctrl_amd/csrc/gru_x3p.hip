@@ -24,7 +24,6 @@ namespace {
 using namespace x3;
 constexpr int BM = 128, BK = 32, BJ = 64, NT = 512, ST = 68;
 constexpr int PA = BM * 4, PB = 3 * BJ * 4;            // 16-byte chunks per split plane of the A / B tile
-constexpr int BUF = 3 * PA + 3 * PB;                   // chunks per buffer (60 KB)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
@@ -59,18 +58,36 @@ __global__ __launch_bounds__(256) void gru_weight_tiles_kernel(const float* __re
 
 #define UAVGNN_X3_FOR_TERMS(M) M(0, 2) M(2, 0) M(1, 1) M(0, 1) M(1, 0) M(0, 0)
 
+// Timing ablations of tools/cell_ablate.py (a probe library compiled with -DUAVGNN_X3P_DBG=bits; the shipped build has 0 and
+// none of this): 1 no DMA behind the first two slices (16: no activation DMA, 32: no weight DMA), 2 no gate epilogue (the accumulators are stored raw), 4 no MFMA, 8 no
+// fragment reads inside the loop.  Results are garbage for every non-zero value.
+#ifndef UAVGNN_X3P_DBG
+#define UAVGNN_X3P_DBG 0
+#endif
+constexpr int DBG = UAVGNN_X3P_DBG;
+__device__ __forceinline__ f32x16 mfma_dbg(bf16x8 a, bf16x8 b, f32x16 c) {
+  if (DBG & 4) {
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+  }
+  return mfma32(a, b, c);
+}
+
 // OPT (timing experiments of tools/cell_probe.py; results are bit-identical for every value):
 //   bit 0  the fragment reads of the second half are issued BEHIND the first six MFMAs of the first half (the compiler waits for
 //          every LDS read in flight - lgkmcnt(0) - in front of the first MFMA that follows a read in program order);
 //   bit 1  THREE activation buffers: the DMA of the A planes runs two slices ahead (they come from HBM; the weight tiles are
 //          L2-resident and stay one slice ahead), raw s_barrier + counted s_waitcnt vmcnt(3) instead of __syncthreads();
-//   bit 2  the epilogue's h tile is requested at the top of the last slice instead of behind the loop.
+//   bit 2  the epilogue's h tile is requested at the top of the last slice instead of behind the loop;
+//   bit 3  (without bit 1) the DMA of slice t + 2 is issued right BEHIND the barrier of iteration t - the buffer of slice t is free
+//          there - instead of at the top of iteration t + 1: a full slice of MFMA work covers it, not half of one.
 template <bool SAVE, int OPT>
 __global__ __launch_bounds__(NT) void gru_cell_fwd_planes_kernel(const u32x4* __restrict__ Ap, const float* __restrict__ h, int N,
                                                                 int H, int n12, int ns, const u32x4* __restrict__ Wt,
                                                                 const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                                 float* __restrict__ h_out, float* __restrict__ pre, int row_blocks) {
-  constexpr bool LATE_READ = OPT & 1, DEEP = OPT & 2, EARLY_H = OPT & 4;
+  constexpr bool LATE_READ = OPT & 1, DEEP = OPT & 2, EARLY_H = OPT & 4, POST = OPT & 8;
+  static_assert(!(POST && DEEP), "bit 3 replaces bit 1");
   constexpr int NA_BUF = DEEP ? 3 : 2;
   constexpr int A_WORDS = 3 * PA, B_WORDS = 3 * PB;
   __shared__ u32x4 smem[NA_BUF * A_WORDS + 2 * B_WORDS];   // A planes [buf][3][128][4], then B planes [buf][3][192 = gate * 64 + unit][4]
@@ -96,11 +113,13 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_planes_kernel(const u32x4* __
   u32x4* const sB = smem + NA_BUF * A_WORDS;
   // wave w copies the 1-KB pieces w, w + 8, ... of a slice's 24 (A) / 36 (B) pieces
   auto issue_a = [&](int s, int buf) {
+    if ((DBG & 16) && s > 1) return;
     const u32x4* ga = a_src + static_cast<size_t>(s) * A_WORDS;
 #pragma unroll
     for (int k = 0; k < 3; ++k) glds16(ga + (wave + 8 * k) * 64, sA + buf * A_WORDS + (wave + 8 * k) * 64);
   };
   auto issue_b = [&](int s, int buf) {
+    if ((DBG & 32) && s > 1) return;
     const u32x4* gw = w_src + static_cast<size_t>(s) * B_WORDS;
 #pragma unroll
     for (int k = 0; k < 4; ++k) glds16(gw + (wave + 8 * k) * 64, sB + buf * B_WORDS + (wave + 8 * k) * 64);
@@ -119,9 +138,9 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_planes_kernel(const u32x4* __
         F.b[gate][pl] = as_frag(sb[pl * PB + (gate * BJ + wc + l32) * 4 + ((2 * (kh) + lh) ^ sw)]);                \
   }
 #define UAVGNN_X3P_TERM(ia, ib)                    \
-  acc[0] = mfma32(F.a[ia], F.b[0][ib], acc[0]);    \
-  acc[1] = mfma32(F.a[ia], F.b[1][ib], acc[1]);    \
-  acc[NSET] = mfma32(F.a[ia], F.b[2][ib], acc[NSET]);
+  acc[0] = mfma_dbg(F.a[ia], F.b[0][ib], acc[0]);  \
+  acc[1] = mfma_dbg(F.a[ia], F.b[1][ib], acc[1]);  \
+  acc[NSET] = mfma_dbg(F.a[ia], F.b[2][ib], acc[NSET]);
 #define UAVGNN_X3P_MFMA(F_, NSET_)                 \
   {                                                \
     constexpr int NSET = NSET_;                    \
@@ -166,32 +185,38 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_planes_kernel(const u32x4* __
     const int ab = DEEP ? t % 3 : (t & 1), bb = t & 1;                 \
     const int ab1 = DEEP ? (t + 1) % 3 : ((t + 1) & 1);                \
     if (EARLY_H && t == ns - 1) { UAVGNN_X3P_LOAD_H }                  \
-    if (t + 1 < ns) issue_b(t + 1, (t + 1) & 1);                       \
-    if (DEEP) { if (t + 2 < ns) issue_a(t + 2, (t + 2) % 3); }         \
-    else if (t + 1 < ns) issue_a(t + 1, (t + 1) & 1);                  \
+    if (!(DBG & 1) && !POST) {                                         \
+      if (t + 1 < ns) issue_b(t + 1, (t + 1) & 1);                     \
+      if (DEEP) { if (t + 2 < ns) issue_a(t + 2, (t + 2) % 3); }       \
+      else if (t + 1 < ns) issue_a(t + 1, (t + 1) & 1);                \
+    }                                                                  \
     if (LATE_READ) {                                                   \
       __builtin_amdgcn_sched_barrier(0);                               \
       UAVGNN_X3P_MFMA_HEAD(f0, NSET)                                   \
       __builtin_amdgcn_sched_barrier(0);                               \
-      UAVGNN_X3P_READ(f1, ab, bb, 1)                                   \
+      if (!(DBG & 8)) UAVGNN_X3P_READ(f1, ab, bb, 1)                   \
       __builtin_amdgcn_sched_barrier(0);                               \
       UAVGNN_X3P_MFMA_TAIL(f0, NSET)                                   \
     } else {                                                           \
-      UAVGNN_X3P_READ(f1, ab, bb, 1)                                   \
+      if (!(DBG & 8)) UAVGNN_X3P_READ(f1, ab, bb, 1)                   \
       __builtin_amdgcn_sched_barrier(0);                               \
       UAVGNN_X3P_MFMA(f0, NSET)                                        \
     }                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                 \
     slice_barrier(t + 2 < ns);                                         \
+    if (POST && !(DBG & 1) && t + 2 < ns) {                            \
+      issue_b(t + 2, t & 1);                                           \
+      issue_a(t + 2, t & 1);                                           \
+    }                                                                  \
     if (LATE_READ) {                                                   \
       __builtin_amdgcn_sched_barrier(0);                               \
       UAVGNN_X3P_MFMA_HEAD(f1, NSET)                                   \
       __builtin_amdgcn_sched_barrier(0);                               \
-      UAVGNN_X3P_READ(f0, ab1, (t + 1) & 1, 0)                         \
+      if (!(DBG & 8)) UAVGNN_X3P_READ(f0, ab1, (t + 1) & 1, 0)         \
       __builtin_amdgcn_sched_barrier(0);                               \
       UAVGNN_X3P_MFMA_TAIL(f1, NSET)                                   \
     } else {                                                           \
-      UAVGNN_X3P_READ(f0, ab1, (t + 1) & 1, 0)                         \
+      if (!(DBG & 8)) UAVGNN_X3P_READ(f0, ab1, (t + 1) & 1, 0)         \
       __builtin_amdgcn_sched_barrier(0);                               \
       UAVGNN_X3P_MFMA(f1, NSET)                                        \
     }                                                                  \
@@ -201,9 +226,14 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_planes_kernel(const u32x4* __
   issue_b(0, 0);
   issue_a(0, 0);
   if (DEEP && ns > 1) issue_a(1, 1);
+  if (POST && ns > 1) {
+    issue_b(1, 1);
+    issue_a(1, 1);
+  }
   slice_barrier(DEEP && ns > 1);
   Half f0, f1;
   UAVGNN_X3P_READ(f0, 0, 0, 0)
+  if (DBG & 8) UAVGNN_X3P_READ(f1, 0, 0, 1)
   int t = 0;
   for (; t < n12; ++t) UAVGNN_X3P_STEP(2)
   for (; t < ns; ++t) UAVGNN_X3P_STEP(3)
@@ -214,6 +244,14 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_planes_kernel(const u32x4* __
 #undef UAVGNN_X3P_TERM
 #undef UAVGNN_X3P_READ
   __syncthreads();   // the last iteration's read of the stale buffer must not race the epilogue's tile
+  if (DBG & 2) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = m0 + wm + 8 * (i >> 2) + 4 * lh + (i & 3);
+      if (row < N) h_out[static_cast<size_t>(row) * H + j0 + wc + l32] = acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i];
+    }
+    return;
+  }
 
   // ---- epilogue (csrc/gru_x3.hip): biases, gates, h' through an LDS tile -------------------------------------------------
   float* sH = reinterpret_cast<float*>(smem);             // [128][ST] fp32 tile: h in, h' out
@@ -281,7 +319,7 @@ extern "C" int uavgnn_gru_split_weight_tiles(const float* W_ih, int K_in, const 
 extern "C" int uavgnn_gru_cell_fwd_planes_opts(const void* planes, int K_in, const float* h, int N, int H, const void* tiles,
                                                const float* b_ih, const float* b_hh, float* h_out, float* pre_save, int opt,
                                                uavgnn_stream_t stream) {
-  if (N < 0 || !planes || !h || !tiles || !b_ih || !b_hh || !h_out || opt < 0 || opt > 7) return UAVGNN_EINVAL;
+  if (N < 0 || !planes || !h || !tiles || !b_ih || !b_hh || !h_out || opt < 0 || opt > 15 || ((opt & 8) && (opt & 2))) return UAVGNN_EINVAL;
   if (K_in < BK || (K_in % BK) || H < BJ || (H % BJ) ||
       ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(tiles) |
         reinterpret_cast<uintptr_t>(h_out)) & 15))
@@ -304,7 +342,7 @@ extern "C" int uavgnn_gru_cell_fwd_planes_opts(const void* planes, int K_in, con
     break;
   switch (opt) {
     UAVGNN_X3P_LAUNCH(0) UAVGNN_X3P_LAUNCH(1) UAVGNN_X3P_LAUNCH(2) UAVGNN_X3P_LAUNCH(3) UAVGNN_X3P_LAUNCH(4) UAVGNN_X3P_LAUNCH(5)
-    UAVGNN_X3P_LAUNCH(6) UAVGNN_X3P_LAUNCH(7)
+    UAVGNN_X3P_LAUNCH(6) UAVGNN_X3P_LAUNCH(7) UAVGNN_X3P_LAUNCH(8) UAVGNN_X3P_LAUNCH(9) UAVGNN_X3P_LAUNCH(12) UAVGNN_X3P_LAUNCH(13)
   }
 #undef UAVGNN_X3P_LAUNCH
   return launch_status();
