@@ -452,6 +452,9 @@ def event_span_floor_us():
     return _SPAN_FLOOR
 
 
+GRAPHED_CYCLE_ROWS = 8192     # agent rows per GPU at or below which --graphed-cycle auto replays the cycle from a hipGraph
+
+
 def k1_roofline(k, a, dist_name, clock_mhz):
     """``roofline`` object of the fused K1 forward from the HIP-event spans `k` of a timed region (every launch of it:
     rollout launches over N_a destinations, the two time-batched encoder launches of an update over (T+1) N_a / T N_a
@@ -687,6 +690,9 @@ def main():
     ap.add_argument("--no-rho-leg", action="store_true", help="skip the replay-ratio leg (one cycle with rho chunks per update)")
     ap.add_argument("--no-env-leg", action="store_true", help="skip the short D-env leg (`roofline_env`: the HBM-bound regime of K1)")
     ap.add_argument("--env-steps", type=int, default=5, help="timed steps of the D-env leg")
+    ap.add_argument("--graphed-cycle", default="auto", choices=["auto", "on", "off"],
+                    help="replay the timed cycle from one hipGraph (graphs.GraphedCycle); auto: below %d agent rows per GPU, "
+                         "single process - the default C3 batch runs eagerly" % GRAPHED_CYCLE_ROWS)
     ap.add_argument("--no-fp32-leg", action="store_true",
                     help="skip the second timing with the bf16x3 kernels off (fp32-MFMA GRU cell, vendor fp32 GEMMs)")
     a = ap.parse_args()
@@ -762,11 +768,30 @@ def main():
             dist.barrier()
         th.cuda.synchronize()
 
+    # Small batches (C2: 4 096 agent rows) are launch-bound: the same cycle, captured once and replayed (every input of
+    # `step` already sits at a fixed device address).  Never for the default C3 batch, never with a collective in the update.
+    eager_step = step
+    graphed_cycle = not use_dist and (a.graphed_cycle == "on" or (a.graphed_cycle == "auto" and a.B * a.n <= GRAPHED_CYCLE_ROWS))
+    if graphed_cycle:
+        from uav_bs_ctrl_amd.graphs import GraphedCycle
+        h_row = learner.init_hidden(1)[:1].clone()      # the agent's initial state, moved to the device outside the capture
+
+        def body():
+            obs = [g.fresh() for g in batch["obs"]]
+            fb = dict(batch, obs=obs, obs_all=batch["obs_all"].fresh(), obs_all_next=batch["obs_all_next"].fresh())
+            h = h_row.expand(a.n * a.B, -1).contiguous()
+            for t in range(a.T):
+                _, h = learner.act(obs[t].fresh(), h, 0.05)
+            return learner.update(fb)
+
+        ops.KERNEL_TIMER.reset(enabled=False)           # HIP events cannot be read back from inside a replayed graph
+        step = GraphedCycle(learner, body)
+
     # Inside the timed region only the GRADED kernel (K1 forward) carries HIP events: timing every launch costs the launch thread
     # ~15 us per launch and makes the rollout phase host-bound (tools/launch_bound_probe.py: 21 -> 29 ms per 50 act forwards).
     # The other kernels are timed in ONE extra, fully instrumented cycle after the timed region (`instrumented_cycle`).
     GRADED = ("gatv2_hetero_fwd",)
-    ops.KERNEL_TIMER.reset(enabled=True, only=GRADED)   # warm-up runs instrumented the same way
+    ops.KERNEL_TIMER.reset(enabled=not graphed_cycle, only=GRADED)   # warm-up runs instrumented the same way
     for _ in range(a.warmup):
         step()
     barrier()
@@ -775,7 +800,7 @@ def main():
     # counting as usual.
     gc.collect()
     gc.disable()
-    ops.KERNEL_TIMER.reset(enabled=True, only=GRADED)
+    ops.KERNEL_TIMER.reset(enabled=not graphed_cycle, only=GRADED)
     learner.grads.collective_events = []            # HIP events around the one collective of an update (when there is one)
     clock = ClockSampler(local)
     with clock:
@@ -795,7 +820,7 @@ def main():
     clock_mhz = clock_info["mean_mhz"] if clock_info else None
     ops.KERNEL_TIMER.reset(enabled=True)              # every span: one more cycle, on every rank (the update holds a collective)
     t_i = time.perf_counter()
-    step()
+    eager_step()
     barrier()
     instr_s = time.perf_counter() - t_i
     kfull = ops.KERNEL_TIMER.summary()
@@ -851,9 +876,12 @@ def main():
             "step_ms_device": [round(marks[i - 1].elapsed_time(marks[i]), 1) for i in range(1, len(marks))],
         }
         # ---- roofline of the dominant message-passing kernel: K1 forward, BOTH relations (one fused launch) ----------
-        k = ktimes.get("gatv2_hetero_fwd")
+        k = ktimes.get("gatv2_hetero_fwd") or kfull.get("gatv2_hetero_fwd")   # graphed cycle: from the eager instrumented cycle
         if k:
             res["roofline"] = k1_roofline(k, a, a.dist, clock_mhz)
+            if graphed_cycle:
+                res["roofline"]["timed_in"] = "the eager instrumented cycle behind the timed replays (`instrumented_cycle`)"
+        res["graphed_cycle"] = graphed_cycle   # the timed steps were replays of ONE captured hipGraph of the whole cycle
         # ---- the GEMM-shaped kernels by time share (the GRU cell is the largest kernel of a dense cycle): MFMA roofs ----------
         sec = []
         kc = kfull.get("gru_cell_fwd")
@@ -910,13 +938,13 @@ def main():
             saved_flags = (ops.GRU_X3, ops.GEMM_X3, ops.K1_BF16Z)     # a run started with UAVGNN_*=0 keeps its own setting afterwards
             ops.GRU_X3 = ops.GEMM_X3 = ops.K1_BF16Z = False
             try:
-                step()
+                eager_step()
                 th.cuda.synchronize()
                 gc.collect()
                 gc.disable()
                 t1 = time.perf_counter()
                 for _ in range(5):
-                    step()
+                    eager_step()
                 th.cuda.synchronize()
                 e1 = time.perf_counter() - t1
                 gc.enable()

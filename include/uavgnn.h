@@ -404,12 +404,14 @@ int uavgnn_gru_cell_fwd_planes_opts(const void* planes, int K_in, const float* h
  * 6 R C bytes, 16-byte aligned.  K % 32 == 0, ldx % 4 == 0, X 16-byte aligned; M, N arbitrary. */
 #define UAVGNN_GEMM_ACCUMULATE 1
 #define UAVGNN_GEMM_RELU 2
-/* kernel variants, selected per call by further bits of `epilogue` (A/B references of tools/gemm_x3_probe.py; same results bit
- * for bit): default = 256 x 128 tiles, eight waves, double-buffered LDS, staging of a slice as a block;
+/* kernel variants, selected per call by further bits of `epilogue` (A/B references of tools/gemm_x3_probe.py; the two eight-wave
+ * variants agree bit for bit, so do the two four-wave ones - the pairs differ in accumulation order, inside the same error
+ * bound): default = 256 x 128 tiles, eight waves, double-buffered LDS, staging of a slice as a block;
  * STAGING_INTERLEAVED = the same with the staging interleaved with the MFMAs (faster per launch, not per power-limited cycle);
- * TILE_128 = 128 x 128 tiles, four waves */
+ * TILE_128 = 128 x 128 tiles, four waves; TILE_64 = 64 x 128 tiles, four waves (batches of a few thousand rows: twice the workgroups) */
 #define UAVGNN_GEMM_STAGING_INTERLEAVED 4
 #define UAVGNN_GEMM_TILE_128 8
+#define UAVGNN_GEMM_TILE_64 16
 int uavgnn_gemm_x3_supported(int M, int N, int K);
 int uavgnn_split_bf16x3(const float* W, int ld, int R, int C, int transpose, void* planes, uavgnn_stream_t stream);
 int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const void* planes, int N, const float* bias, float* Y, int ldy,

@@ -2294,3 +2294,85 @@ def test_rollout_weight_cache_of_the_learner_is_invalidated_by_every_parameter_c
     a, b = episode(True), episode(False)
     for x, y in zip(a, b):
         assert th.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_graphed_cycle_replay_equals_the_eager_cycle():
+    """graphs.GraphedCycle: T act calls on stored graphs + one update, captured once; a replay moves the parameters exactly as the
+    eager cycle does from the same state (the rollout's draws do not feed the update: it trains on the stored batch)."""
+    import bench
+    from uav_bs_ctrl_amd.graphs import GraphedCycle
+    from uav_bs_ctrl_amd.learner import MultiAgentQLearner
+    dev = th.device("cuda")
+    n, M, T, B = 4, 10, 4, 8
+    th.manual_seed(3)
+    env_info = dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=9, n_agents=n, episode_limit=T)
+    lr = MultiAgentQLearner(env_info, bench.exp3_args("cuda"))
+    batch = bench.make_sequence(B, n, M, T, "dense", dev, seed=5, distinct=2)
+    h_row = lr.init_hidden(1)[:1].clone()
+    hs = []
+
+    def body():
+        obs = [g.fresh() for g in batch["obs"]]
+        fb = dict(batch, obs=obs, obs_all=batch["obs_all"].fresh(), obs_all_next=batch["obs_all_next"].fresh())
+        h = h_row.expand(n * B, -1).contiguous()
+        for t in range(T):
+            _, h = lr.act(obs[t].fresh(), h, 0.0)
+        hs.append(h)
+        return lr.update(fb)
+
+    cyc = GraphedCycle(lr, body)
+    state = [t.clone() for t in (lr.flat.flat, lr.flat_target, lr.optimizer.m, lr.optimizer.v, lr.optimizer.hyper)]
+    out = cyc()
+    th.cuda.synchronize()
+    got = [lr.flat.flat.clone(), lr.flat_target.clone(), float(out["LossQ"]), hs[-1].clone()]
+    out2 = cyc()                                   # a second replay starts from the moved parameters
+    th.cuda.synchronize()
+    got2 = [lr.flat.flat.clone(), float(out2["LossQ"])]
+    for dst, src in zip((lr.flat.flat, lr.flat_target, lr.optimizer.m, lr.optimizer.v, lr.optimizer.hyper), state):
+        dst.copy_(src)
+    lr.invalidate_weight_cache()
+    ref = body()
+    th.cuda.synchronize()
+    assert float(ref["LossQ"]) == got[2]
+    assert th.equal(lr.flat.flat, got[0]) and th.equal(lr.flat_target, got[1])
+    assert th.equal(hs[-1], got[3])
+    ref2 = body()
+    th.cuda.synchronize()
+    assert float(ref2["LossQ"]) == got2[1] and th.equal(lr.flat.flat, got2[0])
+    assert got2[1] != got[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 768), (4100, 320, 256), (70, 128, 64)])
+def test_gemm_bf16x3_tile_variants_are_bit_identical(M, N, K):
+    """include/uavgnn.h: the tile variants of uavgnn_gemm_nt_x3 (256 x 128 eight waves, + interleaved staging, 128 x 128 and 64 x 128
+    four waves - the one `ops.gemm_x3` picks for batches of a few thousand rows): bit-identical within the eight-wave pair and
+    within the four-wave pair, every one of them inside the fp32 error bound."""
+    from uav_bs_ctrl_amd import _lib as L
+    lib = L.lib()
+    gen = th.Generator().manual_seed(M + K)
+    a = th.randn(M, K, generator=gen).cuda()
+    W = (0.1 * th.randn(N, K, generator=gen)).cuda()
+    bias = th.randn(N, generator=gen).cuda()
+    planes = th.empty(6 * N * K, dtype=th.uint8, device="cuda")
+    L.check(lib.uavgnn_split_bf16x3(W.data_ptr(), K, N, K, 0, planes.data_ptr(), L.stream()), "split")
+    y0 = th.randn(M, N, generator=gen).cuda()
+    outs = []
+    for flags in (0, 4, 8, 16):
+        for epi in (0, 1, 2, 3):
+            y = y0.clone()
+            L.check(lib.uavgnn_gemm_nt_x3(a.data_ptr(), K, M, K, planes.data_ptr(), N, bias.data_ptr(), y.data_ptr(), N, epi | flags,
+                                          L.stream()), f"gemm flags {flags} epilogue {epi}")
+            outs.append((flags, epi, y))
+    th.cuda.synchronize()
+    ref = a.double() @ W.double().t() + bias.double()
+    scale = a.double().abs() @ W.double().abs().t() + bias.double().abs()
+    # the eight-wave kernels walk a slice half by half, the four-wave kernels term by term: two accumulation orders, each shared by
+    # its two variants, both inside the fp32 bound
+    for group in ((0, 4), (8, 16)):
+        base = {epi: y for f, epi, y in outs if f == group[0]}
+        assert float(((base[0].double() - ref).abs() / scale).max()) < 6e-7
+        for f, epi, y in outs:
+            if f in group:
+                assert th.equal(y, base[epi]), f"variant {f}, epilogue {epi}: differs from variant {group[0]}"

@@ -45,33 +45,37 @@ __global__ __launch_bounds__(256) void split_matrix_kernel(const float* __restri
   *reinterpret_cast<unsigned*>(planes + 2 * n + p) = s.h3;
 }
 
-template <bool ACC, bool RELU>
+// BM_ = 128: four waves of 64 x 64 (2 x 2 tiles of 32 x 32).  BM_ = 64 (UAVGNN_GEMM_TILE_64): 64 x 128 output tile, four waves of
+// 64 x 32 - twice the workgroups for batches of a few thousand rows ([4096, 768] x [768, 256] is 64 workgroups of 128 x 128 on 256 CUs).
+template <bool ACC, bool RELU, int BM_>
 __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(const float* __restrict__ X, int ldx, int M, int K,
                                                             const unsigned short* __restrict__ Bp, int N,
                                                             const float* __restrict__ bias, float* __restrict__ Y, int ldy,
                                                             int row_blocks, int col_blocks) {
+  constexpr int NB = BM_ == 128 ? 2 : 1;     // column tiles of a wave
+  constexpr int XI = BM_ / 32;               // float4 of X per thread and slice
   __shared__ u32x4 sA[3 * PT], sB[3 * PT];   // [plane][row][4 chunks of 8 bf16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l32 = lane & 31, lh = lane >> 5, sw = swz32(l32);
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = BM_ == 128 ? (wave >> 1) * 64 : 0, wn = BM_ == 128 ? (wave & 1) * 64 : wave * 32;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int rb = (slot / col_blocks) * 8 + xcd, cb = slot - (slot / col_blocks) * col_blocks;
   if (rb >= row_blocks) return;
-  const int m0 = rb * BM, n0 = cb * BN;
+  const int m0 = rb * BM_, n0 = cb * BN;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NB];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
   // X loader: float4 q = tid + 256 i -> row tid / 8 + 32 i, k = 4 (tid % 8); rows past M are clamped (stores are masked)
   const int lr = tid >> 3, c4 = tid & 7;
-  unsigned xo[4];
+  unsigned xo[XI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) xo[i] = static_cast<unsigned>(min(m0 + lr + 32 * i, M - 1)) * ldx + 4 * c4;
+  for (int i = 0; i < XI; ++i) xo[i] = static_cast<unsigned>(min(m0 + lr + 32 * i, M - 1)) * ldx + 4 * c4;
   unsigned short* sa_w = reinterpret_cast<unsigned short*>(sA) + lr * 32 + (((c4 >> 1) ^ swz32(lr)) * 8) + (c4 & 1) * 4;
   // B loader: chunk q = tid + 256 i (i < 6): plane q / 512, row (q % 512) / 4, chunk q % 4; rows past N are clamped
   unsigned bo[6];
@@ -83,11 +87,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(const float* __restr
     bo[i] = pl * plane + static_cast<unsigned>(min(n0 + row, N - 1)) * K + 8 * c;
     sbw[i] = pl * PT + row * 4 + (c ^ swz32(row));
   }
-  float4 ra[4];
+  float4 ra[XI];
   u32x4 rw[6];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(X + (xo[i] + k0));
+    for (int i = 0; i < XI; ++i) ra[i] = *reinterpret_cast<const float4*>(X + (xo[i] + k0));
 #pragma unroll
     for (int i = 0; i < 6; ++i) rw[i] = *reinterpret_cast<const u32x4*>(Bp + (bo[i] + k0));
   };
@@ -95,32 +99,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(const float* __restr
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) stage4(sa_w + 32 * i * 32, PT * 8, ra[i]);
+    for (int i = 0; i < XI; ++i) stage4(sa_w + 32 * i * 32, PT * 8, ra[i]);
 #pragma unroll
     for (int i = 0; i < 6; ++i) sB[sbw[i]] = rw[i];
     __syncthreads();
     gload(min(k0 + BK, K - BK));                       // unconditional (the tail re-reads the last slice): static vmcnt
     __builtin_amdgcn_sched_barrier(0);                 // keep the loads ahead of the MFMA block
-    bf16x8 fa[2][2][3], fb[2][2][3];                   // [tile][half][plane]
+    bf16x8 fa[2][2][3], fb[NB][2][3];                  // [tile][half][plane]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
+      for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          fa[a][kh][pl] = as_frag(sA[pl * PT + (wm + a * 32 + l32) * 4 + ((2 * kh + lh) ^ sw)]);
-          fb[a][kh][pl] = as_frag(sB[pl * PT + (wn + a * 32 + l32) * 4 + ((2 * kh + lh) ^ sw)]);
-        }
-    // six products, smallest first; four independent accumulators between dependent MFMAs
+        for (int a = 0; a < 2; ++a) fa[a][kh][pl] = as_frag(sA[pl * PT + (wm + a * 32 + l32) * 4 + ((2 * kh + lh) ^ sw)]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) fb[b][kh][pl] = as_frag(sB[pl * PT + (wn + b * 32 + l32) * 4 + ((2 * kh + lh) ^ sw)]);
+      }
+    // six products, smallest first; four (BM_ = 64: two x two halves) independent accumulators between dependent MFMAs
 #define UAVGNN_X3_TERM(ia, ib)                                                                     \
   _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int a = 0; a < 2; ++a)  \
-      _Pragma("unroll") for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(fa[a][kh][ia], fb[b][kh][ib], acc[a][b]);
+      _Pragma("unroll") for (int b = 0; b < NB; ++b) acc[a][b] = mfma32(fa[a][kh][ia], fb[b][kh][ib], acc[a][b]);
     UAVGNN_X3_TERM(0, 2) UAVGNN_X3_TERM(2, 0) UAVGNN_X3_TERM(1, 1) UAVGNN_X3_TERM(0, 1) UAVGNN_X3_TERM(1, 0) UAVGNN_X3_TERM(0, 0)
 #undef UAVGNN_X3_TERM
   }
   // D layout of a 32 x 32 tile: lane l holds column l % 32, register i holds row 8 (i / 4) + 4 (l / 32) + i % 4
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < NB; ++b) {
     const int col = n0 + wn + b * 32 + l32;
     if (col >= N) continue;
     const float bv = bias != nullptr ? bias[col] : 0.f;
@@ -414,7 +418,7 @@ extern "C" int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const vo
   const unsigned short* bp = static_cast<const unsigned short*>(planes);
   const bool acc = (epilogue & UAVGNN_GEMM_ACCUMULATE) != 0, relu = (epilogue & UAVGNN_GEMM_RELU) != 0;
   const int col_blocks = (N + BN - 1) / BN;
-  if (!(epilogue & UAVGNN_GEMM_TILE_128)) {
+  if (!(epilogue & (UAVGNN_GEMM_TILE_128 | UAVGNN_GEMM_TILE_64))) {
     const int row_blocks = (M + w8::BM8 - 1) / w8::BM8;
     const dim3 grid(((row_blocks + 7) / 8) * 8 * col_blocks), block(w8::NT);
 #define UAVGNN_X3_GEMM(ACC, RELU, IL)                                                                                        \
@@ -431,15 +435,20 @@ extern "C" int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const vo
 #undef UAVGNN_X3_GEMM
     return launch_status();
   }
-  const int row_blocks = (M + BM - 1) / BM;
+  const int bm = (epilogue & UAVGNN_GEMM_TILE_64) ? 64 : BM;
+  const int row_blocks = (M + bm - 1) / bm;
   const dim3 grid(((row_blocks + 7) / 8) * 8 * col_blocks), block(256);
-#define UAVGNN_X3_GEMM(ACC, RELU)                                                                                      \
-  hipLaunchKernelGGL((gemm_nt_x3_kernel<ACC, RELU>), grid, block, 0, st, X, ldx, M, K, bp, N, bias, Y, ldy, row_blocks, \
+#define UAVGNN_X3_GEMM(ACC, RELU, BM_)                                                                                       \
+  hipLaunchKernelGGL((gemm_nt_x3_kernel<ACC, RELU, BM_>), grid, block, 0, st, X, ldx, M, K, bp, N, bias, Y, ldy, row_blocks, \
                      col_blocks)
-  if (acc && relu) UAVGNN_X3_GEMM(true, true);
-  else if (acc) UAVGNN_X3_GEMM(true, false);
-  else if (relu) UAVGNN_X3_GEMM(false, true);
-  else UAVGNN_X3_GEMM(false, false);
+#define UAVGNN_X3_GEMM_BM(BM_)                         \
+  if (acc && relu) UAVGNN_X3_GEMM(true, true, BM_);    \
+  else if (acc) UAVGNN_X3_GEMM(true, false, BM_);      \
+  else if (relu) UAVGNN_X3_GEMM(false, true, BM_);     \
+  else UAVGNN_X3_GEMM(false, false, BM_);
+  if (bm == 64) { UAVGNN_X3_GEMM_BM(64) }
+  else { UAVGNN_X3_GEMM_BM(128) }
+#undef UAVGNN_X3_GEMM_BM
 #undef UAVGNN_X3_GEMM
   return launch_status();
 }

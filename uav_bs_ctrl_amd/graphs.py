@@ -179,3 +179,50 @@ class GraphedUpdate:
             self.graph_tail.replay()
         self.learner.invalidate_weight_cache()   # the replay moved the parameters without passing through learner.apply()
         return self.out
+
+
+class GraphedCycle:
+    """A whole acting / training cycle on FIXED-ADDRESS inputs - e.g. T ``learner.act`` calls on stored graphs followed by one
+    ``learner.update`` - as one graph replay.  For batches of a few thousand agents (BASELINE config 2: 4 x 40, B = 1024) the
+    ~4000 launches of a cycle are 5-20 us each and the launch thread, not the device, sets the pace; the replay removes the gaps.
+
+        cyc = GraphedCycle(learner, body)      # body(): learner calls only, every input at a fixed device address, no host
+        out = cyc()                            # round trip; returns body()'s value (the graph's own buffers)
+
+    ``body`` runs ``warmup`` times for real before the capture (allocator pools, lazy kernels, plane caches); parameters,
+    target and optimiser state are restored afterwards.  Single-process only: a data-parallel update holds a
+    collective (``GraphedUpdate`` cuts the capture there).  The learning rate is pushed to the device before each replay
+    and the rollout's weight-plane store is emptied after it (the replay moved the parameters without passing through
+    ``learner.apply``)."""
+
+    def __init__(self, learner, body, warmup: int = 2):
+        assert learner.fused_tail, "graph capture needs the device-resident update tail (CUDA learner)"
+        assert not learner.needs_collective(), "a data-parallel update cannot be captured whole: use GraphedUpdate"
+        self.learner, self.body = learner, body
+        self.graph = th.cuda.CUDAGraph()
+        if hasattr(self.graph, "register_generator_state"):
+            self.graph.register_generator_state(learner._gen)
+        # the warm-up cycles run for real (an update inside `body` moves the parameters): snapshot and restore around them, so a
+        # graphed run starts from the state an eager run starts from
+        state = (learner.flat.flat, learner.flat_target, learner.optimizer.m, learner.optimizer.v, learner.optimizer.hyper)
+        snap = [t.clone() for t in state]
+        side = th.cuda.Stream()
+        side.wait_stream(th.cuda.current_stream())
+        with th.cuda.stream(side):
+            for _ in range(warmup):
+                body()
+        th.cuda.current_stream().wait_stream(side)
+        learner.invalidate_weight_cache()
+        learner.optimizer.sync_lr()
+        with th.cuda.graph(self.graph):
+            self.out = body()
+        th.cuda.synchronize()
+        for dst, src in zip(state, snap):
+            dst.copy_(src)
+        learner.invalidate_weight_cache()
+
+    def __call__(self):
+        self.learner.optimizer.sync_lr()
+        self.graph.replay()
+        self.learner.invalidate_weight_cache()
+        return self.out

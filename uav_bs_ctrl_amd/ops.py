@@ -574,6 +574,8 @@ def gemm_x3(a, W, transpose_w=False, bias=None, out=None, accumulate=False, relu
             # C2-size batches (N_a = 4096): the 256 x 128 tiles of the eight-wave kernel are 32 workgroups on 256 CUs (58 us for
             # [4096, 768] x [768, 256]); the four-wave kernel's 128 x 128 tiles double the workgroups (UAVGNN_GEMM_TILE_128)
             flags |= 8
+            if ((M + 127) // 128) * ((n_out + 127) // 128) < GEMM_X3_SMALL_GRID:
+                flags = (flags & ~8) | 16         # still under half the CUs: 64 x 128 tiles (UAVGNN_GEMM_TILE_64)
         rc = lib.uavgnn_gemm_nt_x3(a.data_ptr(), a.stride(0), M, K, planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(),
                                    out.stride(0), (1 if accumulate else 0) | (2 if relu else 0) | flags, L.stream())
     L.check(rc, "uavgnn_gemm_nt_x3")
