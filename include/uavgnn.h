@@ -273,7 +273,10 @@ int uavgnn_tarmac_msg_fwd(const float* x, int ld_x, const float* h, int ld_h, in
                           const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src, float scale,
                           float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p, float* x_copy, int ld_xc,
                           void* planes_out, uavgnn_stream_t stream);
-/* timing ablations of tools/msg_probe.py (`dbg` != 0 skips parts of the GEMM loop: the outputs are then WRONG) */
+/* ... with a variant word: bits 0-3 are timing ablations of tools/msg_probe.py (parts of the GEMM loop skipped: the outputs are then
+ * WRONG); bit 4 (16) selects the one-wavefront-per-row-tile kernel where uavgnn_tarmac_msg_fwd runs the wavefront-pair kernel (no
+ * planes_out, M + 2K <= 96) - correct results, the A/B reference; the two kernels sum the x and h halves of the projection in
+ * different orders and may differ in the last bit */
 int uavgnn_tarmac_msg_fwd_dbg(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles,
                               const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src, float scale,
                               float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p, float* x_copy, int ld_xc,

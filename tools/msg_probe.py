@@ -43,12 +43,12 @@ def timeit(fn, reps=30):
     return 1e3 * e0.elapsed_time(e1) / reps
 
 
-def msg(train, pl):
+def msg(train, pl, dbg=0):
     def f():
-        rc = lib.uavgnn_tarmac_msg_fwd(x.data_ptr(), H, h.data_ptr(), H, N, H, n, tiles.data_ptr(), bp.data_ptr(), M, K, off.data_ptr(),
-                                       src.data_ptr(), 1.0 / K, (inp.data_ptr() + 4 * H) if train else c.data_ptr(), (H + M) if train else M,
-                                       a_save.data_ptr() if train else None, proj.data_ptr() if train else None, M + 2 * K,
-                                       inp.data_ptr() if train else None, H + M, planes.data_ptr() if pl else None, L.stream())
+        rc = lib.uavgnn_tarmac_msg_fwd_dbg(x.data_ptr(), H, h.data_ptr(), H, N, H, n, tiles.data_ptr(), bp.data_ptr(), M, K, off.data_ptr(),
+                                           src.data_ptr(), 1.0 / K, (inp.data_ptr() + 4 * H) if train else c.data_ptr(), (H + M) if train else M,
+                                           a_save.data_ptr() if train else None, proj.data_ptr() if train else None, M + 2 * K,
+                                           inp.data_ptr() if train else None, H + M, planes.data_ptr() if pl else None, dbg, L.stream())
         assert rc == 0
     return f
 
@@ -86,13 +86,15 @@ for dbg, what in ((1, "no weight-slice traffic"), (2, "no MFMAs"), (4, "no activ
     def f(dbg=dbg):
         assert lib.uavgnn_tarmac_msg_fwd_dbg(x.data_ptr(), H, h.data_ptr(), H, N, H, n, tiles.data_ptr(), bp.data_ptr(), M, K, off_none.data_ptr(),
                                              src.data_ptr(), 1.0 / K, c.data_ptr(), M, None, None, 0, None, 0, None, dbg, L.stream()) == 0
-    print(f"#   ablation (no edges) dbg={dbg:2d} {what:42s}: {timeit(f):6.1f} us")
+    print(f"#   ablation (no edges, one wavefront per row tile) dbg={dbg:2d} {what:42s}: {timeit(f):6.1f} us")
 print(f"# N = {N} rows ({B} graphs of {n}), H {H}, M {M}, K {K}; us per call, 30 back-to-back calls between one event pair")
 for train in (False, True):
     t_old = timeit(old(train))
     t_new = timeit(msg(train, False))
+    t_one = timeit(msg(train, False, 16))
     t_pl = timeit(msg(train, True))
     rd = 2 * N * H * 4
     wr = N * M * 4 + (N * (H + M + 2 * K) * 4 + E * 4 if train else 0)
-    print(f"train={int(train)}: two GEMMs + K3b {t_old:7.1f} | fused {t_new:7.1f} ({(rd + wr) / t_new / 1e6:.2f} TB/s algorithmic) | "
+    print(f"train={int(train)}: two GEMMs + K3b {t_old:7.1f} | fused, wavefront pair per row tile {t_new:7.1f} ({(rd + wr) / t_new / 1e6:.2f} TB/s algorithmic) | "
+          f"one wavefront per row tile {t_one:7.1f} | "
           f"fused + operand planes {t_pl:7.1f} ({(rd + wr + planes.numel()) / t_pl / 1e6:.2f} TB/s)")

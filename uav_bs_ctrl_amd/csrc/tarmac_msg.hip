@@ -370,6 +370,231 @@ __global__ __launch_bounds__(kMsgThreads, CT == 8 ? 2 : 3) void tarmac_msg_fwd_k
   }
 }
 
+
+// ---- two wavefronts per row tile (split K) ------------------------------------------------------------------------------------
+// N / 16 row tiles are two wavefronts per SIMD at C3, each walking a serial chain of 16 slices (load - split - 36 MFMAs - barrier)
+// and then the attention: the parts of tools/msg_probe.py's ablation ADD (11 us split + tail, 8 us activation stream, 11.6 us
+// weights + MFMAs = 31.5 us).  Here a row tile belongs to a PAIR of wavefronts of one workgroup (eight wavefronts, 64 rows): wave
+// `tile` contracts the x half of [x || h] (+ bias), wave `4 + tile` the h half - half the chain each, four wavefronts per SIMD to
+// hide each other's waits; a weight stage in LDS holds the x slice t AND the h slice t.  The h partial is added to the tile in
+// LDS, then the first wavefront of the pair runs the attention while the second writes `proj` (training).  The sum is
+// (x part + bias) + h part - the order of the two-GEMM path of rounds 1-4 -, not the single 16-slice chain of the kernel above.
+template <int CT, bool TRAIN>
+__global__ __launch_bounds__(2 * kMsgThreads, 4) void tarmac_msg_fwd_k2_kernel(
+    const float* __restrict__ x, int ld_x, const float* __restrict__ h, int ld_h, int N, int H, int n_ag,
+    const u32x4* __restrict__ Wt, const float* __restrict__ bias, int M, int K, const int32_t* __restrict__ talk_off,
+    const int32_t* __restrict__ talk_src, float scale, float* __restrict__ c_out, int ld_c, float* __restrict__ a_save,
+    float* __restrict__ proj_out, int ld_p, float* __restrict__ x_copy, int ld_xc) {
+  constexpr int kThreads = 2 * kMsgThreads;
+  constexpr int RP = 16 * CT;
+  constexpr int BCH = 3 * RP * 4;                   // 16-byte chunks of one weight slice (3 planes)
+  constexpr int BPT = (2 * BCH + kThreads - 1) / kThreads;
+  constexpr int LDP = RP + 1;
+  constexpr int NA = 16, EMAX = NA * NA;
+  constexpr int kScratch = (NA + 1) + 5 * EMAX;
+  constexpr int kLoopBytes = 2 * 2 * BCH * 16, kTailBytes = kMsgWaves * (16 * LDP + kScratch) * 4;   // [stage][x | h][slice]
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[kLoopBytes > kTailBytes ? kLoopBytes : kTailBytes];
+  u32x4(*sB)[2 * BCH] = reinterpret_cast<u32x4(*)[2 * BCH]>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = wave & 3, half = wave >> 2;                 // half 0: x slices, half 1: h slices
+  const int j = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * kMsgRows + tile * 16;
+  const int row = row0 + j, rowc = min(row, N - 1);
+  const int nsx = H / 32;
+  const float* __restrict__ ar = (half ? h + static_cast<size_t>(rowc) * ld_h : x + static_cast<size_t>(rowc) * ld_x) + 4 * g;
+
+  f32x4 acc[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // weight stage t = tiles of slice t (x half) and of slice nsx + t (h half), copied by all eight wavefronts
+  u32x4 rb[BPT];
+  auto load_b = [&](int t) {
+    t = min(t, nsx - 1);
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+      const int q = min(tid + kThreads * i, 2 * BCH - 1);
+      rb[i] = Wt[static_cast<size_t>(q < BCH ? t : nsx + t) * BCH + (q < BCH ? q : q - BCH)];
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) sB[buf][min(tid + kThreads * i, 2 * BCH - 1)] = rb[i];
+  };
+  float4 a0_lo, a0_hi, a1_lo, a1_hi;      // two slices ahead: four wavefronts per SIMD cover the rest of the latency
+#define UAVGNN_MSG_LOAD_A(LO, HI, S)                              \
+  {                                                               \
+    const float* p_ = ar + 32 * min((S), nsx - 1);                \
+    LO = *reinterpret_cast<const float4*>(p_);                    \
+    HI = *reinterpret_cast<const float4*>(p_ + 16);               \
+  }
+  const int toff = half == 0 ? talk_off[min(row0 + min(lane, 16), N)] : 0;
+  load_b(0);
+  __builtin_amdgcn_sched_barrier(0);
+  UAVGNN_MSG_LOAD_A(a0_lo, a0_hi, 0)
+  UAVGNN_MSG_LOAD_A(a1_lo, a1_hi, 1)
+  __builtin_amdgcn_sched_barrier(0);
+  const int e_lo = __shfl(toff, 0);
+  const int E = __shfl(toff, 16) - e_lo;
+  const bool ok = E <= EMAX && E >= 0;
+  store_b(0);
+  load_b(1);
+  int fsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fsrc[i] = (half == 0 && ok && lane + kWave * i < E) ? talk_src[e_lo + lane + kWave * i] : 0;
+  lds_barrier();
+
+#define UAVGNN_MSG_TERM(FA, PB)                                                                                      \
+  acc[cp] = mfma(FA, as_frag(sb[(PB) * RP * 4 + (cp * 16 + j) * 4 + (g ^ swz(j))]), acc[cp]);                        \
+  acc[cp + 1] = mfma(FA, as_frag(sb[(PB) * RP * 4 + ((cp + 1) * 16 + j) * 4 + (g ^ swz(j))]), acc[cp + 1]);
+#define UAVGNN_MSG_STEP(LO, HI, T)                                                                   \
+  if ((T) < nsx) {                                                                                   \
+    const int t_ = (T);                                                                              \
+    const Planes8 pa = split8(LO, HI);                                                               \
+    if (TRAIN && half == 0 && x_copy != nullptr && row < N) {   /* the x half of [x || c] */        \
+      float* d = x_copy + static_cast<size_t>(row) * ld_xc + 32 * t_ + 4 * g;                        \
+      *reinterpret_cast<float4*>(d) = LO;                                                            \
+      *reinterpret_cast<float4*>(d + 16) = HI;                                                       \
+    }                                                                                                \
+    UAVGNN_MSG_LOAD_A(LO, HI, t_ + 2)                                                                \
+    const bf16x8 fa0 = as_frag(pa.p[0]), fa1 = as_frag(pa.p[1]), fa2 = as_frag(pa.p[2]);            \
+    const u32x4* sb = sB[t_ & 1] + half * BCH;                                                       \
+    _Pragma("unroll") for (int cp = 0; cp < CT; cp += 2) {                                           \
+      UAVGNN_MSG_TERM(fa0, 2) UAVGNN_MSG_TERM(fa2, 0) UAVGNN_MSG_TERM(fa1, 1) UAVGNN_MSG_TERM(fa0, 1) \
+      UAVGNN_MSG_TERM(fa1, 0) UAVGNN_MSG_TERM(fa0, 0)                                                \
+    }                                                                                                \
+    store_b((t_ + 1) & 1);   /* its readers passed the barrier of iteration t - 1 */                 \
+    load_b(t_ + 2);                                                                                  \
+    lds_barrier();                                                                                   \
+  }
+  for (int t = 0; t < nsx; t += 2) {
+    UAVGNN_MSG_STEP(a0_lo, a0_hi, t)
+    UAVGNN_MSG_STEP(a1_lo, a1_hi, t + 1)
+  }
+#undef UAVGNN_MSG_STEP
+#undef UAVGNN_MSG_TERM
+#undef UAVGNN_MSG_LOAD_A
+
+  // ---- the pair's tile in LDS: (x part + bias) by the first wavefront, + h part by the second ------------------------------
+  float* __restrict__ P = reinterpret_cast<float*>(smem_raw) + tile * (16 * LDP + kScratch);
+  const int ncol = M + 2 * K;
+  if (half == 0) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int col = ct * 16 + j;
+      const float b = col < ncol ? bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) P[(4 * g + i) * LDP + col] = acc[ct][i] + b;
+    }
+  }
+  lds_barrier();
+  if (half == 1) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int col = ct * 16 + j;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) P[(4 * g + i) * LDP + col] += acc[ct][i];
+    }
+  }
+  lds_barrier();
+  int* __restrict__ OFF = reinterpret_cast<int*>(P + 16 * LDP);
+  float* __restrict__ SC = reinterpret_cast<float*>(OFF + NA + 1);
+  float* __restrict__ AD = SC + EMAX;
+  int* __restrict__ SRC = reinterpret_cast<int*>(AD + EMAX);
+  int* __restrict__ DST = SRC + EMAX;
+  float* __restrict__ AV = reinterpret_cast<float*>(DST + EMAX);
+  if (half == 1) {
+    // the second wavefront of the pair: proj rows to memory (training) while the first one computes the attention weights - the
+    // value columns are overwritten only behind the next barrier
+    if (TRAIN && proj_out != nullptr) {
+      for (int r = 0; r < 16; ++r) {
+        if (row0 + r >= N) break;
+        float* d = proj_out + static_cast<size_t>(row0 + r) * ld_p;
+        for (int col = lane; col < ncol; col += kWave) d[col] = P[r * LDP + col];
+      }
+    }
+    lds_barrier();
+    return;
+  }
+  // ---- attention over the tile's 16 rows as one graph (the first wavefront of the pair), as in the kernel above ----------------
+  bool poison = !ok;
+  if (ok) {
+    for (int i = lane; i < EMAX; i += kWave) AD[i] = 0.f;
+    if (lane <= 16) OFF[lane] = toff - e_lo;
+    wave_sync_lds();
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = lane + kWave * i;
+      if (e < E) {
+        const int u = fsrc[i] - row0;
+        bad |= (u < 0) | (u >= 16);
+        SRC[e] = u < 0 ? 0 : (u >= 16 ? 15 : u);
+        int d = 0;
+#pragma unroll
+        for (int jj = 1; jj < 16; ++jj) d += e >= OFF[jj];
+        DST[e] = d;
+      }
+    }
+    poison = __any(bad);
+    wave_sync_lds();
+    if (!poison) {
+      for (int e = lane; e < E; e += kWave) {
+        const float* __restrict__ sr = P + SRC[e] * LDP + M;
+        const float* __restrict__ qr = P + DST[e] * LDP + M + K;
+        float a = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) a = fmaf(sr[k], qr[k], a);
+        SC[e] = a * scale;
+      }
+      wave_sync_lds();
+      for (int e = lane; e < E; e += kWave) {
+        const int d = DST[e];
+        const int j0 = OFF[d], j1 = OFF[d + 1];
+        float m = -INFINITY;
+#pragma unroll 2
+        for (int jj = j0; jj < j1; ++jj) m = fmaxf(m, SC[jj]);
+        float den = 0.f;
+#pragma unroll 2
+        for (int jj = j0; jj < j1; ++jj) den += expf(SC[jj] - m);
+        const float a = expf(SC[e] - m) / den;
+        if (TRAIN && a_save != nullptr) a_save[e_lo + e] = a;
+        AV[e] = a;
+      }
+      wave_sync_lds();
+      msg_scatter(AD, NA, AV, SRC, DST, OFF, E, lane);
+      wave_sync_lds();
+    }
+  }
+  lds_barrier();          // the partner has read the value columns (proj): they may be overwritten now
+  if (poison) {           // more in-edges than the dense matrix holds, or an edge from outside the tile: fail loudly
+    for (int i = 0; i < 16; ++i)
+      for (int ch = lane; ch < M; ch += kWave) P[i * LDP + ch] = NAN;
+  } else {
+    for (int c0 = 0; c0 < M; c0 += kWave) {
+      const int ch = c0 + lane, chc = ch < M ? ch : M - 1;
+      float v[NA];
+#pragma unroll
+      for (int t = 0; t < NA; ++t) v[t] = P[t * LDP + chc];
+#pragma unroll 4
+      for (int r = 0; r < NA; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < NA; ++t) a = fmaf(AD[r * NA + t], v[t], a);
+        if (ch < M) P[r * LDP + ch] = a;
+      }
+    }
+  }
+  wave_sync_lds();
+  for (int r = 0; r < 16; ++r) {
+    if (row0 + r >= N) break;
+    float* d = c_out + static_cast<size_t>(row0 + r) * ld_c;
+    for (int ch = lane; ch < M; ch += kWave) d[ch] = P[r * LDP + ch];
+  }
+}
+
 }  // namespace
 }  // namespace uavgnn
 
@@ -415,8 +640,10 @@ extern "C" int uavgnn_tarmac_msg_prepare(const float* Wp, int ld, int H, int M, 
 // planes_out: NULL or uavgnn_tarmac_msg_planes_bytes(N, H, M) bytes.  Every graph has exactly n_ag agents (N % n_ag == 0; 16 %
 // n_ag == 0, so no graph straddles two 16-row tiles); the rows of a tile have at most 256 in-edges, all from rows of the same tile -
 // a violating tile gets NaN messages, never a silent fallback.
-// dbg (timing ablations of tools/msg_probe.py; results are WRONG for dbg != 0): bit 0 no weight-slice traffic after the first two
-// slices, bit 1 no MFMAs, bit 2 no activation loads after the first four slices, bit 3 no workgroup barriers
+// dbg: bits 0-3 are timing ablations of tools/msg_probe.py (results are WRONG when any is set): bit 0 no weight-slice traffic
+// after the first two slices, bit 1 no MFMAs, bit 2 no activation loads after the first four slices, bit 3 no workgroup barriers;
+// bit 4 (16) selects the one-wavefront-per-row-tile kernel where the default is the wavefront-pair kernel (no planes, M + 2K <=
+// 96): correct results, the A/B reference
 extern "C" int uavgnn_tarmac_msg_fwd_dbg(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles,
                                          const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src,
                                          float scale, float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p,
@@ -451,6 +678,22 @@ extern "C" int uavgnn_tarmac_msg_fwd_dbg(const float* x, int ld_x, const float* 
     if (ct <= 4) UAVGNN_MSG_BY_FLAGS(NA_, 4)                             \
     else if (ct <= 6) UAVGNN_MSG_BY_FLAGS(NA_, 6)                        \
     else UAVGNN_MSG_BY_FLAGS(NA_, 8)                                     \
+  }
+  if (!planes && ct <= 6 && !(dbg & 31)) {
+    // two wavefronts per row tile (73 KB of LDS at six column tiles: two workgroups per CU; eight column tiles would be one)
+    const dim3 block2(2 * kMsgThreads);
+#define UAVGNN_MSG_K2(CT_, TR_)                                                                                               \
+  hipLaunchKernelGGL((tarmac_msg_fwd_k2_kernel<CT_, TR_>), grid, block2, 0, st, x, ld_x, h, ld_h, N, H, n_ag, Wt, bias, M, K, \
+                     talk_off, talk_src, scale, c_out, ld_c, a_save, proj_out, ld_p, x_copy, ld_xc)
+    if (ct <= 4) {
+      if (train) UAVGNN_MSG_K2(4, true);
+      else UAVGNN_MSG_K2(4, false);
+    } else {
+      if (train) UAVGNN_MSG_K2(6, true);
+      else UAVGNN_MSG_K2(6, false);
+    }
+#undef UAVGNN_MSG_K2
+    return launch_status();
   }
   UAVGNN_MSG_BY_CT(16)
 #undef UAVGNN_MSG_BY_CT

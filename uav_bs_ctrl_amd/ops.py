@@ -893,6 +893,7 @@ def time_split(x_all, T1):
 
 
 MSG_FUSED = os.environ.get("UAVGNN_MSG_FUSED", "1") != "0"   # K3a + K3b in one launch (csrc/tarmac_msg.hip); A/B switch
+MSG_VARIANT = 16 if os.environ.get("UAVGNN_MSG_PAIR", "1") == "0" else 0   # 16: one wavefront per row tile (A/B reference of the pair kernel)
 
 
 def _tarmac_msg_plan(x, h, Wp, bp, M, K, env, N, H):
@@ -917,9 +918,9 @@ def _tarmac_msg_plan(x, h, Wp, bp, M, K, env, N, H):
 def _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, c_ptr, ld_c, a_save, proj, ld_p, x_copy, ld_xc, planes=None):
     tiles, n_ag = msg
     with KERNEL_TIMER.span("tarmac_msg_fwd", (N, H, M, K, int(proj is not None), int(x_copy is not None))):
-        rc = L.lib().uavgnn_tarmac_msg_fwd(x.data_ptr(), x.stride(0), h.data_ptr(), h.stride(0), N, H, n_ag, tiles.data_ptr(),
-                                           bp.data_ptr(), M, K, L.ptr(talk_off), L.ptr(talk_src), 1.0 / K, c_ptr, ld_c, a_save, proj,
-                                           ld_p, x_copy, ld_xc, L.ptr(planes), L.stream())
+        rc = L.lib().uavgnn_tarmac_msg_fwd_dbg(x.data_ptr(), x.stride(0), h.data_ptr(), h.stride(0), N, H, n_ag, tiles.data_ptr(),
+                                               bp.data_ptr(), M, K, L.ptr(talk_off), L.ptr(talk_src), 1.0 / K, c_ptr, ld_c, a_save, proj,
+                                               ld_p, x_copy, ld_xc, L.ptr(planes), MSG_VARIANT, L.stream())
     L.check(rc, "uavgnn_tarmac_msg_fwd")
 
 
