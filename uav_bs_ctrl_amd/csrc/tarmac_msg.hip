@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kMsgThreads, CT == 8 ? 2 : 3) void tarmac_msg_fwd_k
   constexpr int BPT = (BCH + kMsgThreads - 1) / kMsgThreads;
   constexpr int LDP = RP + 1;                       // odd row stride of the projection tile
   constexpr int NA = 16, EMAX = NA * NA;
-  constexpr int kScratch = (NA + 1) + 5 * EMAX;     // OFF | SC | AD | SRC | DST | AV  (words per wavefront)
+  constexpr int kScratch = (NA + 4) + 5 * EMAX;     // OFF (padded to 20 words: SC .. AV stay 16-byte aligned) | SC | AD | SRC | DST | AV
   // ONE LDS region, two lives: the double-buffered weight slices while the GEMM loop runs, then (behind the loop's last barrier)
   // the projection tiles + the attention scratch of the four wavefronts - 45 KB at M + 2K = 96: three workgroups per CU
   constexpr int kLoopBytes = 2 * BCH * 16, kTailBytes = kMsgWaves * (16 * LDP + kScratch) * 4;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kMsgThreads, CT == 8 ? 2 : 3) void tarmac_msg_fwd_k
     for (int i = 0; i < 4; ++i) P[(4 * g + i) * LDP + col] = acc[ct][i] + b;
   }
   int* __restrict__ OFF = reinterpret_cast<int*>(P + 16 * LDP);
-  float* __restrict__ SC = reinterpret_cast<float*>(OFF + NA + 1);
+  float* __restrict__ SC = reinterpret_cast<float*>(OFF + NA + 4);
   float* __restrict__ AD = SC + EMAX;
   int* __restrict__ SRC = reinterpret_cast<int*>(AD + EMAX);
   int* __restrict__ DST = SRC + EMAX;
@@ -344,7 +344,13 @@ __global__ __launch_bounds__(kMsgThreads, CT == 8 ? 2 : 3) void tarmac_msg_fwd_k
         for (int r = 0; r < NA; ++r) {
           float a = 0.f;
 #pragma unroll
-          for (int t = 0; t < NA; ++t) a = fmaf(AD[r * NA + t], v[t], a);
+          for (int t = 0; t < NA; t += 4) {     // a row of A as four 16-byte broadcast reads
+            const float4 q = *reinterpret_cast<const float4*>(AD + r * NA + t);
+            a = fmaf(q.x, v[t], a);
+            a = fmaf(q.y, v[t + 1], a);
+            a = fmaf(q.z, v[t + 2], a);
+            a = fmaf(q.w, v[t + 3], a);
+          }
           if (ch < M) P[r * LDP + ch] = a;
         }
       }
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(2 * kMsgThreads, 4) void tarmac_msg_fwd_k2_kernel(
   constexpr int BPT = (2 * BCH + kThreads - 1) / kThreads;
   constexpr int LDP = RP + 1;
   constexpr int NA = 16, EMAX = NA * NA;
-  constexpr int kScratch = (NA + 1) + 5 * EMAX;
+  constexpr int kScratch = (NA + 4) + 5 * EMAX;
   constexpr int kLoopBytes = 2 * 2 * BCH * 16, kTailBytes = kMsgWaves * (16 * LDP + kScratch) * 4;   // [stage][x | h][slice]
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[kLoopBytes > kTailBytes ? kLoopBytes : kTailBytes];
   u32x4(*sB)[2 * BCH] = reinterpret_cast<u32x4(*)[2 * BCH]>(smem_raw);
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(2 * kMsgThreads, 4) void tarmac_msg_fwd_k2_kernel(
   }
   lds_barrier();
   int* __restrict__ OFF = reinterpret_cast<int*>(P + 16 * LDP);
-  float* __restrict__ SC = reinterpret_cast<float*>(OFF + NA + 1);
+  float* __restrict__ SC = reinterpret_cast<float*>(OFF + NA + 4);
   float* __restrict__ AD = SC + EMAX;
   int* __restrict__ SRC = reinterpret_cast<int*>(AD + EMAX);
   int* __restrict__ DST = SRC + EMAX;
@@ -582,7 +588,13 @@ __global__ __launch_bounds__(2 * kMsgThreads, 4) void tarmac_msg_fwd_k2_kernel(
       for (int r = 0; r < NA; ++r) {
         float a = 0.f;
 #pragma unroll
-        for (int t = 0; t < NA; ++t) a = fmaf(AD[r * NA + t], v[t], a);
+        for (int t = 0; t < NA; t += 4) {     // a row of A as four 16-byte broadcast reads
+          const float4 q = *reinterpret_cast<const float4*>(AD + r * NA + t);
+          a = fmaf(q.x, v[t], a);
+          a = fmaf(q.y, v[t + 1], a);
+          a = fmaf(q.z, v[t + 2], a);
+          a = fmaf(q.w, v[t + 3], a);
+        }
         if (ch < M) P[r * LDP + ch] = a;
       }
     }
