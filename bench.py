@@ -912,7 +912,7 @@ def main():
             # training forwards); algorithmic bytes / launch time against the HBM peak
             by = sum(Nn * (2 * Hh * 4 + Mm * 4) + tr * Nn * (Mm + 2 * Kk) * 4 + xc * Nn * Hh * 4 for (Nn, Hh, Mm, Kk, tr, xc) in km["work"])
             g = by / (km["total_ms"] * 1e-3) / 1e9
-            sec.append({"kernel": "tarmac_msg_fwd_kernel (K3a + K3b: projection GEMM on the bf16 matrix cores + per-tile attention, one launch)",
+            sec.append({"kernel": "tarmac_msg_fwd_k2_kernel (K3a + K3b, two wavefronts per row tile: projection GEMM on the bf16 matrix cores + per-tile attention, one launch)",
                         "bound": "hbm", "launches": km["count"], "avg_launch_ms": km["avg_ms"], "achieved": g, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": g / HBM_PEAK_GBS, "alg_bytes_per_launch": by / km["count"],
                         "share_of_step": km["total_ms"] / (1e3 * instr_s),
