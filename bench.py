@@ -536,11 +536,12 @@ def k1_env_standalone(learner, g, a, reps=50, rounds=15):
         rels.append((x_src, off, g.relation_order(et), enc.f_conv[et]))
     E_s, E_n, N = rels[0][0].shape[0], rels[1][0].shape[0], x_a.shape[0]
     store = {}
+    from uav_bs_ctrl_amd.graphs import _capture
     graph = th.cuda.CUDAGraph()
     with th.no_grad(), ops.frozen_weights(store):
         ops.hetero_gatv2(x_a, enc._n_heads, rels)           # builds the image + any derived index outside the capture
         th.cuda.synchronize()
-        with th.cuda.graph(graph):
+        with _capture(graph):      # thread-local capture mode when a process group (and its watchdog thread) is alive
             out = None
             for _ in range(reps):
                 del out     # the previous launch's [N, 2H] rows go back to the pool first: every launch writes the SAME 67 MB, as the

@@ -399,6 +399,13 @@ int uavgnn_gru_cell_fwd_planes(const void* planes, int K_in, const float* h, int
 int uavgnn_gru_cell_fwd_planes_opts(const void* planes, int K_in, const float* h, int N, int H, const void* tiles,
                                     const float* b_ih, const float* b_hh, float* h_out, float* pre_save, int opt,
                                     uavgnn_stream_t stream);
+/* The Q head for n_actions <= 16 (csrc/head.hip; reference: nn.Linear(H, n_actions) at algos/madrqn/agents/gnn_agents.py:43-46,:56):
+ * q [N, A] (row stride ld_q) = h [N, H] (row stride ld_h) W [A, H]^T (row stride ld_w) + b [A].  fp32 in / out, exact fp32 products
+ * on the matrix cores (v_mfma_f32_16x16x4_f32), one pass over h.  H in {64, 128, 256}, A <= 16, ld_h % 4 == 0, ld_w % 4 == 0, h and W
+ * 16-byte aligned (UAVGNN_EUNSUPPORTED otherwise). */
+int uavgnn_head_supported(int H, int A);
+int uavgnn_head_fwd(const float* h, int ld_h, int N, int H, const float* W, int ld_w, const float* b, int A, float* q, int ld_q,
+                    uavgnn_stream_t stream);
 /* Dense layers on the bf16 matrix cores (csrc/gemm_x3.hip; reference: the nn.Linear layers of
  * algos/madrqn/agents/gnn_agents.py - f_aggr :101-102, :106, TarMAC projections :227-236 - and the input-gradient GEMMs of
  * loss.backward(), learner.py:157): Y[M, N] = X[M, K] B[N, K]^T (+ bias[N]) (+ Y) (then ReLU), fp32 in / out, each fp32 product

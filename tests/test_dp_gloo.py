@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from oracle import restatement as R
 from tests.gpu_util import synth_graph
+from tests.util import wait_worker
 from uav_bs_ctrl_amd import GnnAgent, HeteroBatch, batch as hb_batch
 
 CFG = dict(enc="gnn", c="tarmac", n_heads=4, key_size=4, msg_size=8, n_rounds=1, dueling=False)
@@ -117,7 +118,7 @@ def test_dp2_gradient_equals_single_process_on_concatenated_batch():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = q.get(timeout=240)
+    res = wait_worker(procs[0], q, timeout=240)
     res = {k: (th.as_tensor(v) if hasattr(v, "shape") else v) for k, v in res.items()}
     for p in procs:
         p.join(60)

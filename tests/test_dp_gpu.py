@@ -16,6 +16,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from tests.gpu_util import synth_graph
+from tests.util import wait_worker
 from uav_bs_ctrl_amd import HeteroBatch, batch as hb_batch
 
 pytestmark = pytest.mark.gpu
@@ -104,7 +105,7 @@ def test_dp2_hip_agent_gradient_and_step_equal_single_process_on_concatenated_ba
     for p in procs:
         p.start()
     try:
-        res = q.get(timeout=480)
+        res = wait_worker(procs[0], q, timeout=480)
     finally:
         for p in procs:
             p.join(60)

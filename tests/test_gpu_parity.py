@@ -8,7 +8,7 @@ import torch as th
 
 from oracle import restatement as R
 from tests.gpu_util import agent_from_params, default_init_params, make_args, synth_graph, to_batch
-from tests.util import assert_close, grad_close, load_golden, load_learner_golden
+from tests.util import assert_close, grad_close, load_golden, load_learner_golden, wait_worker
 
 pytestmark = pytest.mark.gpu
 
@@ -1149,7 +1149,7 @@ def test_rccl_path_at_world_size_one_equals_the_non_distributed_step():
     pr = ctx.Process(target=_nccl_ws1_worker, args=(port, q))
     pr.start()
     try:
-        res = q.get(timeout=900)
+        res = wait_worker(pr, q, timeout=480)
     finally:
         pr.join(timeout=60)
         if pr.is_alive():
@@ -1228,7 +1228,7 @@ def test_graphed_update_is_cut_at_the_rccl_collective_and_equals_eager_updates()
     pr = ctx.Process(target=_nccl_graphed_worker, args=(port, q))
     pr.start()
     try:
-        res = q.get(timeout=900)
+        res = wait_worker(pr, q, timeout=480)
     finally:
         pr.join(timeout=60)
         if pr.is_alive():
@@ -2376,3 +2376,34 @@ def test_gemm_bf16x3_tile_variants_are_bit_identical(M, N, K):
         for f, epi, y in outs:
             if f in group:
                 assert th.equal(y, base[epi]), f"variant {f}, epilogue {epi}: differs from variant {group[0]}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,A", [(1, 64, 1), (17, 128, 9), (4099, 256, 9), (32768, 256, 16), (100, 256, 5)])
+def test_head_kernel_vs_float64(N, H, A):
+    """csrc/head.hip (the Q head, gnn_agents.py:56: nn.Linear(H, n_actions)) against the float64 product: ragged row tiles, every
+    supported width, padded row strides of h and W, the fp32 error bound of a K = H accumulation, untouched neighbours."""
+    from uav_bs_ctrl_amd import _lib as L
+    lib = L.lib()
+    gen = th.Generator().manual_seed(N + H + A)
+    h_full = th.randn(N, H + 4, generator=gen).cuda()
+    W_full = (0.2 * th.randn(A, H + 8, generator=gen)).cuda()
+    h, W = h_full[:, :H], W_full[:, :H]
+    b = th.randn(A, generator=gen).cuda()
+    assert lib.uavgnn_head_supported(H, A) == 1
+    q = th.full((N, A + 3), 7.0, device="cuda")
+    L.check(lib.uavgnn_head_fwd(h.data_ptr(), h.stride(0), N, H, W.data_ptr(), W.stride(0), b.data_ptr(), A, q.data_ptr(), A + 3,
+                                L.stream()), "uavgnn_head_fwd")
+    th.cuda.synchronize()
+    ref = h.double() @ W.double().t() + b.double()
+    scale = h.double().abs() @ W.double().abs().t() + b.double().abs()
+    err = float(((q[:, :A].double() - ref).abs() / scale).max())
+    err_vendor = float(((th.addmm(b, h, W.t()).double() - ref).abs() / scale).max())
+    assert err < 4e-7, (err, err_vendor)
+    assert bool((q[:, A:] == 7.0).all()), "columns past n_actions were written"
+    q2 = th.empty(N, A, device="cuda")
+    L.check(lib.uavgnn_head_fwd(h.data_ptr(), h.stride(0), N, H, W.data_ptr(), W.stride(0), b.data_ptr(), A, q2.data_ptr(), A, L.stream()), "again")
+    assert th.equal(q2, q[:, :A].contiguous()), "not bit-reproducible"
+    assert lib.uavgnn_head_supported(512, 9) == 0 and lib.uavgnn_head_supported(256, 17) == 0
+    assert lib.uavgnn_head_fwd(h.data_ptr() + 4, h.stride(0), N, H, W.data_ptr(), W.stride(0), b.data_ptr(), A, q2.data_ptr(), A,
+                               L.stream()) == L.UAVGNN_EUNSUPPORTED       # a misaligned operand is refused, not mis-read

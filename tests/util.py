@@ -134,3 +134,23 @@ def grad_close(actual, ref64, what, ref32=None, floor=0.0):
     assert ok, (f"{what}: gradient rel err {raw:.3e} (max abs {float(err.max()):.3e}) exceeds max(1e-5 relative, "
                 f"{abs_floor:.3e} absolute = 4x the fp32 CPU oracle's own error {e32})")
     return raw
+
+
+def wait_worker(pr, q, timeout=420.0):
+    """Result of a spawned worker that reports through ``q``: returns as soon as it arrives, and FAILS as soon as the worker is gone
+    without having reported (a worker killed by a native abort would otherwise keep the caller waiting for the whole timeout)."""
+    import queue as _queue
+    import time
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            return q.get(timeout=2.0)
+        except _queue.Empty:
+            pass
+        if not pr.is_alive():
+            try:
+                return q.get(timeout=2.0)            # it may have reported just before it exited
+            except _queue.Empty:
+                raise AssertionError(f"worker exited with code {pr.exitcode} without reporting") from None
+        if time.monotonic() > deadline:
+            raise AssertionError(f"worker did not report within {timeout:.0f} s")

@@ -123,6 +123,8 @@ SIGNATURES = {
     "uavgnn_gemm_tn_x3_chunks": (_c_int, [ctypes.c_longlong, _c_int, _c_int]),
     "uavgnn_gemm_tn_x3": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, ctypes.c_longlong, _c_fp, _c_int, _c_int, _c_st]),
     "uavgnn_gemm_x3_supported": (_c_int, [_c_int, _c_int, _c_int]),
+    "uavgnn_head_supported": (_c_int, [_c_int, _c_int]),
+    "uavgnn_head_fwd": (_c_int, [_c_fp, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_st]),
     "uavgnn_split_bf16x3": (_c_int, [_c_fp, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_st]),
     "uavgnn_gemm_nt_x3": (_c_int, [_c_fp, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_int, _c_fp, _c_fp, _c_int, _c_int, _c_st]),
     "uavgnn_gru_gates_bwd_fused": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_st]),

@@ -18,6 +18,19 @@ from . import _lib as L
 from .graph import from_padded_obs
 
 
+def _capture(graph, **kw):
+    """``torch.cuda.graph`` for this module's captures.  With a process group alive the capture runs in THREAD-LOCAL error mode:
+    ProcessGroupNCCL's watchdog thread polls the events of the collectives issued so far (``hipEventQuery``), and under the default
+    global mode a query that lands inside another thread's capture window is an error - "operation not permitted when stream is
+    capturing" - that terminates the process (seen once in ~8 runs of the world-size-1 RCCL test of ``GraphedUpdate``, whose warm-up
+    updates leave all-reduces for the watchdog to retire).  Thread-local mode restricts the check to the capturing thread, which
+    issues nothing but this library's launches."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        kw.setdefault("capture_error_mode", "thread_local")
+    return th.cuda.graph(graph, **kw)
+
+
 class _PaddedObs:
     """Fixed-address padded observation buffers (the simulator's format, mubs_cov.py:215-242) of ``lead`` env steps."""
 
@@ -61,7 +74,7 @@ class GraphedAct:
             for _ in range(warmup):
                 self._body()
         th.cuda.current_stream().wait_stream(side)
-        with th.cuda.graph(self.graph):
+        with _capture(self.graph):
             self.acts, self.h_out = self._body()
 
     @th.no_grad()
@@ -131,13 +144,14 @@ class GraphedUpdate:
                 self._body()
         th.cuda.current_stream().wait_stream(side)
         if self.split:
+            th.cuda.synchronize()          # the warm-up updates' all-reduces are complete before a capture window opens
             self.graph_tail = th.cuda.CUDAGraph()
-            with th.cuda.graph(self.graph):
+            with _capture(self.graph):
                 self.out = self.learner.accumulate(self._batch())
-            with th.cuda.graph(self.graph_tail, pool=self.graph.pool()):
+            with _capture(self.graph_tail, pool=self.graph.pool()):
                 self.learner.apply()
         else:
-            with th.cuda.graph(self.graph):
+            with _capture(self.graph):
                 self.out = self._body()
         th.cuda.synchronize()
         for dst, src in zip((learner.flat.flat, learner.flat_target, learner.optimizer.m, learner.optimizer.v,
@@ -214,7 +228,7 @@ class GraphedCycle:
         th.cuda.current_stream().wait_stream(side)
         learner.invalidate_weight_cache()
         learner.optimizer.sync_lr()
-        with th.cuda.graph(self.graph):
+        with _capture(self.graph):
             self.out = body()
         th.cuda.synchronize()
         for dst, src in zip(state, snap):

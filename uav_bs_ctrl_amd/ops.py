@@ -924,6 +924,25 @@ def _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, c_ptr, ld_
     L.check(rc, "uavgnn_tarmac_msg_fwd")
 
 
+HEAD_KERNEL = os.environ.get("UAVGNN_HEAD_KERNEL", "1") != "0"   # the Q head on csrc/head.hip (one pass over h'); 0: vendor GEMM
+
+
+def head_fwd(h, W_out, b_out):
+    """q = h W_out^T + b_out (gnn_agents.py:56), no autograd: csrc/head.hip for n_actions <= 16, else the vendor GEMM."""
+    N, H = h.shape
+    A = W_out.shape[0]
+    if (HEAD_KERNEL and h.is_cuda and h.dtype == th.float32 and N > 0 and h.stride(1) == 1 and W_out.stride(1) == 1
+            and h.stride(0) % 4 == 0 and W_out.stride(0) % 4 == 0 and h.data_ptr() % 16 == 0 and W_out.data_ptr() % 16 == 0
+            and b_out.is_contiguous() and L.lib().uavgnn_head_supported(H, A)):
+        q = th.empty((N, A), dtype=th.float32, device=h.device)
+        with KERNEL_TIMER.span("head_fwd", (N, H, A)):
+            rc = L.lib().uavgnn_head_fwd(h.data_ptr(), h.stride(0), N, H, W_out.data_ptr(), W_out.stride(0), b_out.data_ptr(), A,
+                                         q.data_ptr(), A, L.stream())
+        L.check(rc, "uavgnn_head_fwd")
+        return q
+    return th.addmm(b_out, h, W_out.t())
+
+
 class _TarmacStep(th.autograd.Function):
     """q, h' = head(GRU([x || c], h)), c = targeted attention over `talk` of the projections of [x || stopgrad(h)]
     (gnn_agents.py:248-271 with n_rounds = 1, then :56).  Forward: 5 vendor GEMMs + K3b + K4, the projection of the two
@@ -1012,7 +1031,7 @@ class _TarmacStep(th.autograd.Function):
                 L.check(rc, "uavgnn_gru_gates_fwd")
             # (an accepted step that ran unfused wrote h' into a tensor of its own, not into slot t + 1: the next step's h then
             # fails the slot check above and reduces per step, like this one - ctx.seq stays None)
-        q = th.addmm(b_out, h2, W_out.t())
+        q = head_fwd(h2, W_out, b_out)
         if proj is None:
             proj = h2                                              # no-grad call through the fused message launch: placeholder
         ctx.dims = (M, K)
