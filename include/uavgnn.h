@@ -426,6 +426,12 @@ int uavgnn_gemm_x3_supported(int M, int N, int K);
 int uavgnn_split_bf16x3(const float* W, int ld, int R, int C, int transpose, void* planes, uavgnn_stream_t stream);
 int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const void* planes, int N, const float* bias, float* Y, int ldy,
                       int epilogue, uavgnn_stream_t stream);
+/* ... with the contraction over TWO buffers, [X (K1 columns) || X2 (K - K1 columns)], without a concatenated copy (K1 % 32 == 0,
+ * ldx2 % 4 == 0, X2 16-byte aligned; default tiles only - UAVGNN_EUNSUPPORTED with TILE_128 / TILE_64): the GRU backward's
+ * d x = d_gi W_ih[:, :H] + d_proj Wp[:, :H] (learner.py:157 through gnn_agents.py:246,:258-260) as one product over K = 3H + M + 2K;
+ * `planes` = uavgnn_split_bf16x3 of the stacked weight. */
+int uavgnn_gemm_nt_x3_cat(const float* X, int ldx, int K1, const float* X2, int ldx2, int M, int K, const void* planes, int N,
+                          const float* bias, float* Y, int ldy, int epilogue, uavgnn_stream_t stream);
 
 /* Weight gradient of a dense layer on the bf16x3 arithmetic (csrc/gemm_tn_x3.hip): partials[s][Mo, Ko] (+)= dY[rows_s, :Mo]^T
  * X[rows_s, :Ko] for the S contiguous row chunks rows_s of the n_rows rows (chunk = ceil(n_rows / S) rounded up to 32 rows);

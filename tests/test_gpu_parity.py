@@ -2407,3 +2407,38 @@ def test_head_kernel_vs_float64(N, H, A):
     assert lib.uavgnn_head_supported(512, 9) == 0 and lib.uavgnn_head_supported(256, 17) == 0
     assert lib.uavgnn_head_fwd(h.data_ptr() + 4, h.stride(0), N, H, W.data_ptr(), W.stride(0), b.data_ptr(), A, q2.data_ptr(), A,
                                L.stream()) == L.UAVGNN_EUNSUPPORTED       # a misaligned operand is refused, not mis-read
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K1,K2,N", [(16384, 768, 96, 256), (33001, 64, 32, 128), (16384, 32, 768, 384)])
+def test_gemm_bf16x3_two_sources(M, K1, K2, N):
+    """uavgnn_gemm_nt_x3_cat: the contraction over [X || X2] from two buffers (the GRU backward's d x = d_gi W_ih[:, :H] + d_proj
+    Wp[:, :H] as one product) equals the float64 sum of the two products within the fp32 bound, and - bit for bit - the
+    single-source kernel on the concatenated copy; strided operands, ragged rows; refused with the small-tile variants."""
+    from uav_bs_ctrl_amd import _lib as L
+    from uav_bs_ctrl_amd import ops
+    lib = L.lib()
+    gen = th.Generator().manual_seed(M + K1 + K2)
+    a1 = th.randn(M, K1 + 4, generator=gen).cuda()[:, :K1]
+    a2 = th.randn(M, K2 + 8, generator=gen).cuda()[:, :K2]
+    W1 = (0.1 * th.randn(K1, N + 4, generator=gen)).cuda()[:, :N]
+    W2 = (0.1 * th.randn(K2, N, generator=gen)).cuda()
+    assert ops.gemm_x3_cat_supported(a1, a2, N)
+    out = th.full((M, N + 4), 3.0, device="cuda")
+    with ops.frozen_weights():
+        ops.gemm_x3_cat(a1, a2, W1, W2, out[:, :N])
+        again = ops.gemm_x3_cat(a1, a2, W1, W2, th.empty(M, N, device="cuda"))
+    th.cuda.synchronize()
+    ref = a1.double() @ W1.double() + a2.double() @ W2.double()
+    scale = a1.double().abs() @ W1.double().abs() + a2.double().abs() @ W2.double().abs()
+    assert float(((out[:, :N].double() - ref).abs() / scale).max()) < 6e-7
+    assert bool((out[:, N:] == 3.0).all()) and th.equal(again, out[:, :N])
+    one = ops.gemm_x3(th.cat((a1, a2), 1), th.cat((W1, W2), 0), True)
+    assert th.equal(one, again), "two sources and the concatenated copy differ"
+    planes = th.empty(6 * (K1 + K2) * N, dtype=th.uint8, device="cuda")
+    Wc = th.cat((W1, W2), 0)
+    L.check(lib.uavgnn_split_bf16x3(Wc.data_ptr(), N, K1 + K2, N, 1, planes.data_ptr(), L.stream()), "split")
+    y = th.empty(M, N, device="cuda")
+    for flag in (8, 16):
+        assert lib.uavgnn_gemm_nt_x3_cat(a1.data_ptr(), a1.stride(0), K1, a2.data_ptr(), a2.stride(0), M, K1 + K2, planes.data_ptr(), N,
+                                         None, y.data_ptr(), N, flag, L.stream()) == L.UAVGNN_EUNSUPPORTED

@@ -127,6 +127,8 @@ SIGNATURES = {
     "uavgnn_head_fwd": (_c_int, [_c_fp, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_int, _c_st]),
     "uavgnn_split_bf16x3": (_c_int, [_c_fp, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_st]),
     "uavgnn_gemm_nt_x3": (_c_int, [_c_fp, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_int, _c_fp, _c_fp, _c_int, _c_int, _c_st]),
+    "uavgnn_gemm_nt_x3_cat": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_int, _c_fp, _c_fp, _c_int,
+                              _c_int, _c_st]),
     "uavgnn_gru_gates_bwd_fused": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_st]),
     "uavgnn_gru_gates_bwd_fused_head": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp,
                                                  _c_st]),

@@ -159,7 +159,10 @@ template <bool ACC, bool RELU, bool IL>
 __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __restrict__ X, int ldx, int M, int K,
                                                               const unsigned short* __restrict__ Bp, int N,
                                                               const float* __restrict__ bias, float* __restrict__ Y, int ldy,
-                                                              int row_blocks, int col_blocks) {
+                                                              int row_blocks, int col_blocks, const float* __restrict__ X2, int ldx2,
+                                                              int ns1) {
+  // X2 != nullptr: the contraction runs over [X || X2] (two buffers, no concatenated copy): slices 0 .. ns1 - 1 come from X, the
+  // rest from X2 (uavgnn_gemm_nt_x3_cat).  One source: ns1 = K / 32.
   using namespace w8;
   __shared__ u32x4 smem[2 * BUF];   // buffer b: X planes [3][256][4] then B planes [3][128][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,9 +183,12 @@ __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __res
 
   // X loader: float4 q = tid + 512 i (i < 4) -> row tid / 8 + 64 i, k = 4 (tid % 8)
   const int lr = tid >> 3, c4 = tid & 7;
-  unsigned xo[4];
+  unsigned xo[4], xo2[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) xo[i] = static_cast<unsigned>(min(m0 + lr + 64 * i, M - 1)) * ldx + 4 * c4;
+  for (int i = 0; i < 4; ++i) {
+    xo[i] = static_cast<unsigned>(min(m0 + lr + 64 * i, M - 1)) * ldx + 4 * c4;
+    xo2[i] = static_cast<unsigned>(min(m0 + lr + 64 * i, M - 1)) * ldx2 + 4 * c4;
+  }
   const int sa_w = lr * 32 + (((c4 >> 1) ^ swz32(lr)) * 8) + (c4 & 1) * 4;   // bf16 units inside an X plane
   // B loader: chunk q = tid + 512 i (i < 3): plane i, row tid / 4, chunk tid % 4
   unsigned bo[3];
@@ -198,9 +204,11 @@ __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __res
   float4 ra[4];
   u32x4 rw[3];
   auto gload_a = [&](int t) {
-    const unsigned k0 = static_cast<unsigned>(t) * BK;
+    const bool second = t >= ns1;                                  // wave-uniform
+    const float* __restrict__ src = second ? X2 : X;
+    const unsigned k0 = static_cast<unsigned>(second ? t - ns1 : t) * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(X + (xo[i] + k0));
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(src + ((second ? xo2[i] : xo[i]) + k0));
   };
   auto gload_w = [&](int t) {
     const unsigned k0 = static_cast<unsigned>(t) * BK;
@@ -407,13 +415,20 @@ extern "C" int uavgnn_split_bf16x3(const float* W, int ld, int R, int C, int tra
   return launch_status();
 }
 
-extern "C" int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const void* planes, int N, const float* bias,
-                                 float* Y, int ldy, int epilogue, uavgnn_stream_t stream) {
-  if (M < 0 || !X || !planes || !Y || ldx < K || ldy < N) return UAVGNN_EINVAL;
+// K1 = columns taken from X (a multiple of 32), the remaining K - K1 from X2 (nullptr: one source, K1 = K)
+static int gemm_nt_x3_launch(const float* X, int ldx, int K1, const float* X2, int ldx2, int M, int K, const void* planes, int N,
+                             const float* bias, float* Y, int ldy, int epilogue, uavgnn_stream_t stream) {
+  if (M < 0 || !X || !planes || !Y || ldx < K1 || ldy < N || K1 <= 0 || K1 > K || (X2 == nullptr) != (K1 == K) ||
+      (X2 != nullptr && ldx2 < K - K1))
+    return UAVGNN_EINVAL;
   if (M == 0) return 0;
   if (!uavgnn_gemm_x3_supported(M, N, K) || (ldx & 3) || static_cast<long long>(M) * ldx >= (1LL << 31) ||
       ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(planes)) & 15))
     return UAVGNN_EUNSUPPORTED;
+  if (X2 != nullptr && ((K1 % BK) || (ldx2 & 3) || static_cast<long long>(M) * ldx2 >= (1LL << 31) ||
+                        (reinterpret_cast<uintptr_t>(X2) & 15) || (epilogue & (UAVGNN_GEMM_TILE_128 | UAVGNN_GEMM_TILE_64))))
+    return UAVGNN_EUNSUPPORTED;          // two sources: the eight-wave kernel only
+  const int ns1 = K1 / BK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned short* bp = static_cast<const unsigned short*>(planes);
   const bool acc = (epilogue & UAVGNN_GEMM_ACCUMULATE) != 0, relu = (epilogue & UAVGNN_GEMM_RELU) != 0;
@@ -423,7 +438,7 @@ extern "C" int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const vo
     const dim3 grid(((row_blocks + 7) / 8) * 8 * col_blocks), block(w8::NT);
 #define UAVGNN_X3_GEMM(ACC, RELU, IL)                                                                                        \
   hipLaunchKernelGGL((gemm_nt_x3w8_kernel<ACC, RELU, IL>), grid, block, 0, st, X, ldx, M, K, bp, N, bias, Y, ldy, row_blocks, \
-                     col_blocks)
+                     col_blocks, X2, ldx2, ns1)
 #define UAVGNN_X3_GEMM_IL(IL)                         \
   if (acc && relu) UAVGNN_X3_GEMM(true, true, IL);    \
   else if (acc) UAVGNN_X3_GEMM(true, false, IL);      \
@@ -451,4 +466,18 @@ extern "C" int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const vo
 #undef UAVGNN_X3_GEMM_BM
 #undef UAVGNN_X3_GEMM
   return launch_status();
+}
+
+extern "C" int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const void* planes, int N, const float* bias,
+                                 float* Y, int ldy, int epilogue, uavgnn_stream_t stream) {
+  if (ldx < K) return UAVGNN_EINVAL;
+  return gemm_nt_x3_launch(X, ldx, K, nullptr, 0, M, K, planes, N, bias, Y, ldy, epilogue, stream);
+}
+
+// Y = [X (K1 columns) || X2 (K - K1 columns)] B^T ...: the contraction over two buffers without a concatenated copy (the GRU
+// backward's d x = d_gi W_ih[:, :H] + d_proj Wp[:, :H] as ONE product; planes = the split of the stacked weight [K, N]^T)
+extern "C" int uavgnn_gemm_nt_x3_cat(const float* X, int ldx, int K1, const float* X2, int ldx2, int M, int K, const void* planes,
+                                     int N, const float* bias, float* Y, int ldy, int epilogue, uavgnn_stream_t stream) {
+  if (!X2) return UAVGNN_EINVAL;
+  return gemm_nt_x3_launch(X, ldx, K1, X2, ldx2, M, K, planes, N, bias, Y, ldy, epilogue, stream);
 }

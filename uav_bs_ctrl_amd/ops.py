@@ -601,6 +601,39 @@ def _mm_nn(dy, W, out=None, accumulate=False):
     return out.addmm_(dy, W) if accumulate else th.mm(dy, W, out=out)
 
 
+DX_CAT = os.environ.get("UAVGNN_DX_CAT", "1") != "0"   # d x of the TarMAC step as ONE product over [d_gi || d_proj] (A/B switch)
+
+
+def gemm_x3_cat_supported(a1, a2, n_out) -> bool:
+    K1, K2 = a1.shape[1], a2.shape[1]
+    return bool(DX_CAT and a2.is_cuda and a2.dtype == th.float32 and a2.dim() == 2 and a2.shape[0] == a1.shape[0] and K1 % 32 == 0
+                and K2 % 32 == 0 and a2.stride(1) == 1 and a2.stride(0) % 4 == 0 and a2.data_ptr() % 16 == 0
+                and a2.shape[0] * a2.stride(0) < 2 ** 31 and gemm_x3_supported(a1, n_out, K1 + K2)
+                and ((a1.shape[0] + 255) // 256) * ((n_out + 127) // 128) >= GEMM_X3_SMALL_GRID and not (GEMM_X3_FLAGS & 8))
+
+
+def gemm_x3_cat(a1, a2, W1, W2, out):
+    """out = a1 @ W1 + a2 @ W2 (W1 [K1, n_out], W2 [K2, n_out], unit inner strides) as ONE bf16x3 product over the contraction
+    [a1 || a2] (csrc/gemm_x3.hip, two-source loader; the stacked weight is split once per weight version inside a
+    frozen_weights() scope).  Caller checks gemm_x3_cat_supported()."""
+    lib = L.lib()
+    M, K1 = a1.shape
+    K2, n_out = a2.shape[1], W1.shape[1]
+    K = K1 + K2
+    assert W1.shape[0] == K1 and W2.shape == (K2, n_out) and W1.stride(1) == 1 and W2.stride(1) == 1
+
+    def build(p):
+        Wc = th.cat((W1, W2), 0)                                  # [K, n_out], contiguous
+        L.check(lib.uavgnn_split_bf16x3(Wc.data_ptr(), n_out, K, n_out, 1, p.data_ptr(), L.stream()), "uavgnn_split_bf16x3")
+    with KERNEL_TIMER.span("gemm_x3", (M, n_out, K)):
+        planes = _cached_planes(("matcat", W1.data_ptr(), W1._version, W1.stride(0), W2.data_ptr(), W2._version, W2.stride(0), K1, K2,
+                                 n_out), 6 * K * n_out, a1.device, build, keep=(W1, W2))
+        rc = lib.uavgnn_gemm_nt_x3_cat(a1.data_ptr(), a1.stride(0), K1, a2.data_ptr(), a2.stride(0), M, K, planes.data_ptr(), n_out,
+                                       None, out.data_ptr(), out.stride(0), GEMM_X3_FLAGS & 4, L.stream())
+    L.check(rc, "uavgnn_gemm_nt_x3_cat")
+    return out
+
+
 GEMM_TN_X3 = os.environ.get("UAVGNN_GEMM_TN_X3", "1") != "0"   # weight gradients on the bf16 matrix cores (csrc/gemm_tn_x3.hip)
 # Measured against the vendor's batched split-K fp32 GEMM (tools/gemm_tn_probe.py, profiles/r03_gemm_tn_probe.txt): BOTH operands
 # have to be split and transposed inside the kernel, which bounds it at 95-108 TFLOP/s fp32-equivalent = the vendor's 106-108
@@ -1091,9 +1124,16 @@ class _TarmacStep(th.autograd.Function):
         # 64 x 32-tile solution (134 us) for the matrix-core kernel (A/B: UAVGNN_DINP_SPLIT=0)
         split_dinp = (DINP_SPLIT and M > 0 and W_ih.stride(1) == 1 and gemm_x3_supported(d_gi, H, W_ih.shape[0])
                       and (ctx.dx_out is None or (ctx.dx_out.stride(1) == 1 and ctx.dx_out.dtype == th.float32)))
+        ld = M + 2 * K
+        d_proj = th.empty((N, ld), dtype=th.float32, device=x.device) if seq is None else seq.slot("d_proj", ctx.seq_t, ld)
+        dx_cat = False
         if split_dinp:
             dx = ctx.dx_out if ctx.dx_out is not None else th.empty((N, H), dtype=th.float32, device=x.device)
-            _mm_nn(d_gi, W_ih[:, :H], out=dx)
+            # d x = d_gi W_ih[:, :H] + d_proj Wp[:, :H]: ONE product over [d_gi || d_proj] once d_proj exists (behind the attention
+            # backward) instead of a product + an accumulating vendor GEMM that re-reads and re-writes d x (31 us per step)
+            dx_cat = Wp.stride(1) == 1 and gemm_x3_cat_supported(d_gi, d_proj, H)
+            if not dx_cat:
+                _mm_nn(d_gi, W_ih[:, :H], out=dx)
             d_c = th.mm(d_gi, W_ih[:, H:])                                 # [N, M]
             d_c_ptr, d_c_ld = d_c.data_ptr(), M
         else:
@@ -1103,13 +1143,13 @@ class _TarmacStep(th.autograd.Function):
         if sink is not None:
             sink.owned.clear()
             sink.owned[dh.data_ptr()] = dh
-        ld = M + 2 * K
-        d_proj = th.empty((N, ld), dtype=th.float32, device=x.device) if seq is None else seq.slot("d_proj", ctx.seq_t, ld)
         _launch_talk_bwd(ctx.env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld,
                          K, M, talk_off, talk_src, (t_off, t_dst, t_pos), N, 1.0 / K, a_save, d_c_ptr,
                          d_c_ld, d_proj.data_ptr() + 4 * M, ld, d_proj.data_ptr() + 4 * (M + K), ld, d_proj.data_ptr(),
                          ld)
-        if split_dinp:
+        if dx_cat:
+            gemm_x3_cat(d_gi, d_proj, W_ih[:, :H], Wp[:, :H], dx)
+        elif split_dinp:
             dx.addmm_(d_proj, Wp[:, :H])                                   # h enters the projections stop-gradded
         else:
             dx = ctx.dx_out                                                # slice of the time-split gradient buffer
