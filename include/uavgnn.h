@@ -451,6 +451,15 @@ int uavgnn_gru_gates_bwd_fused(const float* pre, const float* h, const float* d_
 int uavgnn_gru_gates_bwd_fused_head(const float* pre, const float* h, const float* d_hout, const float* dq, int n_out,
                                     const float* W_out, int N, int H, float* d_gi, float* d_gh, float* d_h,
                                     uavgnn_stream_t stream);
+/* ... which also writes the launch's share of the cell's BIAS gradients: col_sums [uavgnn_gru_gates_bwd_sum_rows(N, H)][4 H] (16-byte
+ * aligned) holds per-workgroup column sums d_r | d_z | d_n (input side) | d_n (hidden side); db_ih = the sum over its rows of columns
+ * [0 : 3H], db_hh = of columns [0 : 2H] and [3H : 4H] (fixed summation order: deterministic).  dq / W_out may both be NULL (no head
+ * term; d_hout is then required).  Replaces autograd's db = sum over rows of d_gi / d_gh (nn.GRUCell under learner.py:157), i.e. a
+ * second pass over the [N, 3H] gate gradients.  uavgnn_gru_gates_bwd_sum_rows returns 0 when H / 4 does not divide 256. */
+int uavgnn_gru_gates_bwd_sum_rows(int N, int H);
+int uavgnn_gru_gates_bwd_fused_sums(const float* pre, const float* h, const float* d_hout, const float* dq, int n_out,
+                                    const float* W_out, int N, int H, float* d_gi, float* d_gh, float* d_h, float* col_sums,
+                                    uavgnn_stream_t stream);
 
 /* Backward of the fused GRU cell as ONE call (csrc/gru_bwd.hip; reference: autograd of nn.GRUCell at gnn_agents.py:246,:270
  * under learner.py:157): gate gradients from the pre-activation sets saved by the forward (pre [N, 4H]), d_inp [N, K_in]

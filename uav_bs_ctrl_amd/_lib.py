@@ -132,6 +132,9 @@ SIGNATURES = {
     "uavgnn_gru_gates_bwd_fused": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_st]),
     "uavgnn_gru_gates_bwd_fused_head": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp,
                                                  _c_st]),
+    "uavgnn_gru_gates_bwd_sum_rows": (_c_int, [_c_int, _c_int]),
+    "uavgnn_gru_gates_bwd_fused_sums": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp,
+                                                 _c_st]),
     "uavgnn_gru_gates_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_st]),
     "uavgnn_gru_gates_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_st]),
 }

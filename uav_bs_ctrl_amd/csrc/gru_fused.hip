@@ -175,13 +175,22 @@ __global__ __launch_bounds__(256, 2) void gru_cell_fwd_kernel(
 // pointwise backward from the saved pre-activation sets: d_gi [N,3H], d_gh [N,3H], d_h [N,H] (layout of gru.hip's kernel)
 // HEAD: the gradient of h' is d_hout (or 0) + dq W_out, the head's input gradient formed on the fly (n_out <= 16 FMAs per element
 // against rows of W_out that stay in L1): the [N, H] sum never goes through HBM and the rank-n_out GEMM launch disappears.
+// col_sums (optional, H / 4 divides 256): [gridDim.x][4 H] column sums of this block's elements - d_r | d_z | d_n (input side) | d_n
+// (hidden side), i.e. the block's share of the bias gradients db_ih = [0 : 3H], db_hh = [0 : 2H] + [3H : 4H] - so that the [T N, 3H]
+// gate gradients of a BPTT sequence are not read again just to be summed (two streaming passes over 6.8 GB per C3 update).  A thread
+// keeps its four columns over the grid-stride loop (the stride is a multiple of H / 4 elements), the 256 / (H / 4) threads of a
+// block that share them are added in a fixed order through LDS: deterministic.
 template <bool HEAD>
 __global__ __launch_bounds__(256) void gru_gates_bwd_fused_kernel(const float* __restrict__ pre, const float* __restrict__ h,
                                                                   const float* __restrict__ d_hout, long long total, int H,
                                                                   float* __restrict__ d_gi, float* __restrict__ d_gh,
                                                                   float* __restrict__ d_h, const float* __restrict__ dq,
-                                                                  int n_out, const float* __restrict__ W_out) {
+                                                                  int n_out, const float* __restrict__ W_out,
+                                                                  float* __restrict__ col_sums) {
   const int HV = H / 4;
+  float cs[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) cs[t] = 0.f;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
     const long long row = i / HV;
     const int col = static_cast<int>(i - row * HV) * 4;
@@ -215,6 +224,10 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_fused_kernel(const float* _
       dr[t] = dn_pre * a_gh[t] * r * (1.f - r);
       dz[t] = a_d[t] * (a_h[t] - n) * z * (1.f - z);
       dh[t] = a_d[t] * z;
+      cs[t] += dr[t];
+      cs[4 + t] += dz[t];
+      cs[8 + t] += dni[t];
+      cs[12 + t] += dnh[t];
     }
     float* gi = d_gi + row * 3 * H + col;
     float* gh = d_gh + row * 3 * H + col;
@@ -225,6 +238,26 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_fused_kernel(const float* _
     *reinterpret_cast<float4*>(gh + H) = make_float4(dz[0], dz[1], dz[2], dz[3]);
     *reinterpret_cast<float4*>(gh + 2 * H) = make_float4(dnh[0], dnh[1], dnh[2], dnh[3]);
     *reinterpret_cast<float4*>(d_h + row * H + col) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+  }
+  if (col_sums != nullptr) {      // uniform: same pointer for every thread
+    __shared__ float sS[256 * 17];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sS[threadIdx.x * 17 + t] = cs[t];
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < HV) {
+      float* out = col_sums + static_cast<size_t>(blockIdx.x) * 4 * H + 4 * threadIdx.x;
+#pragma unroll
+      for (int gate = 0; gate < 4; ++gate) {
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float a = 0.f;
+          for (int part = threadIdx.x; part < 256; part += HV) a += sS[part * 17 + 4 * gate + t];
+          v[t] = a;
+        }
+        *reinterpret_cast<float4*>(out + gate * H) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
   }
 }
 
@@ -264,7 +297,7 @@ extern "C" int uavgnn_gru_gates_bwd_fused(const float* pre, const float* h, cons
   if (N == 0) return 0;
   const long long total = static_cast<long long>(N) * (H / 4);
   hipLaunchKernelGGL(gru_gates_bwd_fused_kernel<false>, dim3(capped_grid(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     pre, h, d_hout, total, H, d_gi, d_gh, d_h, nullptr, 0, nullptr);
+                     pre, h, d_hout, total, H, d_gi, d_gh, d_h, nullptr, 0, nullptr, nullptr);
   return launch_status();
 }
 
@@ -276,6 +309,34 @@ extern "C" int uavgnn_gru_gates_bwd_fused_head(const float* pre, const float* h,
   if (N == 0) return 0;
   const long long total = static_cast<long long>(N) * (H / 4);
   hipLaunchKernelGGL(gru_gates_bwd_fused_kernel<true>, dim3(capped_grid(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     pre, h, d_hout, total, H, d_gi, d_gh, d_h, dq, n_out, W_out);
+                     pre, h, d_hout, total, H, d_gi, d_gh, d_h, dq, n_out, W_out, nullptr);
+  return launch_status();
+}
+
+// rows of the `col_sums` matrix uavgnn_gru_gates_bwd_fused_sums writes for N rows (0: this H has no column-sum variant)
+extern "C" int uavgnn_gru_gates_bwd_sum_rows(int N, int H) {
+  if (N <= 0 || H <= 0 || (H % 4) || (256 % (H / 4))) return 0;
+  return capped_grid(static_cast<long long>(N) * (H / 4), 256);
+}
+
+// ... the same launch (dq / W_out may be NULL: no head term) that ALSO writes col_sums [uavgnn_gru_gates_bwd_sum_rows(N, H)][4 H]:
+// per-block column sums d_r | d_z | d_n (input side) | d_n (hidden side) - the bias gradients of the cell are their sum over rows
+extern "C" int uavgnn_gru_gates_bwd_fused_sums(const float* pre, const float* h, const float* d_hout, const float* dq, int n_out,
+                                               const float* W_out, int N, int H, float* d_gi, float* d_gh, float* d_h,
+                                               float* col_sums, uavgnn_stream_t stream) {
+  if (N < 0 || H <= 0 || !pre || !h || !d_gi || !d_gh || !d_h || !col_sums || (dq == nullptr) != (W_out == nullptr) ||
+      (dq == nullptr && d_hout == nullptr) || (dq != nullptr && n_out <= 0))
+    return UAVGNN_EINVAL;
+  if (N == 0) return 0;
+  if (!uavgnn_gru_gates_bwd_sum_rows(N, H) || n_out > 64 || ((reinterpret_cast<uintptr_t>(W_out) | reinterpret_cast<uintptr_t>(col_sums)) & 15))
+    return UAVGNN_EUNSUPPORTED;
+  const long long total = static_cast<long long>(N) * (H / 4);
+  const dim3 grid(capped_grid(total, 256)), block(256);
+  if (dq != nullptr)
+    hipLaunchKernelGGL(gru_gates_bwd_fused_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), pre, h, d_hout, total, H, d_gi,
+                       d_gh, d_h, dq, n_out, W_out, col_sums);
+  else
+    hipLaunchKernelGGL(gru_gates_bwd_fused_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), pre, h, d_hout, total, H, d_gi,
+                       d_gh, d_h, nullptr, 0, nullptr, col_sums);
   return launch_status();
 }

@@ -175,7 +175,14 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_planes_kernel(const u32x4* __
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     } else {
-      __syncthreads();
+      // EXPLICIT wait for this wavefront's LDS-DMA before the barrier.  __syncthreads() does not promise it: the compiler's fence
+      // covers LDS reads / writes and global stores, while a global_load_lds is waited for only where the compiler happens to order
+      // a later ds_read behind it.  With the DMA issued behind the barrier (bit 3) it emitted NO vmcnt wait in the whole loop and a
+      // fragment read met a 1-KB piece that had not landed about once in a thousand launches (tools/cell_race.py: one 32 x 16
+      // patch of h' off by 3e-7).
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
   };
   // iteration t: DMA of the next slice(s) into the free buffers (their readers passed the barrier of iteration t - 1), fragment

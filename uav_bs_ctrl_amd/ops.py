@@ -442,9 +442,11 @@ DINP_SPLIT = os.environ.get("UAVGNN_DINP_SPLIT", "1") != "0"   # _TarmacStep.bac
 HEAD_FUSED_BWD = os.environ.get("UAVGNN_HEAD_FUSED_BWD", "1") != "0"
 
 
-def _gru_gates_bwd_from_pre(pre, h, d_hout, d_gi=None, d_gh=None, head=None):
+def _gru_gates_bwd_from_pre(pre, h, d_hout, d_gi=None, d_gh=None, head=None, sums=None):
     """Gate gradients from the saved pre-activation sets.  ``head`` = (dq [N, n_out], W_out [n_out, H]): the gradient of h' is
-    d_hout (None = 0) + dq W_out, formed inside the kernel (uavgnn_gru_gates_bwd_fused_head)."""
+    d_hout (None = 0) + dq W_out, formed inside the kernel (uavgnn_gru_gates_bwd_fused_head).  ``sums``: a
+    [uavgnn_gru_gates_bwd_sum_rows(N, H), 4H] buffer that receives the launch's per-workgroup column sums (the bias gradients'
+    share of this step)."""
     N, H = h.shape
     if d_gi is None:
         d_gi = th.empty((N, 3 * H), dtype=th.float32, device=h.device)
@@ -452,7 +454,12 @@ def _gru_gates_bwd_from_pre(pre, h, d_hout, d_gi=None, d_gh=None, head=None):
         d_gh = th.empty_like(d_gi)
     dh = th.empty_like(h)
     with KERNEL_TIMER.span("gru_gates_bwd"):
-        if head is not None:
+        if sums is not None:
+            dq, W_out = head if head is not None else (None, None)
+            rc = L.lib().uavgnn_gru_gates_bwd_fused_sums(pre.data_ptr(), h.data_ptr(), L.ptr(d_hout), L.ptr(dq),
+                                                         0 if dq is None else dq.shape[1], L.ptr(W_out), N, H, d_gi.data_ptr(),
+                                                         d_gh.data_ptr(), dh.data_ptr(), sums.data_ptr(), L.stream())
+        elif head is not None:
             dq, W_out = head
             rc = L.lib().uavgnn_gru_gates_bwd_fused_head(pre.data_ptr(), h.data_ptr(), L.ptr(d_hout), dq.data_ptr(), dq.shape[1],
                                                          W_out.data_ptr(), N, H, d_gi.data_ptr(), d_gh.data_ptr(), dh.data_ptr(),
@@ -601,6 +608,7 @@ def _mm_nn(dy, W, out=None, accumulate=False):
     return out.addmm_(dy, W) if accumulate else th.mm(dy, W, out=out)
 
 
+GATE_SUMS = os.environ.get("UAVGNN_GATE_SUMS", "1") != "0"   # bias gradients of the cell from the gate kernel's column sums (A/B switch)
 DX_CAT = os.environ.get("UAVGNN_DX_CAT", "1") != "0"   # d x of the TarMAC step as ONE product over [d_gi || d_proj] (A/B switch)
 
 
@@ -828,9 +836,16 @@ class WeightGradSink:
             self.weight(("Wp_h", ids["Wp"]), d_proj, h, lambda g: split("Wp", g, H), tn)
             self.bias(("bp", ids["Wp"]), d_proj, lambda g: split("bp", g, 0))
             self.weight(("W_ih", ids["W_ih"]), d_gi, inp, lambda g: split("W_ih", g, 0), tn)
-            self.bias(("b_ih", ids["W_ih"]), d_gi, lambda g: split("b_ih", g, 0))
             self.weight(("W_hh", ids["W_hh"]), d_gh, h, lambda g: split("W_hh", g, 0), tn)
-            self.bias(("b_hh_n", ids["W_hh"]), d_gh[:, 2 * H:], lambda g: split("b_hh", g, 2 * H))
+            if all(t in seq.gsum_steps for t in range(t0, t1)):
+                # the gate kernels of these steps left per-workgroup column sums d_r | d_z | d_n (input) | d_n (hidden): [., 4H]
+                gs = seq.bufs["gsum"][t0:t1]
+                gs = gs.reshape(gs.shape[0] * gs.shape[1], 4 * H)
+                self.bias(("b_ih", ids["W_ih"]), gs[:, :3 * H], lambda g: split("b_ih", g, 0))
+                self.bias(("b_hh_n", ids["W_hh"]), gs[:, 3 * H:], lambda g: split("b_hh", g, 2 * H))
+            else:
+                self.bias(("b_ih", ids["W_ih"]), d_gi, lambda g: split("b_ih", g, 0))
+                self.bias(("b_hh_n", ids["W_hh"]), d_gh[:, 2 * H:], lambda g: split("b_hh", g, 2 * H))
             self.weight(("W_out", ids["W_out"]), dq, h2, lambda g: split("W_out", g, 0), tn)
             self.bias(("b_out", ids["W_out"]), dq, lambda g: split("b_out", g, 0))
 
@@ -852,13 +867,15 @@ class _SequenceStage:
         self.bufs = bufs if bufs is not None else {}
         self.t_fwd = 0
         self.bwd_steps = []
+        self.gsum_steps = set()          # steps whose gate kernel wrote its column-sum partials ("gsum" slots)
         self.split = self.ids = self.H = None
 
-    def slot(self, name, t, cols, extra=0):
-        """[N, cols] slot t of the [T1 + extra, N, cols] buffer `name`."""
+    def slot(self, name, t, cols, extra=0, rows=None):
+        """[N, cols] slot t of the [T1 + extra, N, cols] buffer `name` (``rows``: another row count than N per step)."""
+        n = self.N if rows is None else rows
         b = self.bufs.get(name)
-        if b is None or b.shape != (self.T1 + extra, self.N, cols) or b.device != self.x_all.device:
-            b = self.bufs[name] = th.empty((self.T1 + extra, self.N, cols), dtype=th.float32, device=self.x_all.device)
+        if b is None or b.shape != (self.T1 + extra, n, cols) or b.device != self.x_all.device:
+            b = self.bufs[name] = th.empty((self.T1 + extra, n, cols), dtype=th.float32, device=self.x_all.device)
         return b[t]
 
 
@@ -1108,8 +1125,15 @@ class _TarmacStep(th.autograd.Function):
         seq = ctx.seq if (sink is not None and ctx.seq is not None and sink.seq is ctx.seq) else None
         if seq is not None:      # staged sequence: the gate gradients go straight into the time-batched buffers
             t = ctx.seq_t
+            G = L.lib().uavgnn_gru_gates_bwd_sum_rows(N, H) if GATE_SUMS else 0
+            sums = None
+            if G and (head is not None or dh2_tot is not None):
+                # the step's share of db_ih / db_hh comes out of the gate kernel: end_sequence() sums [T1 G, 4H] partials instead of
+                # streaming the [T1 N, 3H] gate gradients twice more
+                sums = seq.slot("gsum", t, 4 * H, rows=G)
+                seq.gsum_steps.add(t)
             d_gi, d_gh, dh = _gru_gates_bwd_from_pre(gi, h, dh2_tot, seq.slot("d_gi", t, 3 * H), seq.slot("d_gh", t, 3 * H),
-                                                     head=head)
+                                                     head=head, sums=sums)
         elif ctx.fused_gru:
             d_gi, d_gh, dh = _gru_gates_bwd_from_pre(gi, h, dh2_tot, head=head)      # gi holds the saved pre-activation sets
         else:
