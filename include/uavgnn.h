@@ -229,6 +229,12 @@ int uavgnn_eps_greedy_dev(const float* q, int ld_q, int N, int A, int n_agents, 
  * across the BPTT steps in the caller's acc[S, C]; the caller folds the S partials once per update.  Deterministic.
  */
 int uavgnn_colsum_acc(const float* x, long long ld, int N, int C, float* acc, int S, uavgnn_stream_t stream);
+/* The ReLU backward fused with the bias gradient of the Linear in front of it (reference: f_aggr = Sequential(Linear, ReLU),
+ * gnn_agents.py:99-102, under learner.py:157): out [N, C] = dy where y > 0 else 0, acc[S, C] += row-blocked column sums of out
+ * (as uavgnn_colsum_acc).  One pass over the gradient instead of autograd's threshold_backward + sum.  C % 4 == 0, strides % 4 == 0,
+ * 16-byte aligned operands; `out` may alias `dy`. */
+int uavgnn_relu_bwd_colsum(const float* dy, long long ld, const float* y, long long ldy, float* out, long long ldo, int N, int C,
+                           float* acc, int S, uavgnn_stream_t stream);
 
 /* ---- K3b, per-graph formulation ---------------------------------------------------------------------------------
  * Same contract and arithmetic as uavgnn_talk_attn_fwd / _bwd for a batch of B SMALL graphs (what dgl.batch of

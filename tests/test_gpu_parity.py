@@ -2442,3 +2442,46 @@ def test_gemm_bf16x3_two_sources(M, K1, K2, N):
     for flag in (8, 16):
         assert lib.uavgnn_gemm_nt_x3_cat(a1.data_ptr(), a1.stride(0), K1, a2.data_ptr(), a2.stride(0), M, K1 + K2, planes.data_ptr(), N,
                                          None, y.data_ptr(), N, flag, L.stream()) == L.UAVGNN_EUNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,C", [(4096, 256), (5003, 64), (300000, 256), (7, 4)])
+def test_relu_backward_fused_with_the_bias_gradient(n, C):
+    """csrc/colsum.hip uavgnn_relu_bwd_colsum: out = dy where y > 0 else 0 and its row-blocked column sums in one pass, against
+    torch's threshold_backward + float64 column sums; strided operands, ragged row blocks, in place; and ops._LinearReLU's backward
+    with the fused pass equals the unfused one."""
+    from uav_bs_ctrl_amd import _lib as L
+    from uav_bs_ctrl_amd import ops
+    lib = L.lib()
+    gen = th.Generator().manual_seed(n + C)
+    dy = th.randn(n, C + 4, generator=gen).cuda()[:, :C]
+    y = th.relu(th.randn(n, C + 8, generator=gen)).cuda()[:, :C]
+    S = ops._row_blocks(n)
+    out = th.full((n, C + 4), 9.0, device="cuda")
+    acc = th.ones(S, C, device="cuda")
+    L.check(lib.uavgnn_relu_bwd_colsum(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), out.data_ptr(), C + 4, n, C, acc.data_ptr(), S,
+                                       L.stream()), "uavgnn_relu_bwd_colsum")
+    ref = th.ops.aten.threshold_backward(dy.contiguous(), y.contiguous(), 0.0)
+    assert th.equal(out[:, :C], ref) and bool((out[:, C:] == 9.0).all())
+    want = ref.double().sum(0) + S
+    got = acc.double().sum(0)
+    assert float((got - want).abs().max()) <= 1e-5 * float(ref.double().abs().sum(0).max() + 1.0)
+    inplace = dy.contiguous().clone()
+    acc2 = th.zeros(S, C, device="cuda")
+    L.check(lib.uavgnn_relu_bwd_colsum(inplace.data_ptr(), C, y.data_ptr(), y.stride(0), inplace.data_ptr(), C, n, C, acc2.data_ptr(), S,
+                                       L.stream()), "in place")
+    assert th.equal(inplace, ref)
+    if C >= 64 and n >= 4096:
+        x = th.randn(n, 32, generator=gen).cuda().requires_grad_()
+        W = (0.2 * th.randn(C, 32, generator=gen)).cuda().requires_grad_()
+        b = th.randn(C, generator=gen).cuda().requires_grad_()
+        g = th.randn(n, C, generator=gen).cuda()
+        grads = {}
+        for fused in (True, False):
+            ops.RELU_BWD_FUSED = fused
+            try:
+                grads[fused] = th.autograd.grad(ops.linear_relu(x, W, b), (x, W, b), g)
+            finally:
+                ops.RELU_BWD_FUSED = True
+        assert th.equal(grads[True][0], grads[False][0]) and th.equal(grads[True][1], grads[False][1])
+        assert_close(grads[True][2], grads[False][2], 1e-5, "db", floor=1e-4)

@@ -95,6 +95,8 @@ SIGNATURES = {
     "uavgnn_eps_greedy": (_c_int, [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_f32, ctypes.c_void_p, _c_st]),
     "uavgnn_eps_greedy_dev": (_c_int, [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp, ctypes.c_void_p, _c_st]),
     "uavgnn_colsum_acc": (_c_int, [_c_fp, ctypes.c_longlong, _c_int, _c_int, _c_fp, _c_int, _c_st]),
+    "uavgnn_relu_bwd_colsum": (_c_int, [_c_fp, ctypes.c_longlong, _c_fp, ctypes.c_longlong, _c_fp, ctypes.c_longlong, _c_int, _c_int, _c_fp,
+                               _c_int, _c_st]),
     "uavgnn_env_state_dim": (_c_int, [_c_int, _c_int, _c_int]),
     "uavgnn_env_step": (_c_int, [ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double), _c_int] + [_c_fp] * 22 + [_c_st]),
     "uavgnn_adamw_polyak": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, ctypes.c_longlong, _c_fp, ctypes.c_double,

@@ -16,9 +16,14 @@ constexpr int kWaves = kThreads / kWave;
 
 // C >= 64 (or strided narrow matrices).  grid (S, column tiles of 64 * V); wave w of the block takes rows
 // lo + w, lo + w + 4, ...; a lane owns V consecutive columns.
-template <int V>
+// MASK (V = 4 only): x is the gradient of y = relu(.) - the summed value is x where y > 0 and 0 elsewhere, and that masked
+// gradient is also written to `out` (the ReLU backward of gnn_agents.py:99-102 and the bias gradient of the Linear in front of it in
+// ONE pass over the [N, C] gradient instead of an elementwise pass followed by a reduction pass).
+template <int V, bool MASK = false>
 __global__ __launch_bounds__(kThreads) void colsum_wide_kernel(const float* __restrict__ x, long long ld, int N, int C,
-                                                               int rows_per_block, float* __restrict__ acc) {
+                                                               int rows_per_block, float* __restrict__ acc,
+                                                               const float* __restrict__ y = nullptr, long long ldy = 0,
+                                                               float* __restrict__ out = nullptr, long long ldo = 0) {
   __shared__ float part[kWaves][kWave * V];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -37,7 +42,13 @@ __global__ __launch_bounds__(kThreads) void colsum_wide_kernel(const float* __re
       for (int u = 0; u < 4; ++u) {
         const float* __restrict__ q = p + static_cast<long long>(r + u * kWaves) * ld;
         if constexpr (V == 4) {
-          const float4 t4 = *reinterpret_cast<const float4*>(q);
+          float4 t4 = *reinterpret_cast<const float4*>(q);
+          if constexpr (MASK) {
+            const long long row = r + u * kWaves;
+            const float4 y4 = *reinterpret_cast<const float4*>(y + row * ldy + c);
+            t4 = make_float4(y4.x > 0.f ? t4.x : 0.f, y4.y > 0.f ? t4.y : 0.f, y4.z > 0.f ? t4.z : 0.f, y4.w > 0.f ? t4.w : 0.f);
+            *reinterpret_cast<float4*>(out + row * ldo + c) = t4;
+          }
           v[u][0] = t4.x; v[u][1] = t4.y; v[u][2] = t4.z; v[u][3] = t4.w;
         } else {
           v[u][0] = *q;
@@ -51,7 +62,14 @@ __global__ __launch_bounds__(kThreads) void colsum_wide_kernel(const float* __re
     for (; r < hi; r += kWaves) {
       const float* __restrict__ q = p + static_cast<long long>(r) * ld;
 #pragma unroll
-      for (int t = 0; t < V; ++t) a[t] += q[t];
+      for (int t = 0; t < V; ++t) {
+        float v = q[t];
+        if constexpr (MASK) {
+          v = y[static_cast<long long>(r) * ldy + c + t] > 0.f ? v : 0.f;
+          out[static_cast<long long>(r) * ldo + c + t] = v;
+        }
+        a[t] += v;
+      }
     }
   }
 #pragma unroll
@@ -113,5 +131,20 @@ extern "C" int uavgnn_colsum_acc(const float* x, long long ld, int N, int C, flo
   else
     hipLaunchKernelGGL(colsum_wide_kernel<1>, dim3(S, (C + kWave - 1) / kWave), dim3(kThreads), 0, st, x, ld, N, C,
                        rows, acc);
+  return launch_status();
+}
+
+// out [N, C] = dy where y > 0 else 0 (the backward of y = relu(.)), acc[S, C] += its row-blocked column sums: one pass.  C % 4 == 0,
+// row strides multiples of 4 floats, 16-byte aligned operands (UAVGNN_EUNSUPPORTED otherwise).  `out` may be `dy` itself.
+extern "C" int uavgnn_relu_bwd_colsum(const float* dy, long long ld, const float* y, long long ldy, float* out, long long ldo, int N,
+                                      int C, float* acc, int S, uavgnn_stream_t stream) {
+  if (N < 0 || C < 1 || S < 1 || !acc || (N > 0 && (!dy || !y || !out)) || ld < C || ldy < C || ldo < C) return UAVGNN_EINVAL;
+  if ((C & 3) || (ld & 3) || (ldy & 3) || (ldo & 3) ||
+      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15))
+    return UAVGNN_EUNSUPPORTED;
+  if (N == 0) return 0;
+  const int rows = (N + S - 1) / S;
+  hipLaunchKernelGGL((colsum_wide_kernel<4, true>), dim3(S, (C + 4 * kWave - 1) / (4 * kWave)), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream), dy, ld, N, C, rows, acc, y, ldy, out, ldo);
   return launch_status();
 }

@@ -717,6 +717,9 @@ def linear(x, W, b=None):
     return _LinearSplitK.apply(x, W, b)
 
 
+RELU_BWD_FUSED = os.environ.get("UAVGNN_RELU_BWD_FUSED", "1") != "0"   # ReLU mask + bias gradient in one pass (A/B switch)
+
+
 class _LinearReLU(th.autograd.Function):
     """relu(x W^T + b) with the bias + ReLU applied in the GEMM epilogue (hipBLASLt, via ``torch._addmm_activation``):
     the separate elementwise pass over [N_a, H] (and over [(T+1) N_a, H] in the time-batched encoder) disappears from
@@ -731,6 +734,19 @@ class _LinearReLU(th.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, W, y = ctx.saved_tensors
+        n, C = dy.shape
+        if (RELU_BWD_FUSED and ctx.needs_input_grad[2] and dy.is_cuda and dy.dtype == th.float32 and y.dtype == th.float32 and n > 0
+                and C % 4 == 0 and dy.stride(1) == 1 and y.stride(1) == 1 and dy.stride(0) % 4 == 0 and y.stride(0) % 4 == 0
+                and dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0):
+            # the mask and the bias gradient in ONE pass over the gradient (csrc/colsum.hip): autograd's threshold_backward + sum
+            # are two (5.1 + 1.7 GB per C3 update on the time-batched encoder)
+            S = _row_blocks(n)
+            dym = th.empty((n, C), dtype=th.float32, device=dy.device)
+            part = th.zeros((S, C), dtype=th.float32, device=dy.device)
+            L.check(L.lib().uavgnn_relu_bwd_colsum(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), dym.data_ptr(), C, n, C,
+                                                   part.data_ptr(), S, L.stream()), "uavgnn_relu_bwd_colsum")
+            dx, dW, _ = _LinearSplitK._grads(ctx, x, W, dym, False)
+            return dx, dW, part.sum(0)
         dy = th.ops.aten.threshold_backward(dy, y, 0.0)     # dy where y > 0 else 0, one pass (compare + where were two)
         return _LinearSplitK._grads(ctx, x, W, dy, True)
 
