@@ -2485,3 +2485,51 @@ def test_relu_backward_fused_with_the_bias_gradient(n, C):
                 ops.RELU_BWD_FUSED = True
         assert th.equal(grads[True][0], grads[False][0]) and th.equal(grads[True][1], grads[False][1])
         assert_close(grads[True][2], grads[False][2], 1e-5, "db", floor=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,head", [(4096, 256, True), (1000, 256, False), (33, 64, True), (32768, 256, True), (513, 128, False)])
+def test_gate_gradient_kernel_column_sums(N, H, head):
+    """uavgnn_gru_gates_bwd_fused_sums: the same d_gi / d_gh / d_h bits as uavgnn_gru_gates_bwd_fused[_head], and per-workgroup column
+    sums whose total is the bias gradient of the cell - d_r | d_z | d_n (input side) | d_n (hidden side) - to fp32 accuracy against
+    float64 sums of the gate gradients; bit-reproducible; H whose quarter does not divide 256 is refused through _sum_rows."""
+    from uav_bs_ctrl_amd import _lib as L
+    lib = L.lib()
+    gen = th.Generator().manual_seed(N + H)
+    pre = th.randn(N, 4 * H, generator=gen).cuda()
+    h = th.randn(N, H, generator=gen).cuda()
+    dho = th.randn(N, H, generator=gen).cuda()
+    A = 9
+    dq = th.randn(N, A, generator=gen).cuda() if head else None
+    W_out = (0.3 * th.randn(A, H, generator=gen)).cuda() if head else None
+    G = lib.uavgnn_gru_gates_bwd_sum_rows(N, H)
+    assert G > 0 and lib.uavgnn_gru_gates_bwd_sum_rows(N, 24) == 0       # 24 / 4 = 6 does not divide 256
+
+    def run(with_sums):
+        d_gi, d_gh, d_h = (th.full((N, 3 * H), float("nan"), device="cuda"), th.full((N, 3 * H), float("nan"), device="cuda"),
+                           th.full((N, H), float("nan"), device="cuda"))
+        sums = th.full((G, 4 * H), float("nan"), device="cuda") if with_sums else None
+        if with_sums:
+            rc = lib.uavgnn_gru_gates_bwd_fused_sums(pre.data_ptr(), h.data_ptr(), dho.data_ptr(), L.ptr(dq), A if head else 0, L.ptr(W_out),
+                                                     N, H, d_gi.data_ptr(), d_gh.data_ptr(), d_h.data_ptr(), sums.data_ptr(), L.stream())
+        elif head:
+            rc = lib.uavgnn_gru_gates_bwd_fused_head(pre.data_ptr(), h.data_ptr(), dho.data_ptr(), dq.data_ptr(), A, W_out.data_ptr(), N, H,
+                                                     d_gi.data_ptr(), d_gh.data_ptr(), d_h.data_ptr(), L.stream())
+        else:
+            rc = lib.uavgnn_gru_gates_bwd_fused(pre.data_ptr(), h.data_ptr(), dho.data_ptr(), N, H, d_gi.data_ptr(), d_gh.data_ptr(),
+                                                d_h.data_ptr(), L.stream())
+        L.check(rc, "gate gradients")
+        th.cuda.synchronize()
+        return d_gi, d_gh, d_h, sums
+
+    a = run(False)
+    b = run(True)
+    for x, y in zip(a[:3], b[:3]):
+        assert th.equal(x, y)
+    sums = b[3]
+    assert not bool(th.isnan(sums).any())
+    tot = sums.double().sum(0)
+    want = th.cat((a[0].double().sum(0), a[1][:, 2 * H:].double().sum(0)))
+    scale = th.cat((a[0].double().abs().sum(0), a[1][:, 2 * H:].double().abs().sum(0))) + 1e-30
+    assert float(((tot - want).abs() / scale).max()) < 2e-6
+    assert th.equal(run(True)[3], sums), "not bit-reproducible"
