@@ -2533,3 +2533,46 @@ def test_gate_gradient_kernel_column_sums(N, H, head):
     scale = th.cat((a[0].double().abs().sum(0), a[1][:, 2 * H:].double().abs().sum(0))) + 1e-30
     assert float(((tot - want).abs() / scale).max()) < 2e-6
     assert th.equal(run(True)[3], sums), "not bit-reproducible"
+
+
+@pytest.mark.gpu
+def test_graphed_cycle_reports_the_loss_of_every_replay_across_device_synchronisation():
+    """The LossQ a replayed whole-cycle graph hands back is the eager loss of the same update - also for replays behind a device
+    synchronise, at a size (T B n = 204 800 terms) where torch's one-kernel full reduction to a scalar meets at a semaphore: with
+    F.mse_loss the replays behind the first torch.cuda.synchronize() read back stale / partial values while the training step itself
+    stayed right (learner._mse is a two-stage sum for that reason; tools/gc_loss_probe.py)."""
+    import bench
+    from uav_bs_ctrl_amd.graphs import GraphedCycle
+    from uav_bs_ctrl_amd.learner import MultiAgentQLearner
+    dev = th.device("cuda")
+    n, M, T, B = 4, 10, 50, 1024
+    batch = bench.make_sequence(B, n, M, T, "dense", dev, seed=11, distinct=2)
+    env_info = dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=9, n_agents=n, episode_limit=T)
+
+    def make():
+        th.manual_seed(5)
+        lr = MultiAgentQLearner(env_info, bench.exp3_args("cuda"))
+        h_row = lr.init_hidden(1)[:1].clone()
+
+        def body():
+            obs = [g.fresh() for g in batch["obs"]]
+            fb = dict(batch, obs=obs, obs_all=batch["obs_all"].fresh(), obs_all_next=batch["obs_all_next"].fresh())
+            h = h_row.expand(n * B, -1).contiguous()
+            for t in range(3):                       # a short rollout in front of the update: the graph is a cycle, not just an update
+                _, h = lr.act(obs[t].fresh(), h, 0.05)
+            return lr.update(fb)
+        return lr, body
+
+    lr_g, body_g = make()
+    lr_e, body_e = make()
+    cyc = GraphedCycle(lr_g, body_g)
+    want = []
+    for _ in range(6):
+        want.append(float(body_e()["LossQ"]))
+    got = []
+    for k in range(6):
+        got.append(float(cyc()["LossQ"]))            # nothing but the read between two replays
+        if k == 2:
+            th.cuda.synchronize()
+    assert got == want, (got, want)
+    assert th.equal(lr_g.flat.flat, lr_e.flat.flat)

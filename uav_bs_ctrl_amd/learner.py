@@ -290,7 +290,7 @@ class MultiAgentQLearner:
             next_vals = self.target_mixer(next_vals, batch["states"][1:])
         rews, dones = batch["rews"].expand_as(next_vals), batch["dones"].expand_as(next_vals)
         target = rews + self.gamma * (1 - dones) * next_vals
-        return F.mse_loss(qvals, target), agent_out, target_out
+        return _mse(qvals, target), agent_out, target_out
 
     def update(self, batch) -> Dict:
         """One gradient step = ``accumulate`` (loss + backward into the flat gradient buffer) -> the ONE collective of the
@@ -402,6 +402,24 @@ class MultiAgentQLearner:
             if name in ck.get("comm_rng_state", {}) and hasattr(m, "rng_state"):
                 m.rng_state = ck["comm_rng_state"][name].to(self.device)
         return dict(epoch=ck.get("epoch"), t=ck.get("t"))
+
+
+def _mse(x: th.Tensor, y: th.Tensor) -> th.Tensor:
+    """F.mse_loss(x, y) (learner.py:154: the mean of squared differences) as a TWO-STAGE sum: row sums of a [S, numel / S] view, then
+    the sum of the S row sums.  torch's full reduction of a large tensor to one scalar runs as several thread blocks that meet at a
+    semaphore which a ``memset`` in front of the kernel clears; inside a replayed hipGraph of a whole cycle (graphs.GraphedCycle, ~4000
+    nodes) that reduction's final write did not always land once the device had been synchronised between replays - the training step was
+    right (parameters bit-identical to eager over 200 cycles), the reported LossQ was stale (found on the C2 bench line,
+    tools/gc_loss_probe.py).  Neither stage here needs the semaphore path: one block per row, then one block.  On this build
+    F.mse_loss also returns its scalar as a view of the [T, B, n] buffer of squared differences, which this avoids as well."""
+    d = x - y
+    n = d.numel()
+    if n == 0:
+        return d.sum()
+    S = 1
+    while S < 1024 and n % (2 * S) == 0 and n // (2 * S) >= 256:
+        S *= 2
+    return d.square().view(S, n // S).sum(1).sum() / n
 
 
 def params_checksum(module: th.nn.Module) -> th.Tensor:
