@@ -618,6 +618,20 @@ extern "C" int uavgnn_degree_order(const int32_t* seg_off, int N, int32_t* order
   return launch_status();
 }
 
+// Zero fill as a KERNEL (not hipMemsetAsync): inside a captured graph a memset becomes a memset node, and the one place where this
+// build met a memset node ordered in front of a kernel that depends on it - torch's semaphore-based full reduction in a ~4000-node
+// replayed graph - the dependent kernel did not always see it.  The counters below feed atomics.
+namespace uavgnn {
+namespace {
+__global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* __restrict__ p, long long n) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) p[i] = 0;
+}
+inline void zero_i32(int32_t* p, long long n, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(zero_i32_kernel, dim3(capped_grid(n, 256)), dim3(256), 0, st, p, n);
+}
+}  // namespace
+}  // namespace uavgnn
+
 extern "C" size_t uavgnn_csc_transpose_workspace_bytes(int N) {   // slot cursors + the scan's tile totals
   const size_t n = static_cast<size_t>(N > 0 ? N : 0);
   return (n + scan_scratch_elems(static_cast<long long>(n))) * sizeof(int32_t);
@@ -630,13 +644,11 @@ extern "C" int uavgnn_csc_transpose(const int32_t* talk_off, const int32_t* talk
     return UAVGNN_EINVAL;
   if (workspace_bytes < uavgnn_csc_transpose_workspace_bytes(N)) return UAVGNN_EWORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(t_off, 0, (static_cast<size_t>(N) + 1) * sizeof(int32_t), st);
-  if (e != hipSuccess) return -static_cast<int>(e);
-  if (N == 0 || E == 0) return 0;
+  zero_i32(t_off, static_cast<long long>(N) + 1, st);
+  if (N == 0 || E == 0) return launch_status();
   int32_t* cursor = static_cast<int32_t*>(workspace);
   int32_t* sums = cursor + N;
-  e = hipMemsetAsync(cursor, 0, static_cast<size_t>(N) * sizeof(int32_t), st);
-  if (e != hipSuccess) return -static_cast<int>(e);
+  zero_i32(cursor, N, st);
   hipLaunchKernelGGL(csc_out_degrees_kernel, dim3(capped_grid(E, 256)), dim3(256), 0, st, talk_src, E, t_off);
   int rc = scan_inclusive_i32(t_off + 1, N, sums, st);
   if (rc != 0) return rc;
@@ -652,8 +664,8 @@ extern "C" int uavgnn_csc_transpose_env(const int32_t* talk_off, const int32_t* 
   if (B < 0 || N < 0 || !talk_off || !graph_off || !t_off) return UAVGNN_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (B == 0 || N == 0) {
-    hipError_t e = hipMemsetAsync(t_off, 0, (static_cast<size_t>(N) + 1) * sizeof(int32_t), st);
-    return e == hipSuccess ? 0 : -static_cast<int>(e);
+    zero_i32(t_off, static_cast<long long>(N) + 1, st);
+    return launch_status();
   }
   hipLaunchKernelGGL(csc_transpose_env_kernel, dim3(capped_grid(B, kWavesPerBlock, 4096)), dim3(kThreads), 0, st,
                      talk_off, talk_src, graph_off, B, t_off, t_dst, t_pos);
