@@ -715,8 +715,8 @@ def main():
     ap.add_argument("--no-env-leg", action="store_true", help="skip the short D-env leg (`roofline_env`: the HBM-bound regime of K1)")
     ap.add_argument("--env-steps", type=int, default=5, help="timed steps of the D-env leg")
     ap.add_argument("--graphed-cycle", default="auto", choices=["auto", "on", "off"],
-                    help="replay the timed cycle from one hipGraph (graphs.GraphedCycle); auto: below %d agent rows per GPU, "
-                         "single process - the default C3 batch runs eagerly" % GRAPHED_CYCLE_ROWS)
+                    help="EXTRA leg: the cycle replayed from one hipGraph (graphs.GraphedCycle) -> `value_graphed`; auto: below %d agent "
+                         "rows per GPU, single process.  `value` is always the eager cycle" % GRAPHED_CYCLE_ROWS)
     ap.add_argument("--no-fp32-leg", action="store_true",
                     help="skip the second timing with the bf16x3 kernels off (fp32-MFMA GRU cell, vendor fp32 GEMMs)")
     a = ap.parse_args()
@@ -792,30 +792,18 @@ def main():
             dist.barrier()
         th.cuda.synchronize()
 
-    # Small batches (C2: 4 096 agent rows) are launch-bound: the same cycle, captured once and replayed (every input of
-    # `step` already sits at a fixed device address).  Never for the default C3 batch, never with a collective in the update.
+    # Small batches (C2: 4 096 agent rows) are launch-bound: the same cycle, captured once and replayed (every input of `step`
+    # already sits at a fixed device address), is reported as an EXTRA leg (`graphed_cycle_leg` / `value_graphed`) behind the timed
+    # region.  The headline `value` is always the eager cycle: a replay bakes the stored batch's topology into the graph, which a
+    # loop fed fresh observations could only reproduce with capacity-sized (static) graphs.
+    want_graphed = not use_dist and (a.graphed_cycle == "on" or (a.graphed_cycle == "auto" and a.B * a.n <= GRAPHED_CYCLE_ROWS))
     eager_step = step
-    graphed_cycle = not use_dist and (a.graphed_cycle == "on" or (a.graphed_cycle == "auto" and a.B * a.n <= GRAPHED_CYCLE_ROWS))
-    if graphed_cycle:
-        from uav_bs_ctrl_amd.graphs import GraphedCycle
-        h_row = learner.init_hidden(1)[:1].clone()      # the agent's initial state, moved to the device outside the capture
-
-        def body():
-            obs = [g.fresh() for g in batch["obs"]]
-            fb = dict(batch, obs=obs, obs_all=batch["obs_all"].fresh(), obs_all_next=batch["obs_all_next"].fresh())
-            h = h_row.expand(a.n * a.B, -1).contiguous()
-            for t in range(a.T):
-                _, h = learner.act(obs[t].fresh(), h, 0.05)
-            return learner.update(fb)
-
-        ops.KERNEL_TIMER.reset(enabled=False)           # HIP events cannot be read back from inside a replayed graph
-        step = GraphedCycle(learner, body)
 
     # Inside the timed region only the GRADED kernel (K1 forward) carries HIP events: timing every launch costs the launch thread
     # ~15 us per launch and makes the rollout phase host-bound (tools/launch_bound_probe.py: 21 -> 29 ms per 50 act forwards).
     # The other kernels are timed in ONE extra, fully instrumented cycle after the timed region (`instrumented_cycle`).
     GRADED = ("gatv2_hetero_fwd",)
-    ops.KERNEL_TIMER.reset(enabled=not graphed_cycle, only=GRADED)   # warm-up runs instrumented the same way
+    ops.KERNEL_TIMER.reset(enabled=True, only=GRADED)   # warm-up runs instrumented the same way
     for _ in range(a.warmup):
         step()
     barrier()
@@ -824,7 +812,7 @@ def main():
     # counting as usual.
     gc.collect()
     gc.disable()
-    ops.KERNEL_TIMER.reset(enabled=not graphed_cycle, only=GRADED)
+    ops.KERNEL_TIMER.reset(enabled=True, only=GRADED)
     learner.grads.collective_events = []            # HIP events around the one collective of an update (when there is one)
     clock = ClockSampler(local)
     with clock:
@@ -848,6 +836,35 @@ def main():
     barrier()
     instr_s = time.perf_counter() - t_i
     kfull = ops.KERNEL_TIMER.summary()
+    graphed_leg = None
+    if want_graphed:
+        from uav_bs_ctrl_amd.graphs import GraphedCycle
+        ops.KERNEL_TIMER.reset(enabled=False)           # HIP events cannot be read back from inside a replayed graph
+        h_row = learner.init_hidden(1)[:1].clone()      # the agent's initial state, moved to the device outside the capture
+
+        def body():
+            obs = [g.fresh() for g in batch["obs"]]
+            fb = dict(batch, obs=obs, obs_all=batch["obs_all"].fresh(), obs_all_next=batch["obs_all_next"].fresh())
+            h = h_row.expand(a.n * a.B, -1).contiguous()
+            for t in range(a.T):
+                _, h = learner.act(obs[t].fresh(), h, 0.05)
+            return learner.update(fb)
+
+        cyc = GraphedCycle(learner, body)
+        for _ in range(max(1, a.warmup)):
+            cyc()
+        barrier()
+        t_g = time.perf_counter()
+        for _ in range(a.steps):
+            out_g = cyc()
+        barrier()
+        el_g = time.perf_counter() - t_g
+        graphed_leg = {"value": a.B * a.T * a.steps / el_g, "unit": "env-steps/s", "steps": a.steps, "ms_per_step": 1e3 * el_g / a.steps,
+                       "loss": float(out_g["LossQ"]),
+                       "what": "the same cycle captured ONCE into a hipGraph (graphs.GraphedCycle) and replayed: no launch gaps.  The capture "
+                               "holds the stored batch's topology (edge counts, derived indices); a loop fed fresh observations replays a "
+                               "cycle only over capacity-sized static graphs (graph.from_padded_obs(static=True), as GraphedAct / "
+                               "GraphedUpdate do) - hence a separate figure, never `value`"}
     gc.enable()
     ops.KERNEL_TIMER.enabled = False
     el = th.tensor([elapsed], device=device, dtype=th.float64)
@@ -903,9 +920,10 @@ def main():
         k = ktimes.get("gatv2_hetero_fwd") or kfull.get("gatv2_hetero_fwd")   # graphed cycle: from the eager instrumented cycle
         if k:
             res["roofline"] = k1_roofline(k, a, a.dist, clock_mhz)
-            if graphed_cycle:
-                res["roofline"]["timed_in"] = "the eager instrumented cycle behind the timed replays (`instrumented_cycle`)"
-        res["graphed_cycle"] = graphed_cycle   # the timed steps were replays of ONE captured hipGraph of the whole cycle
+        res["graphed_cycle"] = False           # the timed steps are eager launches; the replayed cycle is `graphed_cycle_leg`
+        if graphed_leg is not None:
+            res["graphed_cycle_leg"] = graphed_leg
+            res["value_graphed"] = graphed_leg["value"]
         # ---- the GEMM-shaped kernels by time share (the GRU cell is the largest kernel of a dense cycle): MFMA roofs ----------
         sec = []
         kc = kfull.get("gru_cell_fwd")

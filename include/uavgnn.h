@@ -232,7 +232,8 @@ int uavgnn_colsum_acc(const float* x, long long ld, int N, int C, float* acc, in
 /* The ReLU backward fused with the bias gradient of the Linear in front of it (reference: f_aggr = Sequential(Linear, ReLU),
  * gnn_agents.py:99-102, under learner.py:157): out [N, C] = dy where y > 0 else 0, acc[S, C] += row-blocked column sums of out
  * (as uavgnn_colsum_acc).  One pass over the gradient instead of autograd's threshold_backward + sum.  C % 4 == 0, strides % 4 == 0,
- * 16-byte aligned operands; `out` may alias `dy`. */
+ * 16-byte aligned operands; `out` may be `dy` itself (same pointer and row stride: in place); any other
+ * overlap of `out` with `dy` or `y` is UAVGNN_EINVAL. */
 int uavgnn_relu_bwd_colsum(const float* dy, long long ld, const float* y, long long ldy, float* out, long long ldo, int N, int C,
                            float* acc, int S, uavgnn_stream_t stream);
 

@@ -276,8 +276,13 @@ def drqn_gnn_agent_forward(g: dict, h, p: dict, n_heads: int):
 # --------------------------------------------------------------------------------------------------------------------
 # row L: the BPTT pattern of MultiAgentQLearner.update (learner.py:110-154), loss only (no optimiser).
 
-def madrqn_loss(obs, h0, h1, acts, rews, dones, p_policy, p_target, cfg, gamma, double_q=True):
+def madrqn_loss(obs, h0, h1, acts, rews, dones, p_policy, p_target, cfg, gamma, double_q=True, next_acts=None):
     """obs: list of T+1 graph dicts; acts [T, B*n, 1] long; rews/dones broadcastable to [T, B, n].
+
+    ``next_acts`` [T, B*n, 1] long: the double-Q action choice handed in instead of the argmax over this run's own policy
+    outputs (learner.py:138 takes it from ``agent_out[1:].detach()``).  The argmax is the one discontinuous step of the loss:
+    a checker that compares two precisions first verifies that the two choices differ only on rows whose top-two Q values tie
+    to within the comparison's tolerance, then evaluates both sides under the SAME choice.
 
     Returns (loss, agent_out [T+1, N_a, A], target_out [T, N_a, A])."""
     T = len(obs) - 1
@@ -294,7 +299,9 @@ def madrqn_loss(obs, h0, h1, acts, rews, dones, p_policy, p_target, cfg, gamma, 
     agent_out, target_out = th.stack(agent_out), th.stack(target_out)
     qvals = agent_out[:-1].gather(2, acts)
     if double_q:
-        next_vals = target_out.gather(2, agent_out[1:].detach().argmax(2, keepdim=True))
+        if next_acts is None:
+            next_acts = agent_out[1:].detach().argmax(2, keepdim=True)
+        next_vals = target_out.gather(2, next_acts)
     else:
         next_vals = target_out.max(2, keepdim=True)[0]
     shp = rews.shape[:2] + (-1,)

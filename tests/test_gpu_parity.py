@@ -543,6 +543,7 @@ def test_full_size_configs_by_environment_subsets_and_properties(name, B, n, M, 
 
 
 @pytest.mark.parametrize("name,B,n,M,dist,talk", [("C3 8x80 B=4096 dense", 4096, 8, 80, "dense", "complete"),
+                                                  ("C3 8x80 B=4096 env", 4096, 8, 80, "env", "complete"),
                                                   ("C5 16x200 B=1024 sparse talk", 1024, 16, 200, "ragged", "sparse")])
 def test_full_size_backward_by_masked_loss(name, B, n, M, dist, talk):
     """Backward at FULL batch size: with loss weights that vanish outside a few environments, every parameter gradient
@@ -2576,3 +2577,166 @@ def test_graphed_cycle_reports_the_loss_of_every_replay_across_device_synchronis
             th.cuda.synchronize()
     assert got == want, (got, want)
     assert th.equal(lr_g.flat.flat, lr_e.flat.flat)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 6: the oracle on the path the benchmark times (learner.update at exp3 sizes with production kernel dispatch)
+
+def _oracle_obs(g, dtype):
+    """Segment-layout dict of a HeteroBatch on the CPU (what oracle/restatement.py reads)."""
+    x_gt, seen_off = g.relation_segments("seen")
+    x_ubs, near_off = g.relation_segments("near")
+    talk_off, talk_src = g.talk_csc()
+    f = lambda t: t.detach().cpu().to(dtype)   # noqa: E731
+    return dict(x_a=f(g.agent_feat()), x_gt=f(x_gt), seen_off=seen_off.cpu(), x_ubs=f(x_ubs), near_off=near_off.cpu(),
+                talk_off=talk_off.cpu(), talk_src=talk_src.cpu())
+
+
+class _LibSpy:
+    """Records the name of every C-ABI entry the product fetches from the library (ops.py calls ``L.lib().<entry>(...)``)."""
+
+    def __init__(self, real):
+        self._real, self.names = real, []
+
+    def __getattr__(self, name):
+        self.names.append(name)
+        return getattr(self._real, name)
+
+
+def _exp3_learner_and_sequence(B, n, M, T, dist, seed):
+    """exp3 learner whose target network differs from the policy (as it does after the first polyak step) and whose biases
+    are not DGL's zeros, + one sampled batch of bench.py's generator."""
+    import bench
+    from uav_bs_ctrl_amd.learner import MultiAgentQLearner
+    th.manual_seed(seed)
+    learner = MultiAgentQLearner(dict(obs_shape=dict(agent=2, ubs=2, gt=4), n_actions=9, n_agents=n, episode_limit=T),
+                                 bench.exp3_args("cuda"))
+    gen = th.Generator(device="cuda").manual_seed(1000 + seed)
+    with th.no_grad():
+        for prm in learner.policy_net.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.05 * th.randn(prm.shape, device="cuda", generator=gen))
+        for pt, pp in zip(learner.target_net.parameters(), learner.policy_net.parameters()):
+            pt.copy_(pp + 0.02 * pp.abs().mean() * th.randn(pp.shape, device="cuda", generator=gen))
+    learner.invalidate_weight_cache()
+    batch = bench.make_sequence(B, n, M, T, dist, th.device("cuda"), seed=7 + seed, distinct=2)
+    batch["h0"] = 0.1 * th.randn(B * n, 256, device="cuda", generator=gen)          # stored hidden states, not zeros
+    return learner, batch
+
+
+def _oracle_update(learner, batch, dtype, next_acts=None):
+    """loss, policy outputs and the gradient of every policy parameter from oracle/restatement.py:madrqn_loss on the CPU."""
+    cfg = dict(EXP3)
+    pp = {k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in learner.policy_net.state_dict().items()}
+    pt = {k: v.detach().cpu().to(dtype) for k, v in learner.target_net.state_dict().items()}
+    obs = [_oracle_obs(g, dtype) for g in batch["obs"]]
+    f = lambda t: t.detach().cpu().to(dtype)   # noqa: E731
+    loss, agent_out, _ = R.madrqn_loss(obs, f(batch["h0"]), f(batch["h1"]), batch["acts"].cpu(), f(batch["rews"]), f(batch["dones"]),
+                                       pp, pt, cfg, learner.gamma, True, next_acts=next_acts)
+    names = [k for k, _ in learner.policy_net.named_parameters()]
+    return loss.detach(), agent_out.detach(), dict(zip(names, th.autograd.grad(loss, [pp[k] for k in names])))
+
+
+UPDATE_CASES = [("1280 rows", 160, 8, 20, 3), ("4096 rows", 512, 8, 10, 2)]
+
+
+@pytest.mark.parametrize("dist", ["env", "dense"])
+@pytest.mark.parametrize("label,B,n,M,T", UPDATE_CASES)
+def test_learner_update_at_exp3_sizes_vs_oracle(label, B, n, M, T, dist, monkeypatch):
+    """Row L where its production kernels dispatch (learner.py:110-157 of the reference): ``MultiAgentQLearner.accumulate`` on
+    bench.py's sampled batches - time-batched encoder through ``_TimeSplit``, ``WeightGradSink`` staging, the bf16x3 cell
+    (>= 1024 rows), the fused message kernel, the head kernel, the gate-gradient kernel with the folded head gradient and column
+    sums, and at >= 4096 rows ``gemm_x3`` / ``gemm_nt_x3_cat`` / ``relu_bwd_colsum`` - against ``R.madrqn_loss`` in float64
+    (float32 for the error floor): LossQ, every Q value, and EVERY slice of the flat gradient buffer under ``grad_close``.
+    Then once more through the captured ``GraphedUpdate``."""
+    from uav_bs_ctrl_amd import _lib as L
+    from uav_bs_ctrl_amd import ops
+    learner, batch = _exp3_learner_and_sequence(B, n, M, T, dist, seed=3)
+    N = B * n
+    spy = _LibSpy(L.lib())
+    monkeypatch.setattr(L, "lib", lambda: spy)
+    staged = []
+    orig_end = ops.WeightGradSink.end_sequence
+
+    def end_spy(self):
+        staged.append(0 if self.seq is None else len(self.seq.bwd_steps))
+        return orig_end(self)
+    monkeypatch.setattr(ops.WeightGradSink, "end_sequence", end_spy)
+    out = learner.accumulate(dict(batch))
+    flat = learner.grads.flat.clone()
+    monkeypatch.undo()
+    # --- the dispatch is the benchmark's
+    called = set(spy.names)
+    assert max(staged) == T + 1, f"time-batched staging not taken: {staged}"
+    expect = {"uavgnn_gatv2_hetero_fwd_image", "uavgnn_gru_cell_fwd_x3_opts", "uavgnn_tarmac_msg_fwd", "uavgnn_head_fwd",
+              "uavgnn_gru_gates_bwd_fused_sums", "uavgnn_talk_attn_env_bwd", "uavgnn_gatv2_bwd", "uavgnn_colsum_acc",
+              "uavgnn_relu_bwd_colsum"}
+    if N >= 4096:
+        expect |= {"uavgnn_gemm_nt_x3", "uavgnn_gemm_nt_x3_cat"}
+    assert expect <= called, f"{label}: production kernels not dispatched: {sorted(expect - called)}"
+    # --- oracle, float64: the double-Q argmax is the one discontinuous step - the two sides may differ only on numerical ties
+    l64, q64, g64 = _oracle_update(learner, batch, th.float64)
+    q_gpu = out["QVals"].detach().cpu()
+    assert_close(q_gpu, q64, 1e-5, f"{label} {dist}: QVals")
+    na_gpu, na64 = q_gpu[1:].argmax(2, keepdim=True), q64[1:].argmax(2, keepdim=True)
+    diff = (na_gpu != na64).squeeze(2)
+    if bool(diff.any()):
+        top2 = q64[1:].topk(2, dim=2).values
+        gap = (top2[..., 0] - top2[..., 1])[diff]
+        assert float(gap.max()) <= 2e-5 * float(q64.abs().max()), f"{label} {dist}: argmax differs on rows that do not tie"
+        l64, q64, g64 = _oracle_update(learner, batch, th.float64, next_acts=na_gpu)
+    l32, _, g32 = _oracle_update(learner, batch, th.float32, next_acts=na_gpu)
+    assert_close(out["LossQ"], l64, 1e-5, f"{label} {dist}: LossQ")
+    for k, prm in learner.policy_net.named_parameters():
+        o = learner.grads.offsets[learner.grads.params.index(prm)]
+        got = flat[o:o + prm.numel()].view_as(prm)
+        grad_close(got, g64[k], f"learner.accumulate exp3 {label} {dist}: grad {k}", ref32=g32[k], floor=GRAD_FLOOR)
+    # --- the same accumulate as ONE replayed hipGraph (what `bench.py --graphed-cycle` and a production loop replay): the flat
+    # gradient buffer the replay leaves is the eager one, i.e. the oracle comparison above covers the graphed path too
+    from uav_bs_ctrl_amd.graphs import GraphedCycle
+    cyc = GraphedCycle(learner, lambda: learner.accumulate(batch))
+    learner.grads.flat.fill_(float("nan"))
+    out_g = cyc()
+    th.cuda.synchronize()
+    assert_close(out_g["LossQ"], l64, 1e-5, f"{label} {dist}: LossQ (graph replay)")
+    assert th.equal(learner.grads.flat, flat), f"{label} {dist}: graph replay of accumulate differs from the eager run"
+
+
+def test_drqn_twin_at_exp1_hidden_size_vs_oracle():
+    """BASELINE config 1's model (algos/drqn/agents/gnn_agents.py:9-30) at its production width: H = 256, 4 heads, 1 agent x 20
+    GTs, B = 32 - forward and every gradient against the float64 / float32 oracle (the golden fixture runs it at H = 32)."""
+    import types
+    from uav_bs_ctrl_amd.agents import REGISTRY
+    B, M, H = 32, 20, 256
+    th.manual_seed(5)
+    net = REGISTRY["drqn_gnn"](dict(agent=2, gt=4), 9, types.SimpleNamespace(hidden_size=H, n_heads=4))
+    with th.no_grad():
+        for prm in net.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.05 * th.randn_like(prm))
+    p64 = {k: v.detach().double().clone() for k, v in net.state_dict().items()}
+    g = synth_graph(B, 1, M, "dense", seed=11)
+    g = {k: g[k] for k in ("x_a", "x_gt", "seen_off")}
+    gen = th.Generator().manual_seed(12)
+    h = 0.5 * th.randn(B, H, generator=gen)
+    wq, wh = th.randn(B, 9, generator=gen), th.randn(B, H, generator=gen) / 16
+
+    def oracle(dtype):
+        pp = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in p64.items()}
+        gg = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in g.items()}
+        hh = h.detach().clone().to(dtype).requires_grad_(True)
+        q, h2 = R.drqn_gnn_agent_forward(gg, hh, pp, 4)
+        gr = th.autograd.grad(_loss(q, h2, wq.to(dtype), wh.to(dtype)), list(pp.values()) + [hh])
+        return q, h2, dict(zip(list(pp) + ["__h__"], gr))
+    q64, h64, g64 = oracle(th.float64)
+    _, _, g32 = oracle(th.float32)
+    net = net.cuda()
+    hd = h.cuda().requires_grad_(True)
+    q, h2 = net(to_batch(g), hd)
+    assert_close(q, q64, 1e-5, "drqn H=256: q")
+    assert_close(h2, h64, 1e-5, "drqn H=256: h'")
+    _loss(q, h2, wq.cuda(), wh.cuda()).backward()
+    grads = {k: prm.grad for k, prm in net.named_parameters()}
+    grads["__h__"] = hd.grad
+    for k, ref in g64.items():
+        grad_close(grads[k], ref, f"drqn twin H=256 1x{M} B={B}: grad {k}", ref32=g32[k], floor=GRAD_FLOOR)

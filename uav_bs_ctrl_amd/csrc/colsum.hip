@@ -19,11 +19,13 @@ constexpr int kWaves = kThreads / kWave;
 // MASK (V = 4 only): x is the gradient of y = relu(.) - the summed value is x where y > 0 and 0 elsewhere, and that masked
 // gradient is also written to `out` (the ReLU backward of gnn_agents.py:99-102 and the bias gradient of the Linear in front of it in
 // ONE pass over the [N, C] gradient instead of an elementwise pass followed by a reduction pass).
+// `x` and `out` carry no __restrict__: the MASK instantiation may run IN PLACE (out == x, same row stride) - every element is read
+// and written by the same lane, all loads of an iteration are issued before its stores.
 template <int V, bool MASK = false>
-__global__ __launch_bounds__(kThreads) void colsum_wide_kernel(const float* __restrict__ x, long long ld, int N, int C,
+__global__ __launch_bounds__(kThreads) void colsum_wide_kernel(const float* x, long long ld, int N, int C,
                                                                int rows_per_block, float* __restrict__ acc,
                                                                const float* __restrict__ y = nullptr, long long ldy = 0,
-                                                               float* __restrict__ out = nullptr, long long ldo = 0) {
+                                                               float* out = nullptr, long long ldo = 0) {
   __shared__ float part[kWaves][kWave * V];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -34,24 +36,36 @@ __global__ __launch_bounds__(kThreads) void colsum_wide_kernel(const float* __re
 #pragma unroll
   for (int t = 0; t < V; ++t) a[t] = 0.f;
   if (c < C) {
-    const float* __restrict__ p = x + c;
+    const float* p = x + c;
     int r = lo + wave;
     for (; r + 3 * kWaves < hi; r += 4 * kWaves) {   // four rows in flight per lane
       float v[4][V];
+      if constexpr (V == 4 && MASK) {
+        float4 t4[4], y4[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float* __restrict__ q = p + static_cast<long long>(r + u * kWaves) * ld;
-        if constexpr (V == 4) {
-          float4 t4 = *reinterpret_cast<const float4*>(q);
-          if constexpr (MASK) {
-            const long long row = r + u * kWaves;
-            const float4 y4 = *reinterpret_cast<const float4*>(y + row * ldy + c);
-            t4 = make_float4(y4.x > 0.f ? t4.x : 0.f, y4.y > 0.f ? t4.y : 0.f, y4.z > 0.f ? t4.z : 0.f, y4.w > 0.f ? t4.w : 0.f);
-            *reinterpret_cast<float4*>(out + row * ldo + c) = t4;
+        for (int u = 0; u < 4; ++u) {
+          const long long row = r + u * kWaves;
+          t4[u] = *reinterpret_cast<const float4*>(p + row * ld);
+          y4[u] = *reinterpret_cast<const float4*>(y + row * ldy + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long row = r + u * kWaves;
+          t4[u] = make_float4(y4[u].x > 0.f ? t4[u].x : 0.f, y4[u].y > 0.f ? t4[u].y : 0.f, y4[u].z > 0.f ? t4[u].z : 0.f,
+                              y4[u].w > 0.f ? t4[u].w : 0.f);
+          *reinterpret_cast<float4*>(out + row * ldo + c) = t4[u];
+          v[u][0] = t4[u].x; v[u][1] = t4[u].y; v[u][2] = t4[u].z; v[u][3] = t4[u].w;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* q = p + static_cast<long long>(r + u * kWaves) * ld;
+          if constexpr (V == 4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(q);
+            v[u][0] = t4.x; v[u][1] = t4.y; v[u][2] = t4.z; v[u][3] = t4.w;
+          } else {
+            v[u][0] = *q;
           }
-          v[u][0] = t4.x; v[u][1] = t4.y; v[u][2] = t4.z; v[u][3] = t4.w;
-        } else {
-          v[u][0] = *q;
         }
       }
 #pragma unroll
@@ -60,7 +74,7 @@ __global__ __launch_bounds__(kThreads) void colsum_wide_kernel(const float* __re
         for (int t = 0; t < V; ++t) a[t] += v[u][t];
     }
     for (; r < hi; r += kWaves) {
-      const float* __restrict__ q = p + static_cast<long long>(r) * ld;
+      const float* q = p + static_cast<long long>(r) * ld;
 #pragma unroll
       for (int t = 0; t < V; ++t) {
         float v = q[t];
@@ -135,10 +149,18 @@ extern "C" int uavgnn_colsum_acc(const float* x, long long ld, int N, int C, flo
 }
 
 // out [N, C] = dy where y > 0 else 0 (the backward of y = relu(.)), acc[S, C] += its row-blocked column sums: one pass.  C % 4 == 0,
-// row strides multiples of 4 floats, 16-byte aligned operands (UAVGNN_EUNSUPPORTED otherwise).  `out` may be `dy` itself.
+// row strides multiples of 4 floats, 16-byte aligned operands (UAVGNN_EUNSUPPORTED otherwise).  `out` may be `dy` itself (same pointer AND same row stride: in place); any other
+// overlap of `out` with `dy`, and any overlap with `y`, is UAVGNN_EINVAL.
 extern "C" int uavgnn_relu_bwd_colsum(const float* dy, long long ld, const float* y, long long ldy, float* out, long long ldo, int N,
                                       int C, float* acc, int S, uavgnn_stream_t stream) {
   if (N < 0 || C < 1 || S < 1 || !acc || (N > 0 && (!dy || !y || !out)) || ld < C || ldy < C || ldo < C) return UAVGNN_EINVAL;
+  if (N > 0) {
+    const uintptr_t o0 = reinterpret_cast<uintptr_t>(out), o1 = o0 + 4ull * (static_cast<uintptr_t>(N - 1) * ldo + C);
+    const uintptr_t d0 = reinterpret_cast<uintptr_t>(dy), d1 = d0 + 4ull * (static_cast<uintptr_t>(N - 1) * ld + C);
+    const uintptr_t y0 = reinterpret_cast<uintptr_t>(y), y1 = y0 + 4ull * (static_cast<uintptr_t>(N - 1) * ldy + C);
+    const bool in_place = (o0 == d0 && ldo == ld);
+    if ((!in_place && o0 < d1 && d0 < o1) || (o0 < y1 && y0 < o1)) return UAVGNN_EINVAL;
+  }
   if ((C & 3) || (ld & 3) || (ldy & 3) || (ldo & 3) ||
       ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15))
     return UAVGNN_EUNSUPPORTED;

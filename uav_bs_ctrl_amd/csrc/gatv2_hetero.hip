@@ -359,6 +359,19 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
 
   const int stride = gridDim.x * kWavesPerBlock;
   const int it0 = blockIdx.x * kWavesPerBlock + wave;
+#ifndef K1_S_TRANSPOSE
+#define K1_S_TRANSPOSE 1
+#endif
+  // Phase S hands the degree-SORTED destinations out by position: position p, p + stride, ... go to one wavefront.  With p = it0 the
+  // eight heaviest destinations of a rollout batch (ONE destination per wavefront there: 1 966 of 32 768 have in-edges at D-env) all
+  // land on workgroup 0 - four row tiles each, on both wavefronts of every SIMD - and the last workgroups get none.  Transposed
+  // (wavefront w of workgroup b starts at position w * gridDim + b) every CU gets one destination of each weight class and the two
+  // wavefronts of a SIMD (w, w + 4) a heavy and a light one: D-env rollout launch 19.05 -> 18.15 us, same box, same rows bit for bit
+  // (profiles/r06_k1_handout_ab.txt).  Only for rollout-size launches (one block of phase N per wavefront): over many chunks of
+  // `stride` positions the transposed order gives wavefront 0 the heaviest eighth of EVERY chunk (time-batched launch 751 -> 786 us),
+  // while the plain order's skew between workgroups shrinks with the number of chunks.
+  const bool one_chunk = ((N + 15) >> 4) <= stride;
+  const int it0s = (K1_S_TRANSPOSE && one_chunk) ? wave * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x) : it0;
   const int nblk = (N + 15) >> 4;   // blocks of 16 destinations (phase N)
 #if K1_ABLATE   // `phases` bit 10: per-wavefront time stamps (100 MHz s_memrealtime) into the buffer passed as attn_save_seen
   unsigned long long* const dbg = (phases & 1024) ? reinterpret_cast<unsigned long long*>(a_save_s_arg) : nullptr;
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
   Meta mnext = load_meta(min(it0, nblk - 1));
   // ... and so is the first hand-out chunk of phase S (destination, segment, features of 64 positions: two of the three
   // dependent round trips of a phase that is pure latency on a rollout batch); it waits in LDS while phase N runs
-  const int s_it = min(it0 + lane * stride, N - 1);
+  const int s_it = min(it0s + lane * stride, N - 1);
   const int p_v = seen_order != nullptr ? seen_order[s_it] : s_it;
 
   // ---- workgroup prologue: the parameter image into LDS ------------------------------------------------------------------
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
   const bool phase_n = (phases & 2) && it0 < nblk;
   if (!phase_n) stash();
 
-  const bool phase_s = it0 < N && (phases & 1) && E_seen > 0;
+  const bool phase_s = it0s < N && (phases & 1) && E_seen > 0;
   // (Requesting phase S's first tile from inside phase N, in front of the `near` row stores of the wavefront's last block, was
   // measured: +0.5 us on a rollout launch - the loads queue behind 33 MB of stores and the wait for them is no shorter.  So was
   // running the phases in opposite order on the two wavefronts of a SIMD: +2.5 us - phase S's loads crawl while the other
@@ -800,7 +813,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     // loads would share the lgkm counter with the LDS traffic of process(): its first s_waitcnt lgkmcnt(0) would wait for
     // the look-ahead s_loads of the NEXT destination (an L2 round trip per destination).
     bool done = false;
-    for (int kb = 0; !done && it0 + kb * stride < N; kb += kWave) {
+    for (int kb = 0; !done && it0s + kb * stride < N; kb += kWave) {
       int m_v, m_e0, m_e1;
       float2 m_xv;
       if (kb == 0) {   // requested in the prologue
@@ -810,14 +823,14 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
         m_e1 = sS[wave][lane];
         m_xv = make_float2(__int_as_float(sS[wave][kWave + lane]), __int_as_float(sS[wave][2 * kWave + lane]));
       } else {
-        const int my_it = it0 + (kb + lane) * stride;
+        const int my_it = it0s + (kb + lane) * stride;
         const bool mine = my_it < N;
         m_v = mine ? (seen_order ? seen_order[my_it] : my_it) : 0;
         m_e0 = mine ? seen_off[m_v] : 0;
         m_e1 = mine ? seen_off[m_v + 1] : 0;
         m_xv = mine ? *reinterpret_cast<const float2*>(x_dst + 2 * m_v) : make_float2(0.f, 0.f);
       }
-      const int cnt = min(kWave, (N - it0 - kb * stride + stride - 1) / stride);
+      const int cnt = min(kWave, (N - it0s - kb * stride + stride - 1) / stride);
       {
         const int e0 = __builtin_amdgcn_readlane(m_e0, 0);
         request(e0, __builtin_amdgcn_readlane(m_e1, 0) - e0);

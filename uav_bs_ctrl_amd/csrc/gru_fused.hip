@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void gru_cell_fwd_kernel(
 // gate gradients of a BPTT sequence are not read again just to be summed (two streaming passes over 6.8 GB per C3 update).  A thread
 // keeps its four columns over the grid-stride loop (the stride is a multiple of H / 4 elements), the 256 / (H / 4) threads of a
 // block that share them are added in a fixed order through LDS: deterministic.
-template <bool HEAD>
+template <bool HEAD, bool SUMS>
 __global__ __launch_bounds__(256) void gru_gates_bwd_fused_kernel(const float* __restrict__ pre, const float* __restrict__ h,
                                                                   const float* __restrict__ d_hout, long long total, int H,
                                                                   float* __restrict__ d_gi, float* __restrict__ d_gh,
@@ -188,9 +188,9 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_fused_kernel(const float* _
                                                                   int n_out, const float* __restrict__ W_out,
                                                                   float* __restrict__ col_sums) {
   const int HV = H / 4;
-  float cs[16];
+  float cs[SUMS ? 16 : 1];       // the accumulators (and the LDS array below) exist in the column-sum instantiations only
 #pragma unroll
-  for (int t = 0; t < 16; ++t) cs[t] = 0.f;
+  for (int t = 0; t < (SUMS ? 16 : 1); ++t) cs[t] = 0.f;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
     const long long row = i / HV;
     const int col = static_cast<int>(i - row * HV) * 4;
@@ -224,10 +224,12 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_fused_kernel(const float* _
       dr[t] = dn_pre * a_gh[t] * r * (1.f - r);
       dz[t] = a_d[t] * (a_h[t] - n) * z * (1.f - z);
       dh[t] = a_d[t] * z;
-      cs[t] += dr[t];
-      cs[4 + t] += dz[t];
-      cs[8 + t] += dni[t];
-      cs[12 + t] += dnh[t];
+      if constexpr (SUMS) {
+        cs[t] += dr[t];
+        cs[4 + t] += dz[t];
+        cs[8 + t] += dni[t];
+        cs[12 + t] += dnh[t];
+      }
     }
     float* gi = d_gi + row * 3 * H + col;
     float* gh = d_gh + row * 3 * H + col;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_fused_kernel(const float* _
     *reinterpret_cast<float4*>(gh + 2 * H) = make_float4(dnh[0], dnh[1], dnh[2], dnh[3]);
     *reinterpret_cast<float4*>(d_h + row * H + col) = make_float4(dh[0], dh[1], dh[2], dh[3]);
   }
-  if (col_sums != nullptr) {      // uniform: same pointer for every thread
+  if constexpr (SUMS) {
     __shared__ float sS[256 * 17];
 #pragma unroll
     for (int t = 0; t < 16; ++t) sS[threadIdx.x * 17 + t] = cs[t];
@@ -296,8 +298,8 @@ extern "C" int uavgnn_gru_gates_bwd_fused(const float* pre, const float* h, cons
   if (H % 4) return UAVGNN_EUNSUPPORTED;
   if (N == 0) return 0;
   const long long total = static_cast<long long>(N) * (H / 4);
-  hipLaunchKernelGGL(gru_gates_bwd_fused_kernel<false>, dim3(capped_grid(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     pre, h, d_hout, total, H, d_gi, d_gh, d_h, nullptr, 0, nullptr, nullptr);
+  hipLaunchKernelGGL((gru_gates_bwd_fused_kernel<false, false>), dim3(capped_grid(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), pre, h, d_hout, total, H, d_gi, d_gh, d_h, nullptr, 0, nullptr, nullptr);
   return launch_status();
 }
 
@@ -308,8 +310,8 @@ extern "C" int uavgnn_gru_gates_bwd_fused_head(const float* pre, const float* h,
   if (H % 4 || n_out > 64 || (reinterpret_cast<uintptr_t>(W_out) & 15)) return UAVGNN_EUNSUPPORTED;
   if (N == 0) return 0;
   const long long total = static_cast<long long>(N) * (H / 4);
-  hipLaunchKernelGGL(gru_gates_bwd_fused_kernel<true>, dim3(capped_grid(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     pre, h, d_hout, total, H, d_gi, d_gh, d_h, dq, n_out, W_out, nullptr);
+  hipLaunchKernelGGL((gru_gates_bwd_fused_kernel<true, false>), dim3(capped_grid(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), pre, h, d_hout, total, H, d_gi, d_gh, d_h, dq, n_out, W_out, nullptr);
   return launch_status();
 }
 
@@ -333,10 +335,10 @@ extern "C" int uavgnn_gru_gates_bwd_fused_sums(const float* pre, const float* h,
   const long long total = static_cast<long long>(N) * (H / 4);
   const dim3 grid(capped_grid(total, 256)), block(256);
   if (dq != nullptr)
-    hipLaunchKernelGGL(gru_gates_bwd_fused_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), pre, h, d_hout, total, H, d_gi,
-                       d_gh, d_h, dq, n_out, W_out, col_sums);
+    hipLaunchKernelGGL((gru_gates_bwd_fused_kernel<true, true>), grid, block, 0, static_cast<hipStream_t>(stream), pre, h, d_hout, total, H,
+                       d_gi, d_gh, d_h, dq, n_out, W_out, col_sums);
   else
-    hipLaunchKernelGGL(gru_gates_bwd_fused_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), pre, h, d_hout, total, H, d_gi,
-                       d_gh, d_h, nullptr, 0, nullptr, col_sums);
+    hipLaunchKernelGGL((gru_gates_bwd_fused_kernel<false, true>), grid, block, 0, static_cast<hipStream_t>(stream), pre, h, d_hout, total, H,
+                       d_gi, d_gh, d_h, nullptr, 0, nullptr, col_sums);
   return launch_status();
 }

@@ -31,6 +31,24 @@ def _capture(graph, **kw):
     return th.cuda.graph(graph, **kw)
 
 
+class _RngSnapshot:
+    """The random state a warm-up advances besides the parameters: the learner's epsilon generator and the device {seed, step} pairs
+    of DiscreteComm's in-kernel noise (``rng_state``).  Restored after the capture, so a graphed run starts from the state an eager
+    run starts from.  (A generator registered with a capturing graph keeps its captured offset bookkeeping; only its state before
+    the first replay is put back.)"""
+
+    def __init__(self, learner):
+        self.learner = learner
+        self.gen = learner._gen.get_state()
+        self.comm = [(m, m.rng_state.clone()) for net in (learner.policy_net, learner.target_net) for m in net.modules()
+                     if isinstance(getattr(m, "rng_state", None), th.Tensor)]
+
+    def restore(self):
+        self.learner._gen.set_state(self.gen)
+        for m, st in self.comm:
+            m.rng_state.copy_(st)
+
+
 class _PaddedObs:
     """Fixed-address padded observation buffers (the simulator's format, mubs_cov.py:215-242) of ``lead`` env steps."""
 
@@ -134,8 +152,10 @@ class GraphedUpdate:
         self.dones = th.zeros(T, B, 1, dtype=th.float32, device=dev)
         self.graph = th.cuda.CUDAGraph()
         # warm-up updates run for real (they would move the parameters): snapshot and restore around them
-        snap = {k: [t.clone() for t in (learner.flat.flat, learner.flat_target, learner.optimizer.m, learner.optimizer.v,
-                                        learner.optimizer.hyper)] for k in ("s",)}["s"]
+        learner.optimizer.sync_lr()      # a learning rate the scheduler moved since the last sync is part of the snapshot, not undone by it
+        snap = [t.clone() for t in (learner.flat.flat, learner.flat_target, learner.optimizer.m, learner.optimizer.v,
+                                    learner.optimizer.hyper)]
+        rng = _RngSnapshot(learner)
         self.split = learner.needs_collective()
         side = th.cuda.Stream()
         side.wait_stream(th.cuda.current_stream())
@@ -157,6 +177,7 @@ class GraphedUpdate:
         for dst, src in zip((learner.flat.flat, learner.flat_target, learner.optimizer.m, learner.optimizer.v,
                              learner.optimizer.hyper), snap):
             dst.copy_(src)
+        rng.restore()
         learner.invalidate_weight_cache()
 
     def _body(self) -> Dict:
@@ -218,8 +239,10 @@ class GraphedCycle:
             self.graph.register_generator_state(learner._gen)
         # the warm-up cycles run for real (an update inside `body` moves the parameters): snapshot and restore around them, so a
         # graphed run starts from the state an eager run starts from
+        learner.optimizer.sync_lr()      # a learning rate the scheduler moved since the last sync is part of the snapshot, not undone by it
         state = (learner.flat.flat, learner.flat_target, learner.optimizer.m, learner.optimizer.v, learner.optimizer.hyper)
         snap = [t.clone() for t in state]
+        rng = _RngSnapshot(learner)      # the warm-up's epsilon draws and DiscreteComm noise steps are undone as well
         side = th.cuda.Stream()
         side.wait_stream(th.cuda.current_stream())
         with th.cuda.stream(side):
@@ -227,12 +250,12 @@ class GraphedCycle:
                 body()
         th.cuda.current_stream().wait_stream(side)
         learner.invalidate_weight_cache()
-        learner.optimizer.sync_lr()
         with _capture(self.graph):
             self.out = body()
         th.cuda.synchronize()
         for dst, src in zip(state, snap):
             dst.copy_(src)
+        rng.restore()
         learner.invalidate_weight_cache()
 
     def __call__(self):

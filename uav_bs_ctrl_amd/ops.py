@@ -737,6 +737,7 @@ class _LinearReLU(th.autograd.Function):
         n, C = dy.shape
         if (RELU_BWD_FUSED and ctx.needs_input_grad[2] and dy.is_cuda and dy.dtype == th.float32 and y.dtype == th.float32 and n > 0
                 and C % 4 == 0 and dy.stride(1) == 1 and y.stride(1) == 1 and dy.stride(0) % 4 == 0 and y.stride(0) % 4 == 0
+                and dy.stride(0) >= C and y.stride(0) >= C      # a row-broadcast gradient (stride 0) takes the torch path below
                 and dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0):
             # the mask and the bias gradient in ONE pass over the gradient (csrc/colsum.hip): autograd's threshold_backward + sum
             # are two (5.1 + 1.7 GB per C3 update on the time-batched encoder)
@@ -959,7 +960,6 @@ def time_split(x_all, T1):
 
 
 MSG_FUSED = os.environ.get("UAVGNN_MSG_FUSED", "1") != "0"   # K3a + K3b in one launch (csrc/tarmac_msg.hip); A/B switch
-MSG_VARIANT = 16 if os.environ.get("UAVGNN_MSG_PAIR", "1") == "0" else 0   # 16: one wavefront per row tile (A/B reference of the pair kernel)
 
 
 def _tarmac_msg_plan(x, h, Wp, bp, M, K, env, N, H):
@@ -984,9 +984,9 @@ def _tarmac_msg_plan(x, h, Wp, bp, M, K, env, N, H):
 def _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, c_ptr, ld_c, a_save, proj, ld_p, x_copy, ld_xc, planes=None):
     tiles, n_ag = msg
     with KERNEL_TIMER.span("tarmac_msg_fwd", (N, H, M, K, int(proj is not None), int(x_copy is not None))):
-        rc = L.lib().uavgnn_tarmac_msg_fwd_dbg(x.data_ptr(), x.stride(0), h.data_ptr(), h.stride(0), N, H, n_ag, tiles.data_ptr(),
-                                               bp.data_ptr(), M, K, L.ptr(talk_off), L.ptr(talk_src), 1.0 / K, c_ptr, ld_c, a_save, proj,
-                                               ld_p, x_copy, ld_xc, L.ptr(planes), MSG_VARIANT, L.stream())
+        rc = L.lib().uavgnn_tarmac_msg_fwd(x.data_ptr(), x.stride(0), h.data_ptr(), h.stride(0), N, H, n_ag, tiles.data_ptr(),
+                                           bp.data_ptr(), M, K, L.ptr(talk_off), L.ptr(talk_src), 1.0 / K, c_ptr, ld_c, a_save, proj,
+                                           ld_p, x_copy, ld_xc, L.ptr(planes), L.stream())
     L.check(rc, "uavgnn_tarmac_msg_fwd")
 
 
