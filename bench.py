@@ -836,6 +836,24 @@ def main():
     barrier()
     instr_s = time.perf_counter() - t_i
     kfull = ops.KERNEL_TIMER.summary()
+    gc.enable()
+    ops.KERNEL_TIMER.enabled = False
+    el = th.tensor([elapsed], device=device, dtype=th.float64)
+    if use_dist:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el)
+    loss = float(out["LossQ"])
+    ck = params_checksum(learner.policy_net)
+    if use_dist:   # replicas must stay bit-identical
+        lo, hi = ck.clone(), ck.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(th.equal(lo, hi))
+        assert replicas_identical, "parameter replicas diverged"
+    else:
+        replicas_identical = True
+
+    # (behind the loss / parameter checksum of the TIMED steps: the leg's own updates move the parameters further)
     graphed_leg = None
     if want_graphed:
         from uav_bs_ctrl_amd.graphs import GraphedCycle
@@ -865,23 +883,6 @@ def main():
                                "holds the stored batch's topology (edge counts, derived indices); a loop fed fresh observations replays a "
                                "cycle only over capacity-sized static graphs (graph.from_padded_obs(static=True), as GraphedAct / "
                                "GraphedUpdate do) - hence a separate figure, never `value`"}
-    gc.enable()
-    ops.KERNEL_TIMER.enabled = False
-    el = th.tensor([elapsed], device=device, dtype=th.float64)
-    if use_dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el)
-    loss = float(out["LossQ"])
-    ck = params_checksum(learner.policy_net)
-    if use_dist:   # replicas must stay bit-identical
-        lo, hi = ck.clone(), ck.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        replicas_identical = bool(th.equal(lo, hi))
-        assert replicas_identical, "parameter replicas diverged"
-    else:
-        replicas_identical = True
-
     if rank == 0:
         env_steps = world * a.B * a.T * a.steps
         # SURVEY 8d names: C3 = BASELINE configs[2] (8 x 80, B = 4096); anything else is labelled by its own sizes
@@ -929,15 +930,21 @@ def main():
         kc = kfull.get("gru_cell_fwd")
         if kc and kc["work"]:
             fl = sum(2.0 * N * 3 * H * (K_in + H) for (N, K_in, H, _) in kc["work"])       # fp32-equivalent FLOP
-            x3 = all(w[3] == "bf16x3" for w in kc["work"])
+            kinds = {w[3] for w in kc["work"]}
+            x3, h2 = kinds == {"bf16x3"}, kinds == {"f16x2"}
             tf = fl / (kc["total_ms"] * 1e-3) / 1e12
-            sec.append({"kernel": "gru_cell_fwd_x3w8_kernel + split_planes_kernel (K4, whole GRU cell)" if x3 else
-                                  "gru_cell_fwd_kernel (K4, whole GRU cell, fp32 MFMA)",
+            mult = 6.0 if x3 else 3.0 if h2 else 1.0          # 16-bit MFMA products per fp32 product
+            sec.append({"kernel": ("gru_cell_fwd_h2_kernel + split_planes_h2_kernel (K4, whole GRU cell; f16x2: exactly scaled two-term f16 splits, "
+                                   "row maxima from the message kernel)" if h2 else
+                                   "gru_cell_fwd_x3w8_kernel + split_planes_kernel (K4, whole GRU cell)" if x3 else
+                                   "gru_cell_fwd_kernel (K4, whole GRU cell, fp32 MFMA)" if kinds == {"f32"} else
+                                   "GRU cell, mixed kernels: " + ", ".join(sorted(kinds))),
                         "bound": "mfma", "launches": kc["count"], "avg_launch_ms": kc["avg_ms"],
                         "fp32_equivalent_tflops": tf,
-                        "achieved": 6.0 * tf if x3 else tf, "peak": BF16_PEAK_TFLOPS if x3 else FP32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s (bf16 MFMA: six products per fp32 product)" if x3 else "TFLOP/s",
-                        "frac": (6.0 * tf / BF16_PEAK_TFLOPS) if x3 else tf / FP32_PEAK_TFLOPS,
+                        "achieved": mult * tf, "peak": BF16_PEAK_TFLOPS if mult > 1 else FP32_PEAK_TFLOPS,
+                        "unit": ("TFLOP/s (f16 MFMA: three products per fp32 product)" if h2 else
+                                 "TFLOP/s (bf16 MFMA: six products per fp32 product)" if x3 else "TFLOP/s"),
+                        "frac": (mult * tf / BF16_PEAK_TFLOPS) if mult > 1 else tf / FP32_PEAK_TFLOPS,
                         "share_of_step": kc["total_ms"] / (1e3 * instr_s)})
         kg = kfull.get("gemm_x3")
         if kg and kg["work"]:
@@ -976,8 +983,13 @@ def main():
                                      "note": "one extra cycle AFTER the timed steps with HIP events around every C-ABI launch: source of "
                                              "`roofline_secondary` and `kernel_ms_per_launch`.  The timed steps carry events around the "
                                              "graded kernel (`roofline`) only - timing every launch makes the rollout host-bound"}
-        res["arithmetic"] = ("fp32 in / out / accumulate everywhere.  K3b, K5 and all pointwise kernels: fp32 FMA.  The score GEMM of K1 "
-                             "(csrc/gatv2_hetero.hip), the GRU cell (csrc/gru_x3.hip), the dense layers whose output tiles by 128 "
+        res["arithmetic"] = ("fp32 in / out / accumulate everywhere.  K3b, K5 and all pointwise kernels: fp32 FMA.  The GRU cell of the TarMAC "
+                             "step (csrc/gru_h2.hip, round 6): every operand row scaled by an exact power of two into f16's range and "
+                             "split into hi + lo f16 terms (hi + lo = v to <= 2^-23 |v|), each fp32 product the fp32-accumulated sum of 3 "
+                             "exact f16 x f16 MFMA products (dropped term <= 2^-22 |a b|); measured error vs fp64 below the bf16x3 cell's "
+                             "and the vendor fp32 GEMM's on the same data (profiles/r06_h2_probe.txt, r06_h2_error_tables.txt; "
+                             "UAVGNN_GRU_H2=0: the bf16x3 cell).  The score GEMM of K1 "
+                             "(csrc/gatv2_hetero.hip), the other GRU cells (csrc/gru_x3.hip), the dense layers whose output tiles by 128 "
                              "columns (csrc/gemm_x3.hip) and the time-batched encoder weight gradient (csrc/gemm_tn_x3.hip): each "
                              "fp32 operand is split EXACTLY into 3 bf16 terms and each fp32 product is the fp32-accumulated sum of 6 "
                              "exact bf16 x bf16 MFMA products (dropped terms <= 2^-23 |a b|); measured error vs fp64 is BELOW the "

@@ -280,6 +280,14 @@ int uavgnn_tarmac_msg_fwd(const float* x, int ld_x, const float* h, int ld_h, in
                           const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src, float scale,
                           float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p, float* x_copy, int ld_xc,
                           void* planes_out, uavgnn_stream_t stream);
+/* ... that also writes row_absmax [N] = max(|x_row|, |c_row|, |h_row|) per agent - the row scales of uavgnn_gru_cell_fwd_h2 behind it
+ * (every element of x and h passes through this kernel anyway; a maximum is order-independent: deterministic).  Wavefront-pair
+ * kernel only: M + 2K <= 96 (uavgnn_tarmac_msg_rowmax_supported), UAVGNN_EUNSUPPORTED otherwise. */
+int uavgnn_tarmac_msg_rowmax_supported(int H, int M, int K, int n_ag);
+int uavgnn_tarmac_msg_fwd_rowmax(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles,
+                                 const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src, float scale,
+                                 float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p, float* x_copy, int ld_xc,
+                                 float* row_absmax, uavgnn_stream_t stream);
 /* ... with a variant word: bits 0-3 are timing ablations of tools/msg_probe.py (parts of the GEMM loop skipped: the outputs are then
  * WRONG); bit 4 (16) selects the one-wavefront-per-row-tile kernel where uavgnn_tarmac_msg_fwd runs the wavefront-pair kernel (no
  * planes_out, M + 2K <= 96) - correct results, the A/B reference; the two kernels sum the x and h halves of the projection in
@@ -390,6 +398,29 @@ int uavgnn_gru_cell_fwd_x3_cat(const float* inp, int ld_inp, int K1, const float
 int uavgnn_gru_cell_fwd_x3_opts(const float* inp, int ld_inp, int K1, const float* inp2, int ld_inp2, int K2, const float* h,
                                 int N, int H, const void* planes, const float* b_ih, const float* b_hh, float* h_out,
                                 float* pre_save, int flags, uavgnn_stream_t stream);
+/* The same cell with HALF the matrix-core work (csrc/gru_h2.hip, round 6): "f16x2" - every row of the activation operand
+ * [inp || inp2 || h] and every output unit's row of [W_ih | W_hh] is scaled by a power of two that puts its largest magnitude into
+ * [2^14, 2^15) (exact), the scaled value is split as hi = rn_f16(v), lo = rn_f16(v - hi) (hi + lo = v to <= 2^-23 |v|), and an fp32
+ * product is the fp32-accumulated sum of THREE f16 x f16 MFMA products (hi lo + lo hi + hi hi; the dropped lo lo <= 2^-22 |a b|),
+ * un-scaled exactly in the epilogue.  fp32 in / out / accumulate; measured error against float64 at or below the vendor fp32 GEMM's
+ * and the bf16x3 cell's (profiles/r06_h2_error_tables.txt).  Replaces nn.GRUCell at gnn_agents.py:246 exactly like
+ * uavgnn_gru_cell_fwd_x3_cat.
+ *   row_absmax [N]   an upper bound of max |.| over every row of [inp || inp2 || h], tight to within its power of two:
+ *                    uavgnn_tarmac_msg_fwd_rowmax writes it on its way (the producer of `c`), uavgnn_row_absmax computes it in a pass
+ *                    of its own.  A bound that is too SMALL overflows f16: the row's outputs are NaN, never a plausible number;
+ *   planes           uavgnn_gru_split_weights_h2: f16 planes [2][3H][K_in] | [2][3H][H] | 2^-e per weight row (float [3H]),
+ *                    uavgnn_gru_cell_h2_workspace_bytes bytes, 16-byte aligned; rebuilt whenever the weights may have changed.
+ * Non-finite operands follow the bf16x3 kernels' contract (a row that holds Inf / NaN yields NaN outputs); rows whose largest
+ * magnitude is below 2^-112 lose relative precision (the scale exponent is clamped to 126).  Same shape limits as the x3 cell. */
+int uavgnn_gru_cell_h2_supported(int K_in, int H);   /* K_in % 32 == 0 and H % 64 == 0 */
+long long uavgnn_gru_cell_h2_workspace_bytes(int K_in, int H);
+int uavgnn_gru_split_weights_h2(const float* W_ih, int K_in, const float* W_hh, int H, void* planes, uavgnn_stream_t stream);
+int uavgnn_gru_cell_fwd_h2(const float* inp, int ld_inp, int K1, const float* inp2, int ld_inp2, int K2, const float* h, int N, int H,
+                           const float* row_absmax, const void* planes, const float* b_ih, const float* b_hh, float* h_out,
+                           float* pre_save, uavgnn_stream_t stream);
+/* out [N] = max |.| per row over up to three row-major pieces (a2 / a3 may be NULL); Inf when the row holds Inf or NaN. */
+int uavgnn_row_absmax(const float* a1, int ld1, int K1, const float* a2, int ld2, int K2, const float* a3, int ld3, int K3, int N,
+                      float* out, uavgnn_stream_t stream);
 /* The same cell from PREPARED operand planes (csrc/gru_x3p.hip): bit-identical results to uavgnn_gru_cell_fwd_x3 with no operand
  * split inside the kernel - staging a K slice is a linear LDS-DMA copy.  `planes`: the operand [inp || h] of the N rows as bf16
  * plane tiles, written by uavgnn_tarmac_msg_fwd (planes_out; K_in = H + M there); `h`: the same hidden state in fp32 (read by the

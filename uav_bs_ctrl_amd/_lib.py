@@ -111,6 +111,15 @@ SIGNATURES = {
                                             _c_fp, _c_fp, _c_st]),
     "uavgnn_gru_cell_fwd_x3_opts": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_fp,
                                              _c_fp, _c_fp, _c_int, _c_st]),
+    "uavgnn_gru_cell_h2_supported": (_c_int, [_c_int, _c_int]),
+    "uavgnn_gru_cell_h2_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
+    "uavgnn_gru_split_weights_h2": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, ctypes.c_void_p, _c_st]),
+    "uavgnn_gru_cell_fwd_h2": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, ctypes.c_void_p, _c_fp,
+                                        _c_fp, _c_fp, _c_fp, _c_st]),
+    "uavgnn_row_absmax": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_fp, _c_st]),
+    "uavgnn_tarmac_msg_rowmax_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
+    "uavgnn_tarmac_msg_fwd_rowmax": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_int, _c_int,
+                                              _c_ip, _c_ip, _c_f32, _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_fp, _c_int, _c_fp, _c_st]),
     "uavgnn_gru_weight_tiles_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
     "uavgnn_gru_split_weight_tiles": (_c_int, [_c_fp, _c_int, _c_fp, _c_int, ctypes.c_void_p, _c_st]),
     "uavgnn_gru_cell_fwd_planes": (_c_int, [ctypes.c_void_p, _c_int, _c_fp, _c_int, _c_int, ctypes.c_void_p, _c_fp, _c_fp, _c_fp, _c_fp,

@@ -385,13 +385,17 @@ __global__ __launch_bounds__(kMsgThreads, CT == 8 ? 2 : 3) void tarmac_msg_fwd_k
 // hide each other's waits; a weight stage in LDS holds the x slice t AND the h slice t.  The h partial is added to the tile in
 // LDS, then the first wavefront of the pair runs the attention while the second writes `proj` (training).  The sum is
 // (x part + bias) + h part - the order of the two-GEMM path of rounds 1-4 -, not the single 16-slice chain of the kernel above.
-template <int CT, bool TRAIN>
+// RM: max(|x_row|, |c_row|, |h_row|) per agent is written to `row_absmax` - the row scales of the f16x2 GRU cell (csrc/gru_h2.hip); every
+// element of x and h passes through this kernel's registers anyway and c is made here (order-independent: deterministic).
+template <int CT, bool TRAIN, bool RM = false>
 __global__ __launch_bounds__(2 * kMsgThreads, 4) void tarmac_msg_fwd_k2_kernel(
     const float* __restrict__ x, int ld_x, const float* __restrict__ h, int ld_h, int N, int H, int n_ag,
     const u32x4* __restrict__ Wt, const float* __restrict__ bias, int M, int K, const int32_t* __restrict__ talk_off,
     const int32_t* __restrict__ talk_src, float scale, float* __restrict__ c_out, int ld_c, float* __restrict__ a_save,
-    float* __restrict__ proj_out, int ld_p, float* __restrict__ x_copy, int ld_xc) {
+    float* __restrict__ proj_out, int ld_p, float* __restrict__ x_copy, int ld_xc, float* __restrict__ row_absmax = nullptr) {
   constexpr int kThreads = 2 * kMsgThreads;
+  __shared__ float sRowMax[kMsgWaves][2][16];   // RM: per row tile, max |x| (first wavefront of the pair) and max |h| (second)
+  float amax = 0.f;
   constexpr int RP = 16 * CT;
   constexpr int BCH = 3 * RP * 4;                   // 16-byte chunks of one weight slice (3 planes)
   constexpr int BPT = (2 * BCH + kThreads - 1) / kThreads;
@@ -459,6 +463,11 @@ __global__ __launch_bounds__(2 * kMsgThreads, 4) void tarmac_msg_fwd_k2_kernel(
   if ((T) < nsx) {                                                                                   \
     const int t_ = (T);                                                                              \
     const Planes8 pa = split8(LO, HI);                                                               \
+    if (RM) {                                                                                        \
+      amax = fmaxf(fmaxf(amax, fabsf(LO.x)), fmaxf(fabsf(LO.y), fabsf(LO.z)));                        \
+      amax = fmaxf(fmaxf(amax, fabsf(LO.w)), fmaxf(fabsf(HI.x), fabsf(HI.y)));                        \
+      amax = fmaxf(fmaxf(amax, fabsf(HI.z)), fabsf(HI.w));                                           \
+    }                                                                                                \
     if (TRAIN && half == 0 && x_copy != nullptr && row < N) {   /* the x half of [x || c] */        \
       float* d = x_copy + static_cast<size_t>(row) * ld_xc + 32 * t_ + 4 * g;                        \
       *reinterpret_cast<float4*>(d) = LO;                                                            \
@@ -486,6 +495,11 @@ __global__ __launch_bounds__(2 * kMsgThreads, 4) void tarmac_msg_fwd_k2_kernel(
   // ---- the pair's tile in LDS: (x part + bias) by the first wavefront, + h part by the second ------------------------------
   float* __restrict__ P = reinterpret_cast<float*>(smem_raw) + tile * (16 * LDP + kScratch);
   const int ncol = M + 2 * K;
+  if (RM) {   // lane (j, g) holds the maximum over its k of row j: combine the four lane groups
+    amax = fmaxf(amax, __shfl_xor(amax, 16));
+    amax = fmaxf(amax, __shfl_xor(amax, 32));
+    if (g == 0) sRowMax[tile][half][j] = amax;
+  }
   if (half == 0) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -605,6 +619,13 @@ __global__ __launch_bounds__(2 * kMsgThreads, 4) void tarmac_msg_fwd_k2_kernel(
     float* d = c_out + static_cast<size_t>(row0 + r) * ld_c;
     for (int ch = lane; ch < M; ch += kWave) d[ch] = P[r * LDP + ch];
   }
+  if (RM) {   // lane (part g, row j): a quarter of row j's message, then the four parts and the maxima of x and h (NaN messages of a
+    float cm = 0.f;   // poisoned tile: fmaxf drops them, the cell turns the NaN elements themselves into NaN outputs)
+    for (int ch = g; ch < M; ch += 4) cm = fmaxf(cm, fabsf(P[j * LDP + ch]));
+    cm = fmaxf(cm, __shfl_xor(cm, 16));
+    cm = fmaxf(cm, __shfl_xor(cm, 32));
+    if (g == 0 && row < N) row_absmax[row] = fmaxf(cm, fmaxf(sRowMax[tile][0][j], sRowMax[tile][1][j]));
+  }
 }
 
 }  // namespace
@@ -652,6 +673,11 @@ extern "C" int uavgnn_tarmac_msg_prepare(const float* Wp, int ld, int H, int M, 
 // planes_out: NULL or uavgnn_tarmac_msg_planes_bytes(N, H, M) bytes.  Every graph has exactly n_ag agents (N % n_ag == 0; 16 %
 // n_ag == 0, so no graph straddles two 16-row tiles); the rows of a tile have at most 256 in-edges, all from rows of the same tile -
 // a violating tile gets NaN messages, never a silent fallback.
+static int msg_launch(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles, const float* bias, int M,
+                      int K, const int32_t* talk_off, const int32_t* talk_src, float scale, float* c_out, int ld_c, float* a_save,
+                      float* proj_out, int ld_p, float* x_copy, int ld_xc, void* planes_out, float* row_absmax, int dbg,
+                      uavgnn_stream_t stream);
+
 // dbg: bits 0-3 are timing ablations of tools/msg_probe.py (results are WRONG when any is set): bit 0 no weight-slice traffic
 // after the first two slices, bit 1 no MFMAs, bit 2 no activation loads after the first four slices, bit 3 no workgroup barriers;
 // bit 4 (16) selects the one-wavefront-per-row-tile kernel where the default is the wavefront-pair kernel (no planes, M + 2K <=
@@ -660,6 +686,14 @@ extern "C" int uavgnn_tarmac_msg_fwd_dbg(const float* x, int ld_x, const float* 
                                          const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src,
                                          float scale, float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p,
                                          float* x_copy, int ld_xc, void* planes_out, int dbg, uavgnn_stream_t stream) {
+  return msg_launch(x, ld_x, h, ld_h, N, H, n_ag, tiles, bias, M, K, talk_off, talk_src, scale, c_out, ld_c, a_save, proj_out, ld_p, x_copy,
+                    ld_xc, planes_out, nullptr, dbg, stream);
+}
+
+static int msg_launch(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles, const float* bias, int M,
+                      int K, const int32_t* talk_off, const int32_t* talk_src, float scale, float* c_out, int ld_c, float* a_save,
+                      float* proj_out, int ld_p, float* x_copy, int ld_xc, void* planes_out, float* row_absmax, int dbg,
+                      uavgnn_stream_t stream) {
   if (N < 0 || !x || !h || !tiles || !bias || !talk_off || !c_out || ld_x < H || ld_h < H || ld_c < M) return UAVGNN_EINVAL;
   if (proj_out && ld_p < M + 2 * K) return UAVGNN_EINVAL;
   if (x_copy && ld_xc < H) return UAVGNN_EINVAL;
@@ -691,18 +725,25 @@ extern "C" int uavgnn_tarmac_msg_fwd_dbg(const float* x, int ld_x, const float* 
     else if (ct <= 6) UAVGNN_MSG_BY_FLAGS(NA_, 6)                        \
     else UAVGNN_MSG_BY_FLAGS(NA_, 8)                                     \
   }
+  if (row_absmax != nullptr && (planes || ct > 6 || (dbg & 31))) return UAVGNN_EUNSUPPORTED;   // written by the wavefront-pair kernel only
   if (!planes && ct <= 6 && !(dbg & 31)) {
     // two wavefronts per row tile (73 KB of LDS at six column tiles: two workgroups per CU; eight column tiles would be one)
     const dim3 block2(2 * kMsgThreads);
-#define UAVGNN_MSG_K2(CT_, TR_)                                                                                               \
-  hipLaunchKernelGGL((tarmac_msg_fwd_k2_kernel<CT_, TR_>), grid, block2, 0, st, x, ld_x, h, ld_h, N, H, n_ag, Wt, bias, M, K, \
-                     talk_off, talk_src, scale, c_out, ld_c, a_save, proj_out, ld_p, x_copy, ld_xc)
+#define UAVGNN_MSG_K2(CT_, TR_)                                                                                                        \
+  {                                                                                                                                    \
+    if (row_absmax != nullptr)                                                                                                         \
+      hipLaunchKernelGGL((tarmac_msg_fwd_k2_kernel<CT_, TR_, true>), grid, block2, 0, st, x, ld_x, h, ld_h, N, H, n_ag, Wt, bias, M, K, \
+                         talk_off, talk_src, scale, c_out, ld_c, a_save, proj_out, ld_p, x_copy, ld_xc, row_absmax);                   \
+    else                                                                                                                               \
+      hipLaunchKernelGGL((tarmac_msg_fwd_k2_kernel<CT_, TR_, false>), grid, block2, 0, st, x, ld_x, h, ld_h, N, H, n_ag, Wt, bias, M, K, \
+                         talk_off, talk_src, scale, c_out, ld_c, a_save, proj_out, ld_p, x_copy, ld_xc, nullptr);                      \
+  }
     if (ct <= 4) {
-      if (train) UAVGNN_MSG_K2(4, true);
-      else UAVGNN_MSG_K2(4, false);
+      if (train) UAVGNN_MSG_K2(4, true)
+      else UAVGNN_MSG_K2(4, false)
     } else {
-      if (train) UAVGNN_MSG_K2(6, true);
-      else UAVGNN_MSG_K2(6, false);
+      if (train) UAVGNN_MSG_K2(6, true)
+      else UAVGNN_MSG_K2(6, false)
     }
 #undef UAVGNN_MSG_K2
     return launch_status();
@@ -712,6 +753,21 @@ extern "C" int uavgnn_tarmac_msg_fwd_dbg(const float* x, int ld_x, const float* 
 #undef UAVGNN_MSG_BY_FLAGS
 #undef UAVGNN_MSG_LAUNCH
   return launch_status();
+}
+
+// ... that also writes row_absmax [N] = max(|x_row|, |c_row|, |h_row|): the row scales of uavgnn_gru_cell_fwd_h2.  M + 2K <= 96, no
+// planes_out (UAVGNN_EUNSUPPORTED otherwise: the caller runs uavgnn_tarmac_msg_fwd and the bf16x3 cell)
+extern "C" int uavgnn_tarmac_msg_rowmax_supported(int H, int M, int K, int n_ag) {
+  return (uavgnn_tarmac_msg_supported(H, M, K, n_ag) && (M + 2 * K + 15) / 16 <= 6) ? 1 : 0;
+}
+
+extern "C" int uavgnn_tarmac_msg_fwd_rowmax(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles,
+                                            const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src,
+                                            float scale, float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p,
+                                            float* x_copy, int ld_xc, float* row_absmax, uavgnn_stream_t stream) {
+  if (!row_absmax) return UAVGNN_EINVAL;
+  return msg_launch(x, ld_x, h, ld_h, N, H, n_ag, tiles, bias, M, K, talk_off, talk_src, scale, c_out, ld_c, a_save, proj_out, ld_p, x_copy,
+                    ld_xc, nullptr, row_absmax, 0, stream);
 }
 
 extern "C" int uavgnn_tarmac_msg_fwd(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles,

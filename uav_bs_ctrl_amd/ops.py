@@ -332,6 +332,9 @@ def gru_cell_supported(inp, h) -> bool:
 
 
 GRU_X3 = os.environ.get("UAVGNN_GRU_X3", "1") != "0"   # the cell's GEMMs as bf16x3 splits on the bf16 matrix cores (csrc/gru_x3.hip)
+# ... as exactly scaled two-term f16 splits, three products per fp32 product (csrc/gru_h2.hip), where the producer of the cell's input
+# hands over the row maxima (the TarMAC step); UAVGNN_GRU_H2=0: the bf16x3 cell everywhere (A/B)
+GRU_H2 = os.environ.get("UAVGNN_GRU_H2", "1") != "0"
 
 # bf16 planes of weight matrices (and the parameter image of the fused K1 forward), reused ONLY inside a `frozen_weights()`
 # scope.  A drop-in module's weights may change behind any cache (`.data` writes bump no version counter), so by default every
@@ -404,13 +407,35 @@ def gru_cell_two_piece_supported(x, c, h) -> bool:
                 and 4 * x.shape[0] * max(x.stride(0), c.stride(0), H) < 2 ** 32)
 
 
-def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save, inp2=None, h2_out=None):
+def gru_cell_h2_supported(K_in, H, N, ld_max) -> bool:
+    """The f16x2 cell (csrc/gru_h2.hip) covers this call - given a `row_absmax` from the kernel that produced the input."""
+    return bool(GRU_H2 and GRU_X3 and N >= GRU_FUSED_MIN_ROWS and L.lib().uavgnn_gru_cell_h2_supported(K_in, H)
+                and 4 * N * max(ld_max, H) < 2 ** 32)
+
+
+def _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save, inp2=None, h2_out=None, rowmax=None):
     """h' (and the [N, 4H] pre-activation sets when `save`) of the fused GRU cell.  inp2: second piece of the input
     ([inp || inp2] is what W_ih multiplies; the caller checked gru_cell_two_piece_supported).  h2_out: contiguous [N, H]
-    buffer h' is written into (a slot of the time-batched staging of a BPTT sequence)."""
+    buffer h' is written into (a slot of the time-batched staging of a BPTT sequence).  rowmax [N]: max |.| over every row of
+    [inp || inp2 || h], written by the kernel that produced the input (the fused TarMAC message launch) - selects the f16x2 cell
+    (csrc/gru_h2.hip: half the matrix-core work of the bf16x3 cell; the caller checked gru_cell_h2_supported)."""
     N, H = h.shape
     h2 = th.empty_like(h) if h2_out is None else h2_out
     pre = th.empty((N, 4 * H), dtype=th.float32, device=h.device) if save else None
+    if rowmax is not None:
+        lib, K1, K2 = L.lib(), inp.shape[1], (0 if inp2 is None else inp2.shape[1])
+        K_in = K1 + K2
+        with KERNEL_TIMER.span("gru_cell_fwd", (N, K_in, H, "f16x2")):
+            planes = _cached_planes(("gruh2", W_ih.data_ptr(), W_hh.data_ptr(), W_ih._version, W_hh._version, K_in, H),
+                                    lib.uavgnn_gru_cell_h2_workspace_bytes(K_in, H), h.device,
+                                    lambda p: L.check(lib.uavgnn_gru_split_weights_h2(W_ih.data_ptr(), K_in, W_hh.data_ptr(), H,
+                                                                                      p.data_ptr(), L.stream()),
+                                                      "uavgnn_gru_split_weights_h2"), keep=(W_ih, W_hh))
+            rc = lib.uavgnn_gru_cell_fwd_h2(inp.data_ptr(), inp.stride(0), K1, L.ptr(inp2), 0 if inp2 is None else inp2.stride(0), K2,
+                                            h.data_ptr(), N, H, rowmax.data_ptr(), planes.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(),
+                                            h2.data_ptr(), L.ptr(pre), L.stream())
+        L.check(rc, "uavgnn_gru_cell_fwd_h2")
+        return h2, pre
     if inp2 is not None or (GRU_X3 and L.lib().uavgnn_gru_cell_x3_supported(inp.shape[1], H)
                             and 4 * N * max(inp.stride(0), H) < 2 ** 32):   # 32-bit byte offsets inside the kernel (3.3 M rows at K_in = 320)
         lib, K1, K2 = L.lib(), inp.shape[1], (0 if inp2 is None else inp2.shape[1])
@@ -475,10 +500,10 @@ class _GruCellFused(th.autograd.Function):
     """nn.GRUCell as ONE forward launch (K4); backward = gate kernel on the saved pre-activations + vendor GEMMs."""
 
     @staticmethod
-    def forward(ctx, inp, h, W_ih, b_ih, W_hh, b_hh, train):
+    def forward(ctx, inp, h, W_ih, b_ih, W_hh, b_hh, train, rowmax=None):
         inp, h = L.f32c(inp), L.f32c(h)
         p = [L.f32c(t.detach()) for t in (W_ih, b_ih, W_hh, b_hh)]
-        h2, pre = _gru_cell_launch(inp, h, *p, save=bool(train))
+        h2, pre = _gru_cell_launch(inp, h, *p, save=bool(train), rowmax=rowmax)
         ctx.have_pre = bool(train)
         if train:
             ctx.save_for_backward(inp, h, pre, p[0], p[2])
@@ -499,17 +524,34 @@ class _GruCellFused(th.autograd.Function):
         gbih = _colsum(d_gi) if ctx.needs_input_grad[3] else None
         gWhh = _wgrad(d_gh, h) if ctx.needs_input_grad[4] else None
         gbhh = _colsum(d_gh) if ctx.needs_input_grad[5] else None
-        return d_inp, dh, gWih, gbih, gWhh, gbhh, None
+        return d_inp, dh, gWih, gbih, gWhh, gbhh, None, None
 
 
-def gru_cell(inp, h, cell):
+def row_absmax(*pieces):
+    """[N] = max |.| per row over up to three row-major fp32 matrices with N rows each (Inf for a row that holds Inf / NaN): the
+    `rowmax` of the f16x2 GRU cell for callers whose producer does not hand it over (one extra pass over the operand)."""
+    ps = [L.f32c(t) for t in pieces]
+    N = ps[0].shape[0]
+    out = th.empty(N, dtype=th.float32, device=ps[0].device)
+    args = []
+    for i in range(3):
+        t = ps[i] if i < len(ps) else None
+        args += [L.ptr(t), 0 if t is None else t.stride(0), 0 if t is None else t.shape[1]]
+    L.check(L.lib().uavgnn_row_absmax(*args, N, out.data_ptr(), L.stream()), "uavgnn_row_absmax")
+    return out
+
+
+def gru_cell(inp, h, cell, rowmax=None):
     """nn.GRUCell(inp, h) with `cell`'s parameters: fused kernel when the shape has an instantiation, else vendor GEMMs +
-    the gate kernel."""
+    the gate kernel.  rowmax [N] (``row_absmax(inp, h)`` or a producer's): the f16x2 cell where it covers the shape."""
     if gru_cell_supported(inp, h):
         # ANY differentiable input makes autograd run the backward, which reads the saved [N, 4H] pre-activation sets
         train = th.is_grad_enabled() and any(t.requires_grad for t in (inp, h, cell.weight_ih, cell.bias_ih,
                                                                        cell.weight_hh, cell.bias_hh))
-        return _GruCellFused.apply(inp, h, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, train)
+        if rowmax is not None and not (GRU_H2 and GRU_X3 and L.lib().uavgnn_gru_cell_h2_supported(inp.shape[1], h.shape[1])
+                                       and 4 * inp.shape[0] * max(inp.stride(0), h.shape[1]) < 2 ** 32):
+            rowmax = None
+        return _GruCellFused.apply(inp, h, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, train, rowmax)
     gi = linear(inp, cell.weight_ih, cell.bias_ih)
     gh = linear(h, cell.weight_hh, cell.bias_hh)
     return gru_gates(gi, gh, h)
@@ -981,8 +1023,17 @@ def _tarmac_msg_plan(x, h, Wp, bp, M, K, env, N, H):
     return tiles, n_ag
 
 
-def _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, c_ptr, ld_c, a_save, proj, ld_p, x_copy, ld_xc, planes=None):
+def _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, c_ptr, ld_c, a_save, proj, ld_p, x_copy, ld_xc, planes=None,
+                       rowmax=None):
+    """rowmax [N] (optional): receives max(|x_row|, |c_row|, |h_row|) - the row scales of the f16x2 GRU cell behind this launch."""
     tiles, n_ag = msg
+    if rowmax is not None:
+        with KERNEL_TIMER.span("tarmac_msg_fwd", (N, H, M, K, int(proj is not None), int(x_copy is not None))):
+            rc = L.lib().uavgnn_tarmac_msg_fwd_rowmax(x.data_ptr(), x.stride(0), h.data_ptr(), h.stride(0), N, H, n_ag, tiles.data_ptr(),
+                                                      bp.data_ptr(), M, K, L.ptr(talk_off), L.ptr(talk_src), 1.0 / K, c_ptr, ld_c, a_save,
+                                                      proj, ld_p, x_copy, ld_xc, rowmax.data_ptr(), L.stream())
+        L.check(rc, "uavgnn_tarmac_msg_fwd_rowmax")
+        return
     with KERNEL_TIMER.span("tarmac_msg_fwd", (N, H, M, K, int(proj is not None), int(x_copy is not None))):
         rc = L.lib().uavgnn_tarmac_msg_fwd(x.data_ptr(), x.stride(0), h.data_ptr(), h.stride(0), N, H, n_ag, tiles.data_ptr(),
                                            bp.data_ptr(), M, K, L.ptr(talk_off), L.ptr(talk_src), 1.0 / K, c_ptr, ld_c, a_save, proj,
@@ -1037,6 +1088,11 @@ class _TarmacStep(th.autograd.Function):
         ld = M + 2 * K
         ctx.seq = ctx.seq_t = None
         aligned = all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (W_ih, W_hh))
+        # the f16x2 cell needs the row maxima of [x || c || h]: the fused message launch writes them on its way
+        rowmax = None
+        if (msg is not None and aligned and GRU_FUSED and gru_cell_h2_supported(H + M, H, N, max(x.stride(0), H + M))
+                and H % 32 == 0 and M % 32 == 0 and L.lib().uavgnn_tarmac_msg_rowmax_supported(H, M, K, msg[1])):
+            rowmax = th.empty(N, dtype=th.float32, device=x.device)
         c_only = None
         if not train and aligned and h.shape[0] >= GRU_FUSED_MIN_ROWS and GRU_FUSED:
             c_only = th.empty((N, M), dtype=th.float32, device=x.device)
@@ -1046,11 +1102,12 @@ class _TarmacStep(th.autograd.Function):
             # no-grad call (rollout, target network): nothing keeps [x || c] for a backward, so K3b writes c alone and the cell
             # reads its input from the two buffers - the 2 x 4 H bytes per agent of the concatenating copy disappear
             if msg is not None:
-                _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, c_only.data_ptr(), M, None, None, 0, None, 0)
+                _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, c_only.data_ptr(), M, None, None, 0, None, 0,
+                                   rowmax=rowmax)
             else:
                 _launch_talk_fwd(env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld, K, M,
                                  talk_off, talk_src, N, 1.0 / K, c_only.data_ptr(), M, a_save.data_ptr(), None, 0, 0)
-            h2, _ = _gru_cell_launch(x, h, W_ih, b_ih, W_hh, b_hh, save=False, inp2=c_only)
+            h2, _ = _gru_cell_launch(x, h, W_ih, b_ih, W_hh, b_hh, save=False, inp2=c_only, rowmax=rowmax)
             inp, fused = c_only, True
             gi = gh = h2                                           # placeholders keep save_for_backward's arity
         else:
@@ -1076,7 +1133,7 @@ class _TarmacStep(th.autograd.Function):
             if msg is not None:     # proj, the attention weights and the x half of [x || c] are the launch's training outputs
                 proj = th.empty((N, ld), dtype=th.float32, device=x.device)
                 _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(),
-                                   proj.data_ptr(), ld, inp.data_ptr(), H + M)
+                                   proj.data_ptr(), ld, inp.data_ptr(), H + M, rowmax=rowmax)
             else:
                 _launch_talk_fwd(env, proj.data_ptr() + 4 * M, ld, proj.data_ptr() + 4 * (M + K), ld, proj.data_ptr(), ld, K, M,
                                  talk_off, talk_src, N, 1.0 / K, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(), x.data_ptr(),
@@ -1084,7 +1141,7 @@ class _TarmacStep(th.autograd.Function):
             fused = gru_cell_supported(inp, h) and aligned
             if fused:      # K4 in one launch: gi / gh never reach HBM; training forwards keep the [N, 4H] pre-activation sets
                 h2, pre = _gru_cell_launch(inp, h, W_ih, b_ih, W_hh, b_hh, save=bool(train),
-                                           h2_out=None if seq is None else seq.slot("h", seq_t + 1, H, extra=1))
+                                           h2_out=None if seq is None else seq.slot("h", seq_t + 1, H, extra=1), rowmax=rowmax)
                 if seq is not None and pre is not None:
                     ctx.seq, ctx.seq_t = seq, seq_t
                 gi = gh = pre if pre is not None else h2           # placeholders keep save_for_backward's arity
