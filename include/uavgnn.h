@@ -229,6 +229,31 @@ int uavgnn_eps_greedy_dev(const float* q, int ld_q, int N, int A, int n_agents, 
  * across the BPTT steps in the caller's acc[S, C]; the caller folds the S partials once per update.  Deterministic.
  */
 int uavgnn_colsum_acc(const float* x, long long ld, int N, int C, float* acc, int S, uavgnn_stream_t stream);
+/* ---- dense layers on the f16 matrix cores, exactly scaled two-term splits (csrc/gemm_h2.hip, round 6) -----------------------------
+ * Y = [X (K1 columns) || X2 (K - K1 columns; NULL: one source, K1 = K)] B^T (+ bias) (+ Y) (ReLU): the products of
+ * uavgnn_gemm_nt_x3 / _cat with THREE f16 x f16 MFMA products per fp32 product instead of six bf16 ones (arithmetic, error and
+ * non-finite behaviour: uavgnn_gru_cell_fwd_h2 above).  Replaces the input-gradient halves of the recurrent step and of f_aggr under
+ * loss.backward() (learner.py:157 through gnn_agents.py:246, :99).
+ *   rowmax / rowmax2  per row of the activation operand an upper bound of max |.| over the row (rowmax2 may be NULL; the larger of
+ *                     the two is used), tight to within its power of two, from the kernels that produced the operand:
+ *                     uavgnn_gru_gates_bwd_fused_sums_rowmax (d_gi / d_gh), uavgnn_relu_bwd_colsum_rowmax (masked gradient),
+ *                     uavgnn_row_absmax (anything, as a pass of its own);
+ *   planes            uavgnn_split_h2(W [R, C], transpose): f16 planes [2][n_out][K] + 2^-e per output row (uavgnn_split_h2_bytes(n_out,
+ *                     K) bytes, 16-byte aligned), n_out / K = R / C (transpose = 0: y = x W^T) or C / R (transpose = 1: dx = dy W);
+ *   epilogue          UAVGNN_GEMM_ACCUMULATE, UAVGNN_GEMM_RELU, UAVGNN_GEMM_STAGING_INTERLEAVED (the 256 x 128-tile kernel only:
+ *                     UAVGNN_GEMM_TILE_* are UAVGNN_EUNSUPPORTED). */
+int uavgnn_gemm_h2_supported(int M, int N, int K);
+long long uavgnn_split_h2_bytes(int n_out, int K);
+int uavgnn_split_h2(const float* W, int ld, int R, int C, int transpose, void* planes, uavgnn_stream_t stream);
+int uavgnn_gemm_nt_h2(const float* X, int ldx, int K1, const float* X2, int ldx2, int M, int K, const float* rowmax, const float* rowmax2,
+                      const void* planes, int N, const float* bias, float* Y, int ldy, int epilogue, uavgnn_stream_t stream);
+/* uavgnn_gru_gates_bwd_fused_sums / uavgnn_relu_bwd_colsum that ALSO write row_absmax [N] = max |.| over the rows of d_gi and d_gh /
+ * of `out` (H = 256 / C = 256 only - one wavefront owns a row -, UAVGNN_EUNSUPPORTED otherwise; the second not in place). */
+int uavgnn_gru_gates_bwd_fused_sums_rowmax(const float* pre, const float* h, const float* d_hout, const float* dq, int n_out,
+                                           const float* W_out, int N, int H, float* d_gi, float* d_gh, float* d_h, float* col_sums,
+                                           float* row_absmax, uavgnn_stream_t stream);
+int uavgnn_relu_bwd_colsum_rowmax(const float* dy, long long ld, const float* y, long long ldy, float* out, long long ldo, int N, int C,
+                                  float* acc, int S, float* row_absmax, uavgnn_stream_t stream);
 /* The ReLU backward fused with the bias gradient of the Linear in front of it (reference: f_aggr = Sequential(Linear, ReLU),
  * gnn_agents.py:99-102, under learner.py:157): out [N, C] = dy where y > 0 else 0, acc[S, C] += row-blocked column sums of out
  * (as uavgnn_colsum_acc).  One pass over the gradient instead of autograd's threshold_backward + sum.  C % 4 == 0, strides % 4 == 0,

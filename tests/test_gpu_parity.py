@@ -2718,10 +2718,12 @@ def test_learner_update_at_exp3_sizes_vs_oracle(label, B, n, M, T, dist, monkeyp
     expect = {"uavgnn_gatv2_hetero_fwd_image", "uavgnn_gru_cell_fwd_h2", "uavgnn_tarmac_msg_fwd_rowmax", "uavgnn_head_fwd",
               "uavgnn_gru_gates_bwd_fused_sums", "uavgnn_talk_attn_env_bwd", "uavgnn_gatv2_bwd", "uavgnn_colsum_acc",
               "uavgnn_relu_bwd_colsum"}
-    if N >= 4096:
-        expect |= {"uavgnn_gemm_nt_x3"}
-    if N >= 16384:      # d x of the recurrent step as ONE product over [d_gi || d_proj]: from 128 tiles of 256 x 128
-        expect |= {"uavgnn_gemm_nt_x3_cat"}
+    if N >= 4096:       # f_aggr on the bf16x3 kernel; its input gradient over the (T + 1) N time-batched rows on the f16x2 kernel
+        expect |= {"uavgnn_gemm_nt_x3", "uavgnn_gemm_nt_h2", "uavgnn_relu_bwd_colsum_rowmax"}
+        expect -= {"uavgnn_relu_bwd_colsum"}
+    if N >= 16384:      # d x of the recurrent step as ONE f16x2 product over [d_gi || d_proj] and d h += d_gh W_hh: from 128 tiles of 256 x 128
+        expect |= {"uavgnn_gru_gates_bwd_fused_sums_rowmax", "uavgnn_row_absmax"}
+        expect -= {"uavgnn_gru_gates_bwd_fused_sums"}
     assert expect <= called, f"{label}: production kernels not dispatched: {sorted(expect - called)}"
     # --- oracle, float64.  The loss has two kinds of DISCONTINUITIES, at which an fp32 and a float64 evaluation may legitimately part:
     # the double-Q argmax (learner.py:138) and the ReLU kinks of the encoder (one flipped element of 3 x 10^6 moves a gradient by
@@ -2980,3 +2982,96 @@ def test_tarmac_step_on_the_f16x2_cell_equals_the_bf16x3_step_and_the_message_ke
     for i, (a, b) in enumerate(zip(g1, g0)):
         if a is not None:     # (floor: analytically zero gradients - d f_sign.bias - are rounding noise on both sides)
             assert_close(a, b, 2e-5, f"gradient {i}: f16x2 vs bf16x3 step", floor=1e-6 * scale)
+
+
+@pytest.mark.parametrize("M,K1,K2,N,acc,relu,transpose", [(16384, 768, 0, 256, True, False, True), (16640, 768, 96, 256, False, False, True),
+                                                          (33001, 256, 0, 512, False, True, False), (33000, 64, 32, 128, True, True, True)])
+def test_gemm_f16x2_vs_float64_and_the_other_gemms(M, K1, K2, N, acc, relu, transpose):
+    """csrc/gemm_h2.hip against float64: one and two sources, accumulate / ReLU epilogues, both weight orientations, ragged row
+    tiles; error measured like test_gemm_bf16x3_vs_float64 (|err| / sum_k |a b|) and held to the bf16x3 kernel's and the vendor fp32
+    GEMM's on the same data (gradient-like operands: rows whose magnitudes span six orders)."""
+    import json
+    import os
+    from uav_bs_ctrl_amd import ops
+    gen = th.Generator().manual_seed(M + N + K1)
+    K = K1 + K2
+    a = (th.randn(M, K, generator=gen) * th.exp2(th.randint(-20, 1, (M, 1), generator=gen).float())).cuda()
+    W = (0.1 * th.randn(K, N, generator=gen)).cuda() if transpose else (0.1 * th.randn(N, K, generator=gen)).cuda()
+    bias = None if transpose else (0.1 * th.randn(N, generator=gen)).cuda()
+    y0 = (1e-3 * th.randn(M, N, generator=gen)).cuda() if acc else None
+    B64 = (W.double() if transpose else W.double().t())            # [K, N]
+    ref = a.double() @ B64
+    den = a.double().abs() @ B64.abs()
+    if bias is not None:
+        ref, den = ref + bias.double(), den + bias.double().abs()
+    if acc:
+        ref, den = ref + y0.double(), den + y0.double().abs()
+    if relu:
+        ref = ref.clamp_min(0)
+    a1, a2 = (a[:, :K1].contiguous(), a[:, K1:].contiguous()) if K2 else (a, None)
+    rm1 = ops.row_absmax(a1)
+    rm2 = ops.row_absmax(a2) if K2 else None
+    assert ops.gemm_h2_supported(a1, N, K)
+    if K2:
+        out = ops.gemm_h2(a1, W[:K1], rm1, True, out=y0.clone() if acc else None, accumulate=acc, relu=relu, a2=a2, W2=W[K1:], rowmax2=rm2)
+    else:
+        out = ops.gemm_h2(a1, W, rm1, transpose, bias=bias, out=y0.clone() if acc else None, accumulate=acc, relu=relu)
+    x3 = ops.gemm_x3(a, W, transpose, bias=bias, out=y0.clone() if acc else None, accumulate=acc, relu=relu)
+    vend = a @ (W if transpose else W.t())
+    if bias is not None:
+        vend = vend + bias
+    if acc:
+        vend = vend + y0
+    if relu:
+        vend = vend.clamp_min(0)
+    rows = []
+    for tag, o in (("f16x2", out), ("bf16x3", x3), ("vendor fp32", vend)):
+        e = (o.double() - ref).abs() / den.clamp_min(1e-300)
+        e = e[den > 0]
+        rows.append(dict(what=tag, max=float(e.max()), mean=float(e.mean())))
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir, "gpurun_out", "h2_errors.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test="gemm", M=M, K1=K1, K2=K2, N=N, acc=acc, relu=relu, rows=rows)) + "\n")
+    except OSError:
+        pass
+    assert rows[0]["max"] < 4e-7 and rows[0]["mean"] < 4e-8, rows          # the absolute bar of test_gemm_bf16x3_vs_float64
+    assert rows[0]["mean"] <= 1.25 * max(rows[1]["mean"], rows[2]["mean"]), rows
+    assert rows[0]["max"] <= 2.0 * max(rows[1]["max"], rows[2]["max"]), rows
+
+
+def test_row_maxima_of_the_gate_gradient_and_relu_backward_kernels_are_exact():
+    """uavgnn_gru_gates_bwd_fused_sums_rowmax / uavgnn_relu_bwd_colsum_rowmax: same outputs as the kernels without the row maxima, bit
+    for bit, and row_absmax == max |.| over the rows they wrote."""
+    from uav_bs_ctrl_amd import _lib as L
+    lib = L.lib()
+    N, H, A = 5000, 256, 9
+    gen = th.Generator().manual_seed(31)
+    pre, h, dh = (th.randn(N, 4 * H, generator=gen).cuda(), th.tanh(th.randn(N, H, generator=gen)).cuda(), th.randn(N, H, generator=gen).cuda())
+    dq, Wo = th.randn(N, A, generator=gen).cuda(), th.randn(A, H, generator=gen).cuda()
+    G = lib.uavgnn_gru_gates_bwd_sum_rows(N, H)
+    outs = []
+    for rm in (False, True):
+        d_gi, d_gh, d_h = th.empty(N, 3 * H, device="cuda"), th.empty(N, 3 * H, device="cuda"), th.empty(N, H, device="cuda")
+        sums, rowmax = th.empty(G, 4 * H, device="cuda"), th.full((N,), -1.0, device="cuda")
+        args = (pre.data_ptr(), h.data_ptr(), dh.data_ptr(), dq.data_ptr(), A, Wo.data_ptr(), N, H, d_gi.data_ptr(), d_gh.data_ptr(),
+                d_h.data_ptr(), sums.data_ptr())
+        if rm:
+            L.check(lib.uavgnn_gru_gates_bwd_fused_sums_rowmax(*args, rowmax.data_ptr(), L.stream()), "rowmax")
+        else:
+            L.check(lib.uavgnn_gru_gates_bwd_fused_sums(*args, L.stream()), "plain")
+        outs.append((d_gi, d_gh, d_h, sums, rowmax))
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert th.equal(a, b)
+    assert th.equal(outs[1][4], th.maximum(outs[1][0].abs().max(1).values, outs[1][1].abs().max(1).values))
+    assert lib.uavgnn_gru_gates_bwd_fused_sums_rowmax(pre.data_ptr(), h.data_ptr(), dh.data_ptr(), None, 0, None, 64, 128, d_gi.data_ptr(),
+                                                      d_gh.data_ptr(), d_h.data_ptr(), sums.data_ptr(), rowmax.data_ptr(), L.stream()) == L.UAVGNN_EUNSUPPORTED
+    n, C, S = 5003, 256, 8
+    dy, y = th.randn(n, C, generator=gen).cuda(), th.randn(n, C, generator=gen).cuda()
+    o0, o1 = th.empty(n, C, device="cuda"), th.empty(n, C, device="cuda")
+    p0, p1, rmx = th.zeros(S, C, device="cuda"), th.zeros(S, C, device="cuda"), th.full((n,), -1.0, device="cuda")
+    L.check(lib.uavgnn_relu_bwd_colsum(dy.data_ptr(), C, y.data_ptr(), C, o0.data_ptr(), C, n, C, p0.data_ptr(), S, L.stream()), "plain")
+    L.check(lib.uavgnn_relu_bwd_colsum_rowmax(dy.data_ptr(), C, y.data_ptr(), C, o1.data_ptr(), C, n, C, p1.data_ptr(), S, rmx.data_ptr(),
+                                              L.stream()), "rowmax")
+    assert th.equal(o0, o1) and th.equal(p0, p1) and th.equal(rmx, o1.abs().max(1).values)
+    assert lib.uavgnn_relu_bwd_colsum_rowmax(dy.data_ptr(), C, y.data_ptr(), C, o1.data_ptr(), C, n, 128, p1.data_ptr(), S, rmx.data_ptr(),
+                                             L.stream()) == L.UAVGNN_EUNSUPPORTED

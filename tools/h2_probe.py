@@ -106,3 +106,27 @@ for rnd in (1, 2):
     t_d = time_us(lambda: L.check(lib.uavgnn_tarmac_msg_fwd_rowmax(*head, xc.data_ptr() + 4 * H, K_in, a_s.data_ptr(), proj.data_ptr(), M + 2 * K, xc.data_ptr(), K_in, rmo.data_ptr(), st), "msg tr rm"))
     want = th.maximum(th.maximum(x.abs().max(1).values, h.abs().max(1).values), xc[:, H:].abs().max(1).values)
     print(f"tarmac_msg_fwd: no-grad {t_a:5.1f} us, + row maxima {t_b:5.1f} us | training {t_c:5.1f} us, + row maxima {t_d:5.1f} us | row maxima exact: {bool(th.equal(rmo, want))}")
+
+# ---- dense layers: f16x2 (csrc/gemm_h2.hip) against bf16x3 (csrc/gemm_x3.hip) at the shapes of the update's input-gradient products
+print("--- GEMMs (second pass figures)")
+for name, M_, K1, K2, N_, acc in (("d h += d_gh W_hh        [32768 x 768] -> 256, accumulate", 32768, 768, 0, 256, True),
+                                  ("d x = [d_gi || d_proj] W [32768 x (768 + 96)] -> 256", 32768, 768, 96, 256, False),
+                                  ("d K1out = dy W_aggr     [1671168 x 256] -> 512", 1671168, 256, 0, 512, False)):
+    a1 = th.randn(M_, K1, device=dev, generator=gen) * 1e-3
+    a2 = th.randn(M_, K2, device=dev, generator=gen) * 1e-3 if K2 else None
+    W = 0.1 * th.randn(K1 + K2, N_, device=dev, generator=gen)
+    y = th.zeros(M_, N_, device=dev)
+    rm1 = ops.row_absmax(a1)
+    rm2 = ops.row_absmax(a2) if K2 else None
+    with ops.frozen_weights():
+        if K2:
+            f_h2 = lambda: ops.gemm_h2(a1, W[:K1], rm1, True, out=y, a2=a2, W2=W[K1:], rowmax2=rm2)
+            f_x3 = lambda: ops.gemm_x3_cat(a1, a2, W[:K1], W[K1:], y)
+        else:
+            f_h2 = lambda: ops.gemm_h2(a1, W, rm1, True, out=y, accumulate=acc)
+            f_x3 = lambda: ops.gemm_x3(a1, W, True, out=y, accumulate=acc)
+        for _ in range(2):
+            t_h2, t_x3 = time_us(f_h2, reps=10), time_us(f_x3, reps=10)
+    fl_ = 2.0 * M_ * N_ * (K1 + K2)
+    print(f"{name}: f16x2 {t_h2:8.1f} us ({fl_ / t_h2 * 1e-6:6.1f} TF) | bf16x3 {t_x3:8.1f} us ({fl_ / t_x3 * 1e-6:6.1f} TF)")
+    del a1, a2, y

@@ -97,6 +97,13 @@ SIGNATURES = {
     "uavgnn_colsum_acc": (_c_int, [_c_fp, ctypes.c_longlong, _c_int, _c_int, _c_fp, _c_int, _c_st]),
     "uavgnn_relu_bwd_colsum": (_c_int, [_c_fp, ctypes.c_longlong, _c_fp, ctypes.c_longlong, _c_fp, ctypes.c_longlong, _c_int, _c_int, _c_fp,
                                _c_int, _c_st]),
+    "uavgnn_relu_bwd_colsum_rowmax": (_c_int, [_c_fp, ctypes.c_longlong, _c_fp, ctypes.c_longlong, _c_fp, ctypes.c_longlong, _c_int, _c_int,
+                                               _c_fp, _c_int, _c_fp, _c_st]),
+    "uavgnn_gemm_h2_supported": (_c_int, [_c_int, _c_int, _c_int]),
+    "uavgnn_split_h2_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
+    "uavgnn_split_h2": (_c_int, [_c_fp, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_st]),
+    "uavgnn_gemm_nt_h2": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp, ctypes.c_void_p, _c_int, _c_fp, _c_fp,
+                                   _c_int, _c_int, _c_st]),
     "uavgnn_env_state_dim": (_c_int, [_c_int, _c_int, _c_int]),
     "uavgnn_env_step": (_c_int, [ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double), _c_int] + [_c_fp] * 22 + [_c_st]),
     "uavgnn_adamw_polyak": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, ctypes.c_longlong, _c_fp, ctypes.c_double,
@@ -146,6 +153,8 @@ SIGNATURES = {
     "uavgnn_gru_gates_bwd_sum_rows": (_c_int, [_c_int, _c_int]),
     "uavgnn_gru_gates_bwd_fused_sums": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp,
                                                  _c_st]),
+    "uavgnn_gru_gates_bwd_fused_sums_rowmax": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp,
+                                                        _c_fp, _c_st]),
     "uavgnn_gru_gates_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_st]),
     "uavgnn_gru_gates_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_st]),
 }

@@ -21,11 +21,14 @@ constexpr int kWaves = kThreads / kWave;
 // ONE pass over the [N, C] gradient instead of an elementwise pass followed by a reduction pass).
 // `x` and `out` carry no __restrict__: the MASK instantiation may run IN PLACE (out == x, same row stride) - every element is read
 // and written by the same lane, all loads of an iteration are issued before its stores.
-template <int V, bool MASK = false>
+// RM (MASK, C = 256: the 64 lanes of a wavefront own ONE row): row_absmax[row] = max |.| over the row of `out` - the row scales of
+// the f16x2 product d(K1 output) = out W_aggr behind this kernel (csrc/gemm_h2.hip).
+template <int V, bool MASK = false, bool RM = false>
 __global__ __launch_bounds__(kThreads) void colsum_wide_kernel(const float* x, long long ld, int N, int C,
                                                                int rows_per_block, float* __restrict__ acc,
                                                                const float* __restrict__ y = nullptr, long long ldy = 0,
-                                                               float* out = nullptr, long long ldo = 0) {
+                                                               float* out = nullptr, long long ldo = 0,
+                                                               float* __restrict__ row_absmax = nullptr) {
   __shared__ float part[kWaves][kWave * V];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -55,6 +58,10 @@ __global__ __launch_bounds__(kThreads) void colsum_wide_kernel(const float* x, l
                               y4[u].w > 0.f ? t4[u].w : 0.f);
           *reinterpret_cast<float4*>(out + row * ldo + c) = t4[u];
           v[u][0] = t4[u].x; v[u][1] = t4[u].y; v[u][2] = t4[u].z; v[u][3] = t4[u].w;
+          if constexpr (RM) {
+            const float m = wave_max(fmaxf(fmaxf(fabsf(t4[u].x), fabsf(t4[u].y)), fmaxf(fabsf(t4[u].z), fabsf(t4[u].w))));
+            if (lane == 0) row_absmax[row] = m;
+          }
         }
       } else {
 #pragma unroll
@@ -75,6 +82,7 @@ __global__ __launch_bounds__(kThreads) void colsum_wide_kernel(const float* x, l
     }
     for (; r < hi; r += kWaves) {
       const float* q = p + static_cast<long long>(r) * ld;
+      float rmx = 0.f;
 #pragma unroll
       for (int t = 0; t < V; ++t) {
         float v = q[t];
@@ -83,6 +91,11 @@ __global__ __launch_bounds__(kThreads) void colsum_wide_kernel(const float* x, l
           out[static_cast<long long>(r) * ldo + c + t] = v;
         }
         a[t] += v;
+        if constexpr (RM) rmx = fmaxf(rmx, fabsf(v));
+      }
+      if constexpr (RM) {
+        rmx = wave_max(rmx);
+        if (lane == 0) row_absmax[r] = rmx;
       }
     }
   }
@@ -168,5 +181,21 @@ extern "C" int uavgnn_relu_bwd_colsum(const float* dy, long long ld, const float
   const int rows = (N + S - 1) / S;
   hipLaunchKernelGGL((colsum_wide_kernel<4, true>), dim3(S, (C + 4 * kWave - 1) / (4 * kWave)), dim3(kThreads), 0,
                      static_cast<hipStream_t>(stream), dy, ld, N, C, rows, acc, y, ldy, out, ldo);
+  return launch_status();
+}
+
+// ... that ALSO writes row_absmax [N] = max |.| over the rows of `out` (C = 256: one wavefront per row; UAVGNN_EUNSUPPORTED otherwise):
+// the row scales of the f16x2 input-gradient product behind it (uavgnn_gemm_nt_h2).  Not in place (out != dy).
+extern "C" int uavgnn_relu_bwd_colsum_rowmax(const float* dy, long long ld, const float* y, long long ldy, float* out, long long ldo, int N,
+                                             int C, float* acc, int S, float* row_absmax, uavgnn_stream_t stream) {
+  if (N < 0 || C < 1 || S < 1 || !acc || !row_absmax || (N > 0 && (!dy || !y || !out)) || ld < C || ldy < C || ldo < C || out == dy)
+    return UAVGNN_EINVAL;
+  if (C != 4 * kWave || (ld & 3) || (ldy & 3) || (ldo & 3) ||
+      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15))
+    return UAVGNN_EUNSUPPORTED;
+  if (N == 0) return 0;
+  const int rows = (N + S - 1) / S;
+  hipLaunchKernelGGL((colsum_wide_kernel<4, true, true>), dim3(S, 1), dim3(kThreads), 0, static_cast<hipStream_t>(stream), dy, ld, N, C,
+                     rows, acc, y, ldy, out, ldo, row_absmax);
   return launch_status();
 }

@@ -180,13 +180,16 @@ __global__ __launch_bounds__(256, 2) void gru_cell_fwd_kernel(
 // gate gradients of a BPTT sequence are not read again just to be summed (two streaming passes over 6.8 GB per C3 update).  A thread
 // keeps its four columns over the grid-stride loop (the stride is a multiple of H / 4 elements), the 256 / (H / 4) threads of a
 // block that share them are added in a fixed order through LDS: deterministic.
-template <bool HEAD, bool SUMS>
+// RM (H = 256 only: the 64 lanes of a wavefront own ONE row): row_absmax[row] = max |.| over the row of d_gi and of d_gh - the row
+// scales of the f16x2 products d x = [d_gi || d_proj] W and d h += d_gh W_hh behind this kernel (csrc/gemm_h2.hip).
+template <bool HEAD, bool SUMS, bool RM = false>
 __global__ __launch_bounds__(256) void gru_gates_bwd_fused_kernel(const float* __restrict__ pre, const float* __restrict__ h,
                                                                   const float* __restrict__ d_hout, long long total, int H,
                                                                   float* __restrict__ d_gi, float* __restrict__ d_gh,
                                                                   float* __restrict__ d_h, const float* __restrict__ dq,
                                                                   int n_out, const float* __restrict__ W_out,
-                                                                  float* __restrict__ col_sums) {
+                                                                  float* __restrict__ col_sums,
+                                                                  float* __restrict__ row_absmax = nullptr) {
   const int HV = H / 4;
   float cs[SUMS ? 16 : 1];       // the accumulators (and the LDS array below) exist in the column-sum instantiations only
 #pragma unroll
@@ -240,6 +243,13 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_fused_kernel(const float* _
     *reinterpret_cast<float4*>(gh + H) = make_float4(dz[0], dz[1], dz[2], dz[3]);
     *reinterpret_cast<float4*>(gh + 2 * H) = make_float4(dnh[0], dnh[1], dnh[2], dnh[3]);
     *reinterpret_cast<float4*>(d_h + row * H + col) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+    if constexpr (RM) {
+      float m = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) m = fmaxf(fmaxf(fmaxf(m, fabsf(dr[t])), fmaxf(fabsf(dz[t]), fabsf(dni[t]))), fabsf(dnh[t]));
+      m = wave_max(m);
+      if ((threadIdx.x & 63) == 0) row_absmax[row] = m;
+    }
   }
   if constexpr (SUMS) {
     __shared__ float sS[256 * 17];
@@ -340,5 +350,28 @@ extern "C" int uavgnn_gru_gates_bwd_fused_sums(const float* pre, const float* h,
   else
     hipLaunchKernelGGL((gru_gates_bwd_fused_kernel<false, true>), grid, block, 0, static_cast<hipStream_t>(stream), pre, h, d_hout, total, H,
                        d_gi, d_gh, d_h, nullptr, 0, nullptr, col_sums);
+  return launch_status();
+}
+
+// ... that ALSO writes row_absmax [N] = max |.| over the rows of d_gi and d_gh (H = 256: one wavefront per row; UAVGNN_EUNSUPPORTED
+// otherwise): the row scales of the f16x2 input-gradient products behind it (uavgnn_gemm_nt_h2)
+extern "C" int uavgnn_gru_gates_bwd_fused_sums_rowmax(const float* pre, const float* h, const float* d_hout, const float* dq, int n_out,
+                                                      const float* W_out, int N, int H, float* d_gi, float* d_gh, float* d_h,
+                                                      float* col_sums, float* row_absmax, uavgnn_stream_t stream) {
+  if (N < 0 || H <= 0 || !pre || !h || !d_gi || !d_gh || !d_h || !col_sums || !row_absmax || (dq == nullptr) != (W_out == nullptr) ||
+      (dq == nullptr && d_hout == nullptr) || (dq != nullptr && n_out <= 0))
+    return UAVGNN_EINVAL;
+  if (N == 0) return 0;
+  if (H != 256 || !uavgnn_gru_gates_bwd_sum_rows(N, H) || n_out > 64 ||
+      ((reinterpret_cast<uintptr_t>(W_out) | reinterpret_cast<uintptr_t>(col_sums)) & 15))
+    return UAVGNN_EUNSUPPORTED;
+  const long long total = static_cast<long long>(N) * (H / 4);
+  const dim3 grid(capped_grid(total, 256)), block(256);
+  if (dq != nullptr)
+    hipLaunchKernelGGL((gru_gates_bwd_fused_kernel<true, true, true>), grid, block, 0, static_cast<hipStream_t>(stream), pre, h, d_hout, total,
+                       H, d_gi, d_gh, d_h, dq, n_out, W_out, col_sums, row_absmax);
+  else
+    hipLaunchKernelGGL((gru_gates_bwd_fused_kernel<false, true, true>), grid, block, 0, static_cast<hipStream_t>(stream), pre, h, d_hout,
+                       total, H, d_gi, d_gh, d_h, nullptr, 0, nullptr, col_sums, row_absmax);
   return launch_status();
 }

@@ -467,7 +467,7 @@ DINP_SPLIT = os.environ.get("UAVGNN_DINP_SPLIT", "1") != "0"   # _TarmacStep.bac
 HEAD_FUSED_BWD = os.environ.get("UAVGNN_HEAD_FUSED_BWD", "1") != "0"
 
 
-def _gru_gates_bwd_from_pre(pre, h, d_hout, d_gi=None, d_gh=None, head=None, sums=None):
+def _gru_gates_bwd_from_pre(pre, h, d_hout, d_gi=None, d_gh=None, head=None, sums=None, rowmax=None):
     """Gate gradients from the saved pre-activation sets.  ``head`` = (dq [N, n_out], W_out [n_out, H]): the gradient of h' is
     d_hout (None = 0) + dq W_out, formed inside the kernel (uavgnn_gru_gates_bwd_fused_head).  ``sums``: a
     [uavgnn_gru_gates_bwd_sum_rows(N, H), 4H] buffer that receives the launch's per-workgroup column sums (the bias gradients'
@@ -479,7 +479,13 @@ def _gru_gates_bwd_from_pre(pre, h, d_hout, d_gi=None, d_gh=None, head=None, sum
         d_gh = th.empty_like(d_gi)
     dh = th.empty_like(h)
     with KERNEL_TIMER.span("gru_gates_bwd"):
-        if sums is not None:
+        if sums is not None and rowmax is not None:      # ... + the row maxima of d_gi / d_gh (`rowmax` [N], H = 256)
+            dq, W_out = head if head is not None else (None, None)
+            rc = L.lib().uavgnn_gru_gates_bwd_fused_sums_rowmax(pre.data_ptr(), h.data_ptr(), L.ptr(d_hout), L.ptr(dq),
+                                                                0 if dq is None else dq.shape[1], L.ptr(W_out), N, H, d_gi.data_ptr(),
+                                                                d_gh.data_ptr(), dh.data_ptr(), sums.data_ptr(), rowmax.data_ptr(),
+                                                                L.stream())
+        elif sums is not None:
             dq, W_out = head if head is not None else (None, None)
             rc = L.lib().uavgnn_gru_gates_bwd_fused_sums(pre.data_ptr(), h.data_ptr(), L.ptr(d_hout), L.ptr(dq),
                                                          0 if dq is None else dq.shape[1], L.ptr(W_out), N, H, d_gi.data_ptr(),
@@ -640,8 +646,11 @@ def _mm_nt(x, W, b=None, relu=False):
     return th.addmm(b, x, W.t()) if b is not None else th.mm(x, W.t())
 
 
-def _mm_nn(dy, W, out=None, accumulate=False):
-    """dy @ W (+ out when accumulate)."""
+def _mm_nn(dy, W, out=None, accumulate=False, rowmax=None):
+    """dy @ W (+ out when accumulate).  rowmax: the row maxima of dy from its producer -> the f16x2 kernel where it covers the shape."""
+    if rowmax is not None and gemm_h2_supported(dy, W.shape[1], W.shape[0]) and W.stride(1) == 1 and \
+            (out is None or (out.stride(1) == 1 and out.dtype == th.float32)):
+        return gemm_h2(dy, W, rowmax, True, out=out, accumulate=accumulate)
     if gemm_x3_supported(dy, W.shape[1], W.shape[0]) and W.stride(1) == 1 and \
             (out is None or (out.stride(1) == 1 and out.dtype == th.float32)):
         return gemm_x3(dy, W, True, out=out, accumulate=accumulate)
@@ -681,6 +690,54 @@ def gemm_x3_cat(a1, a2, W1, W2, out):
         rc = lib.uavgnn_gemm_nt_x3_cat(a1.data_ptr(), a1.stride(0), K1, a2.data_ptr(), a2.stride(0), M, K, planes.data_ptr(), n_out,
                                        None, out.data_ptr(), out.stride(0), GEMM_X3_FLAGS & 4, L.stream())
     L.check(rc, "uavgnn_gemm_nt_x3_cat")
+    return out
+
+
+# The input-gradient products of the recurrent step and of f_aggr on the f16x2 arithmetic (csrc/gemm_h2.hip: three f16 products per fp32
+# product) where the kernel that produced the activation operand hands over its row maxima; UAVGNN_GEMM_H2=0: bf16x3 everywhere (A/B)
+GEMM_H2 = os.environ.get("UAVGNN_GEMM_H2", "1") != "0"
+
+
+def gemm_h2_supported(a, n_out, k) -> bool:
+    """The eight-wave f16x2 kernel covers y = a B^T: what gemm_x3_supported asks, and a grid that fills the chip with 256 x 128 tiles
+    (the bf16x3 path switches to smaller tiles below; the f16x2 kernel has none)."""
+    return bool(GEMM_H2 and gemm_x3_supported(a, n_out, k) and L.lib().uavgnn_gemm_h2_supported(a.shape[0], n_out, k)
+                and ((a.shape[0] + 255) // 256) * ((n_out + 127) // 128) >= GEMM_X3_SMALL_GRID)
+
+
+def gemm_h2(a, W, rowmax, transpose_w=False, bias=None, out=None, accumulate=False, relu=False, a2=None, W2=None, rowmax2=None):
+    """out = a @ W.T (transpose_w=False) or a @ W (transpose_w=True) (+ bias) (+ out) (relu) on the f16x2 kernel; with a2 / W2:
+    [a || a2] @ [W; W2] (W [K1, n_out], W2 [K2, n_out], transposed form only).  rowmax (and rowmax2): per row an upper bound of
+    max |.| over the row of the activation operand, from its producer(s).  Caller checks gemm_h2_supported()."""
+    lib = L.lib()
+    M, K1 = a.shape
+    if a2 is not None:
+        assert transpose_w and W2 is not None and W.stride(1) == 1 and W2.stride(1) == 1
+        K2, n_out = a2.shape[1], W.shape[1]
+        K = K1 + K2
+        key = ("h2cat", W.data_ptr(), W._version, W.stride(0), W2.data_ptr(), W2._version, W2.stride(0), K1, K2, n_out)
+
+        def build(p):
+            Wc = th.cat((W, W2), 0)                                   # [K, n_out], contiguous
+            L.check(lib.uavgnn_split_h2(Wc.data_ptr(), n_out, K, n_out, 1, p.data_ptr(), L.stream()), "uavgnn_split_h2")
+        keep = (W, W2)
+    else:
+        R, C = W.shape
+        n_out, K = (C, R) if transpose_w else (R, C)
+        assert K == K1 and W.stride(1) == 1
+        key = ("h2mat", W.data_ptr(), W._version, W.stride(0), R, C, bool(transpose_w))
+
+        def build(p):
+            L.check(lib.uavgnn_split_h2(W.data_ptr(), W.stride(0), R, C, int(transpose_w), p.data_ptr(), L.stream()), "uavgnn_split_h2")
+        keep = (W,)
+    if out is None:
+        out = th.empty((M, n_out), dtype=th.float32, device=a.device)
+    with KERNEL_TIMER.span("gemm_x3", (M, n_out, K)):
+        planes = _cached_planes(key, lib.uavgnn_split_h2_bytes(n_out, K), a.device, build, keep=keep)
+        rc = lib.uavgnn_gemm_nt_h2(a.data_ptr(), a.stride(0), K1, L.ptr(a2), 0 if a2 is None else a2.stride(0), M, K, rowmax.data_ptr(),
+                                   L.ptr(rowmax2), planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(), out.stride(0),
+                                   (1 if accumulate else 0) | (2 if relu else 0) | (GEMM_X3_FLAGS & 4), L.stream())
+    L.check(rc, "uavgnn_gemm_nt_h2")
     return out
 
 
@@ -732,11 +789,11 @@ class _LinearSplitK(th.autograd.Function):
         return _LinearSplitK._grads(ctx, x, W, dy, ctx.has_bias)
 
     @staticmethod
-    def _grads(ctx, x, W, dy, has_bias):
+    def _grads(ctx, x, W, dy, has_bias, rowmax=None):
         dy = dy.contiguous()
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = _mm_nn(dy, W)
+            dx = _mm_nn(dy, W, rowmax=rowmax)
         if ctx.needs_input_grad[1] and gemm_tn_x3_supported(dy, x):
             dW = gemm_tn_x3(dy, x).sum(0)
         elif ctx.needs_input_grad[1]:
@@ -786,9 +843,17 @@ class _LinearReLU(th.autograd.Function):
             S = _row_blocks(n)
             dym = th.empty((n, C), dtype=th.float32, device=dy.device)
             part = th.zeros((S, C), dtype=th.float32, device=dy.device)
-            L.check(L.lib().uavgnn_relu_bwd_colsum(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), dym.data_ptr(), C, n, C,
-                                                   part.data_ptr(), S, L.stream()), "uavgnn_relu_bwd_colsum")
-            dx, dW, _ = _LinearSplitK._grads(ctx, x, W, dym, False)
+            rowmax = None
+            if C == 256 and ctx.needs_input_grad[0] and gemm_h2_supported(dym, W.shape[1], C) and W.stride(1) == 1:
+                # the masked gradient's row maxima on the way: d x = dym W runs on the f16x2 kernel (csrc/gemm_h2.hip)
+                rowmax = th.empty(n, dtype=th.float32, device=dy.device)
+                L.check(L.lib().uavgnn_relu_bwd_colsum_rowmax(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), dym.data_ptr(), C, n,
+                                                              C, part.data_ptr(), S, rowmax.data_ptr(), L.stream()),
+                        "uavgnn_relu_bwd_colsum_rowmax")
+            else:
+                L.check(L.lib().uavgnn_relu_bwd_colsum(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), dym.data_ptr(), C, n, C,
+                                                       part.data_ptr(), S, L.stream()), "uavgnn_relu_bwd_colsum")
+            dx, dW, _ = _LinearSplitK._grads(ctx, x, W, dym, False, rowmax=rowmax)
             return dx, dW, part.sum(0)
         dy = th.ops.aten.threshold_backward(dy, y, 0.0)     # dy where y > 0 else 0, one pass (compare + where were two)
         return _LinearSplitK._grads(ctx, x, W, dy, True)
@@ -1173,6 +1238,7 @@ class _TarmacStep(th.autograd.Function):
         if not ctx.have_pre:    # gi would be the [N, H] placeholder: reading 4H floats per row from it is out of bounds
             raise L.UavGnnError("tarmac_step: backward through a forward that saved no pre-activations (train=False)")
         sink = GRAD_SINK
+        rm_g = None
         dq = L.f32c(dq) if dq is not None else th.zeros((N, W_out.shape[0]), dtype=th.float32, device=x.device)
         # d h' = d_hout + dq W_out inside the gate kernel when the cell ran fused (its pre-activation sets are what that kernel reads)
         head = None
@@ -1205,8 +1271,11 @@ class _TarmacStep(th.autograd.Function):
                 # streaming the [T1 N, 3H] gate gradients twice more
                 sums = seq.slot("gsum", t, 4 * H, rows=G)
                 seq.gsum_steps.add(t)
+            rm_g = None
+            if (sums is not None and H == 256 and W_hh.stride(1) == 1 and gemm_h2_supported(seq.slot("d_gh", t, 3 * H), H, 3 * H)):
+                rm_g = th.empty(N, dtype=th.float32, device=x.device)      # row maxima of d_gi / d_gh for the f16x2 products below
             d_gi, d_gh, dh = _gru_gates_bwd_from_pre(gi, h, dh2_tot, seq.slot("d_gi", t, 3 * H), seq.slot("d_gh", t, 3 * H),
-                                                     head=head, sums=sums)
+                                                     head=head, sums=sums, rowmax=rm_g)
         elif ctx.fused_gru:
             d_gi, d_gh, dh = _gru_gates_bwd_from_pre(gi, h, dh2_tot, head=head)      # gi holds the saved pre-activation sets
         else:
@@ -1236,7 +1305,7 @@ class _TarmacStep(th.autograd.Function):
         else:
             d_inp = _mm_nn(d_gi, W_ih)
             d_c_ptr, d_c_ld = d_inp.data_ptr() + 4 * H, H + M
-        _mm_nn(d_gh, W_hh, out=dh, accumulate=True)
+        _mm_nn(d_gh, W_hh, out=dh, accumulate=True, rowmax=rm_g)
         if sink is not None:
             sink.owned.clear()
             sink.owned[dh.data_ptr()] = dh
@@ -1244,7 +1313,10 @@ class _TarmacStep(th.autograd.Function):
                          K, M, talk_off, talk_src, (t_off, t_dst, t_pos), N, 1.0 / K, a_save, d_c_ptr,
                          d_c_ld, d_proj.data_ptr() + 4 * M, ld, d_proj.data_ptr() + 4 * (M + K), ld, d_proj.data_ptr(),
                          ld)
-        if dx_cat:
+        if dx_cat and rm_g is not None and gemm_h2_supported(d_gi, H, d_gi.shape[1] + d_proj.shape[1]):
+            # f16x2: the row scale of [d_gi || d_proj] is the larger of the gate kernel's bound and d_proj's own (96 columns: a 4-us pass)
+            gemm_h2(d_gi, W_ih[:, :H], rm_g, True, out=dx, a2=d_proj, W2=Wp[:, :H], rowmax2=row_absmax(d_proj))
+        elif dx_cat:
             gemm_x3_cat(d_gi, d_proj, W_ih[:, :H], Wp[:, :H], dx)
         elif split_dinp:
             dx.addmm_(d_proj, Wp[:, :H])                                   # h enters the projections stop-gradded
