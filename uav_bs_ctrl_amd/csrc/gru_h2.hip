@@ -31,6 +31,8 @@
 // v_mfma_f32_32x32x16_f16, double-buffered LDS planes with one barrier per 32-wide K slice, staging interleaved with the first MFMA
 // group) with two planes instead of three: 40 KB per LDS stage instead of 60, 8 fragment reads per slice half instead of 12, 3 VALU per
 // staged element instead of 5.5 (v_pk_mul, v_cvt_pk_f16_f32, v_cvt_f32_f16, v_pk_fma, v_cvt_pk_f16_f32).
+#include <type_traits>
+
 #include "common.h"
 
 namespace uavgnn {
@@ -155,8 +157,10 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
   }
   const unsigned wc8 = 16u * (tid & 3);    // byte offset of the lane's 8-f16 chunk inside a weight slice
   const int n1 = K1 / BK, n12 = n1 + K2 / BK, ns = n12 + H / BK;   // slices of inp, of [inp || inp2], of everything
-  float4 ra[2];
-  u32x4 rw[3];
+  // TWO register sets: the loads of slice t + 3 are issued while slice t computes (two iterations of latency cover; with one set -
+  // one iteration - the staging waited for its loads: 26 of the kernel's 117 us in tools/h2_ablate.py)
+  float4 ra[2][2];
+  u32x4 rw[2][3];
   unsigned oa[2], ow[3];
   const char* __restrict__ Ab = reinterpret_cast<const char*>(inp);
   const char* __restrict__ Wb = reinterpret_cast<const char*>(Wih_p);
@@ -173,13 +177,15 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
   };
   set_a(inp, ld_inp);
   set_w(Wih_p, K1 + K2);
-  auto gload_a = [&]() {
+  auto gload_a = [&](auto set) {
+    constexpr int S = decltype(set)::value;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(Ab + oa[i]);
+    for (int i = 0; i < 2; ++i) ra[S][i] = *reinterpret_cast<const float4*>(Ab + oa[i]);
   };
-  auto gload_w = [&]() {
+  auto gload_w = [&](auto set) {
+    constexpr int S = decltype(set)::value;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) rw[i] = *reinterpret_cast<const u32x4*>(Wb + ow[i]);
+    for (int i = 0; i < 3; ++i) rw[S][i] = *reinterpret_cast<const u32x4*>(Wb + ow[i]);
   };
   auto advance = [&]() {      // after both loads of slice lt were issued; past the last slice the cursor stays on it
     if (lt + 1 >= ns) return;
@@ -192,39 +198,50 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
       set_w(Whh_p, H);
     }
   };
-  auto gload = [&]() {
-    gload_a();
-    gload_w();
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  auto gload = [&](auto set) {
+    gload_a(set);
+    gload_w(set);
     advance();
   };
-  auto lstore_b = [&](int buf) {
+  auto lstore_b = [&](int buf, auto set) {
+    constexpr int S = decltype(set)::value;
     u32x4* sb = smem + buf * BUF;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) sb[sbw[i]] = rw[i];
+    for (int i = 0; i < 3; ++i) sb[sbw[i]] = rw[S][i];
   };
-  auto lstore_a = [&](int buf, int i) {
+  auto lstore_a = [&](int buf, int i, auto set) {
+    constexpr int S = decltype(set)::value;
     unsigned short* sa = reinterpret_cast<unsigned short*>(smem + buf * BUF) + sa_w;
-    stage4(sa + 64 * i * 32, PA * 8, ra[i], sca[i]);
+    stage4(sa + 64 * i * 32, PA * 8, ra[S][i], sca[i]);
   };
-  auto lstore = [&](int buf) {
-    lstore_a(buf, 0);
-    lstore_a(buf, 1);
-    lstore_b(buf);
+  auto lstore = [&](int buf, auto set) {
+    lstore_a(buf, 0, set);
+    lstore_a(buf, 1, set);
+    lstore_b(buf, set);
   };
+#ifdef UAVGNN_H2_DBG
+#define UAVGNN_H2_DBG_ UAVGNN_H2_DBG
+#else
+#define UAVGNN_H2_DBG_ 0
+#endif
   struct Half {
     f16x8 a[2], b[3][2];   // [plane], [gate][plane]
   };
 #define UAVGNN_H2_READ(F, buf, kh)                                                                                 \
-  {                                                                                                                \
+  if (!(UAVGNN_H2_DBG_ & 16) || t == 0) {                                                                          \
     const u32x4* sb = smem + (buf) * BUF;                                                                          \
     _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) F.a[pl] = as_frag(sb[pl * PA + (wm + l32) * 4 + ((2 * (kh) + lh) ^ sw)]); \
     _Pragma("unroll") for (int gate = 0; gate < 3; ++gate) _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)        \
         F.b[gate][pl] = as_frag(sb[2 * PA + pl * PB + (gate * BJ + wc + l32) * 4 + ((2 * (kh) + lh) ^ sw)]);       \
   }
-#define UAVGNN_H2_TERM(ia, ib)                     \
-  acc[0] = mfma32(F.a[ia], F.b[0][ib], acc[0]);    \
-  acc[1] = mfma32(F.a[ia], F.b[1][ib], acc[1]);    \
-  acc[NSET] = mfma32(F.a[ia], F.b[2][ib], acc[NSET]);
+#define UAVGNN_H2_TERM(ia, ib)                       \
+  if (!(UAVGNN_H2_DBG_ & 8)) {                       \
+    acc[0] = mfma32(F.a[ia], F.b[0][ib], acc[0]);    \
+    acc[1] = mfma32(F.a[ia], F.b[1][ib], acc[1]);    \
+    acc[NSET] = mfma32(F.a[ia], F.b[2][ib], acc[NSET]); \
+  }
 #define UAVGNN_H2_MFMA(F_, NSET_)                                  \
   {                                                                \
     constexpr int NSET = NSET_;                                    \
@@ -232,27 +249,28 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
     UAVGNN_H2_TERM(0, 1) UAVGNN_H2_TERM(1, 0) UAVGNN_H2_TERM(0, 0) \
   }
 
-  gload();
-  lstore(0);
-  gload();
+  gload(Set0{});          // slice 0
+  lstore(0, Set0{});
+  gload(Set1{});          // slice 1
+  gload(Set0{});          // slice 2
   __syncthreads();
   // Software pipeline as in gru_x3.hip: the fragment reads of a half are issued one MFMA group (9 MFMAs) before their use; iteration
   // t stages slice t + 1 into the other buffer INSIDE its first MFMA group (an independent VALU / LDS / memory instruction issues in
   // the shadow of an executing MFMA only when it follows it in the instruction stream) and starts the loads of slice t + 2.
   Half f0, f1;
-  UAVGNN_H2_READ(f0, 0, 0)
   int t = 0;
+  UAVGNN_H2_READ(f0, 0, 0)
 #ifndef UAVGNN_H2_DBG
-#define UAVGNN_H2_DBG 0   /* timing experiments: 1 = no global loads in the loop, 2 = no staging either, 3 = prologue + epilogue only */
+#define UAVGNN_H2_DBG 0   /* timing experiments (tools/h2_ablate.py; results are WRONG): bit 0 no global loads in the loop, 1 no staging, 2 no slice loop at all, 3 no MFMAs, 4 no fragment reads in the loop */
 #endif
-#define UAVGNN_H2_STEP(NSET_)                              \
+#define UAVGNN_H2_STEP(NSET_, SET_)                        \
   {                                                        \
     constexpr int NSET = NSET_;                            \
     UAVGNN_H2_READ(f1, t & 1, 1)                           \
     __builtin_amdgcn_sched_barrier(0);                     \
     const Half& F = f0;                                    \
-    if (UAVGNN_H2_DBG < 2) lstore_b((t + 1) & 1);          \
-    if (UAVGNN_H2_DBG < 1) gload_w();                      \
+    if (!(UAVGNN_H2_DBG & 2)) lstore_b((t + 1) & 1, SET_{}); \
+    if (!(UAVGNN_H2_DBG & 1)) gload_w(SET_{});             \
     UAVGNN_H2_TERM(0, 1)                                   \
     _Pragma("unroll") for (int sg = 0; sg < 3; ++sg) {     \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   \
     }                                                      \
     __builtin_amdgcn_sched_barrier(0);                     \
-    if (UAVGNN_H2_DBG < 2) { lstore_a((t + 1) & 1, 0); lstore_a((t + 1) & 1, 1); } \
+    if (!(UAVGNN_H2_DBG & 2)) { lstore_a((t + 1) & 1, 0, SET_{}); lstore_a((t + 1) & 1, 1, SET_{}); } \
     UAVGNN_H2_TERM(1, 0)                                   \
     _Pragma("unroll") for (int sg = 0; sg < 3; ++sg) {     \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
@@ -268,7 +286,7 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
       __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);   \
     }                                                      \
     __builtin_amdgcn_sched_barrier(0);                     \
-    if (UAVGNN_H2_DBG < 1) gload_a();                      \
+    if (!(UAVGNN_H2_DBG & 1)) gload_a(SET_{});             \
     UAVGNN_H2_TERM(0, 0)                                   \
     _Pragma("unroll") for (int sg = 0; sg < 3; ++sg) {     \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
@@ -276,16 +294,35 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   \
     }                                                      \
     __builtin_amdgcn_sched_barrier(0);                     \
-    if (UAVGNN_H2_DBG < 1) advance();                      \
+    if (!(UAVGNN_H2_DBG & 1)) advance();                   \
   }                                                        \
   __syncthreads();                                         \
   UAVGNN_H2_READ(f0, (t + 1) & 1, 0)                       \
   __builtin_amdgcn_sched_barrier(0);                       \
   UAVGNN_H2_MFMA(f1, NSET_)                                \
   __builtin_amdgcn_sched_barrier(0);
-  if (UAVGNN_H2_DBG == 3) t = ns;
-  for (; t < n12; ++t) { UAVGNN_H2_STEP(2) }
-  for (; t < ns; ++t) { UAVGNN_H2_STEP(3) }
+  if (UAVGNN_H2_DBG & 4) t = ns;
+  // iteration t stages slice t + 1 out of register set (t + 1) & 1 and refills that set with slice t + 3
+  for (; t + 1 < n12; ++t) {
+    UAVGNN_H2_STEP(2, Set1)
+    ++t;
+    UAVGNN_H2_STEP(2, Set0)
+  }
+  if (t < n12) {            // an odd number of input slices: the pairs of the second loop start on an odd slice
+    UAVGNN_H2_STEP(2, Set1)
+    ++t;
+    UAVGNN_H2_STEP(3, Set0)
+    ++t;
+  }
+  for (; t + 1 < ns; ++t) {
+    UAVGNN_H2_STEP(3, Set1)
+    ++t;
+    UAVGNN_H2_STEP(3, Set0)
+  }
+  if (t < ns) {             // (odd slice count)
+    UAVGNN_H2_STEP(3, Set1)
+    ++t;
+  }
 #undef UAVGNN_H2_STEP
 #undef UAVGNN_H2_MFMA
 #undef UAVGNN_H2_READ
