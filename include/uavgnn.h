@@ -505,6 +505,19 @@ int uavgnn_gemm_nt_x3_cat(const float* X, int ldx, int K1, const float* X2, int 
 int uavgnn_gemm_tn_x3_chunks(long long n_rows, int Mo, int Ko);
 int uavgnn_gemm_tn_x3(const float* dY, int ldy, int Mo, const float* X, int ldx, int Ko, long long n_rows, float* partials,
                       int S, int accumulate, uavgnn_stream_t stream);
+/* The same weight gradient on the f16x2 arithmetic (csrc/gemm_tn_h2.hip, round 6; arithmetic and error: uavgnn_gru_cell_fwd_h2): the
+ * contraction runs over the ROWS of both operands, so the power-of-two scales of the two-term split are per COLUMN.
+ *   colmax_y [Mo] / colmax_x [Ko]  upper bounds of max |.| over every column of dY / X, tight to within their power of two:
+ *                                  uavgnn_col_absmax (one pass over the operand; Inf for a column that holds Inf / NaN -> NaN outputs);
+ *   partials [S][Mo][Ko]           one partial product per row chunk (the caller sums them in a fixed order), `accumulate` adds in place.
+ * n_rows % 32 == 0, Mo % 4 == 0, Ko % 4 == 0, 16-byte aligned rows (uavgnn_gemm_tn_h2_supported; UAVGNN_EUNSUPPORTED otherwise).
+ * Replaces the vendor's fp32 split-K GEMM for dW_ih / dW_hh of nn.GRUCell (gnn_agents.py:246) and csrc/gemm_tn_x3.hip for f_aggr
+ * (gnn_agents.py:99) under loss.backward() (learner.py:157) over the time-batched rows of a BPTT sequence. */
+int uavgnn_col_absmax(const float* x, long long ld, long long n, int C, float* out, uavgnn_stream_t stream);
+int uavgnn_gemm_tn_h2_supported(long long n_rows, int Mo, int Ko);
+int uavgnn_gemm_tn_h2_chunks(long long n_rows, int Mo, int Ko);
+int uavgnn_gemm_tn_h2(const float* dY, long long ldy, int Mo, const float* X, long long ldx, int Ko, long long n_rows,
+                      const float* colmax_y, const float* colmax_x, float* partials, int S, int accumulate, uavgnn_stream_t stream);
 int uavgnn_gru_gates_bwd_fused(const float* pre, const float* h, const float* d_hout, int N, int H, float* d_gi, float* d_gh,
                                float* d_h, uavgnn_stream_t stream);
 /* The same with the Q head's input gradient folded in: the gradient of h' is d_hout (NULL = 0) + dq W_out, dq [N, n_out] the

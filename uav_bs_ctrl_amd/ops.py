@@ -747,6 +747,26 @@ GEMM_TN_X3 = os.environ.get("UAVGNN_GEMM_TN_X3", "1") != "0"   # weight gradient
 # at the per-step shapes (32 768 rows; 0.4-0.6 x on the 96- and 9-row outputs), 142 vs 134 at the time-batched encoder shape
 # (1.67 M rows).  Only the latter takes the kernel; its error against float64 is 0.5-0.8 x the vendor's on every shape.
 GEMM_TN_MIN_ROWS = 1 << 18
+# ... on the f16x2 arithmetic with LDS transposing reads (csrc/gemm_tn_h2.hip): the recurrent weights of a staged BPTT sequence
+GEMM_TN_H2 = os.environ.get("UAVGNN_GEMM_TN_H2", "1") != "0"
+
+
+def _max_two_stage(t):
+    """max over all elements as row maxima of a [S, numel / S] view, then the maximum of the S row maxima - neither stage takes torch's
+    multi-block semaphore path, whose final write did not always land inside a replayed hipGraph (learner._mse)."""
+    n = t.numel()
+    S = 1
+    while S < 1024 and n % (2 * S) == 0 and n // (2 * S) >= 256:
+        S *= 2
+    return t.reshape(S, n // S).max(1).values.max()
+
+
+def gemm_tn_h2_supported(dy, x) -> bool:
+    return bool(GEMM_X3 and GEMM_H2 and GEMM_TN_H2 and dy.is_cuda and dy.dtype == th.float32 and x.dtype == th.float32 and dy.dim() == 2
+                and x.dim() == 2 and dy.shape[0] == x.shape[0] and dy.shape[0] >= GEMM_TN_MIN_ROWS and dy.stride(1) == 1 and x.stride(1) == 1
+                and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+                and dy.shape[1] >= 256 and x.shape[1] >= 128          # (a 96- or 9-row output leaves most of a 256 x 128 tile idle: the vendor GEMM)
+                and L.lib().uavgnn_gemm_tn_h2_supported(dy.shape[0], dy.shape[1], x.shape[1]))
 
 
 def gemm_tn_x3_supported(dy, x) -> bool:
@@ -912,6 +932,23 @@ class WeightGradSink:
         else:
             slot[0].baddbmm_(dy.view(S, n // S, -1).transpose(1, 2), x.view(S, n // S, -1))
 
+    def weight_h2(self, key, dy, x, bound_y, bound_x, flush_fn):
+        """buffer[S, out, in] += chunked dy^T x on the f16x2 kernel (csrc/gemm_tn_h2.hip).  bound_y / bound_x: 0-dim device tensors, upper
+        bounds of max |.| over ALL of dy / x - the column scales of the split (see gemm_tn_h2_supported)."""
+        lib = L.lib()
+        n, Mo, Ko = dy.shape[0], dy.shape[1], x.shape[1]
+        S = lib.uavgnn_gemm_tn_h2_chunks(n, Mo, Ko)
+        key = (key, "tnh2", S)
+        slot = self.slots.get(key)
+        acc = slot is not None
+        if slot is None:
+            self.slots[key] = slot = (th.empty((S, Mo, Ko), dtype=th.float32, device=x.device), flush_fn)
+        cy, cx = bound_y.expand(Mo).contiguous(), bound_x.expand(Ko).contiguous()
+        with KERNEL_TIMER.span("gemm_tn_h2", (n, Mo, Ko)):
+            rc = lib.uavgnn_gemm_tn_h2(dy.data_ptr(), dy.stride(0), Mo, x.data_ptr(), x.stride(0), Ko, n, cy.data_ptr(), cx.data_ptr(),
+                                       slot[0].data_ptr(), S, int(acc), L.stream())
+        L.check(rc, "uavgnn_gemm_tn_h2")
+
     def bias(self, key, dy, flush_fn):
         """buffer[S, out] += row-blocked column sums of dy: one streaming HIP pass per matrix (csrc/colsum.hip), in
         place (torch: a reduction into a temporary plus an add per step; a transposed GEMV was 20x slower still)"""
@@ -959,8 +996,18 @@ class WeightGradSink:
             self.weight(("Wp_x", ids["Wp"]), d_proj, x, lambda g: split("Wp", g, 0), tn)
             self.weight(("Wp_h", ids["Wp"]), d_proj, h, lambda g: split("Wp", g, H), tn)
             self.bias(("bp", ids["Wp"]), d_proj, lambda g: split("bp", g, 0))
-            self.weight(("W_ih", ids["W_ih"]), d_gi, inp, lambda g: split("W_ih", g, 0), tn)
-            self.weight(("W_hh", ids["W_hh"]), d_gh, h, lambda g: split("W_hh", g, 0), tn)
+            if full and gemm_tn_h2_supported(d_gi, inp) and gemm_tn_h2_supported(d_gh, h) and seq.rowmax_steps >= set(range(T1)) \
+                    and seq.rm_g_steps >= set(range(T1)):
+                # dW_ih / dW_hh on the f16x2 kernel (177-187 TFLOP/s against the vendor's 131-143 at C3): the column scales of the split
+                # come for free - the row maxima the message kernel (max over [x || c || h] per agent) and the gate kernel (d_gi / d_gh) left
+                # for the f16x2 cell / input-gradient products bound every column; a column far below the global maximum is held with fewer
+                # bits (absolute error <= 2^-39 of the bound per element, averaged down over 10^6 rows: DESIGN.md section 5)
+                bx, by = _max_two_stage(seq.bufs["rowmax"][:T1]), _max_two_stage(seq.bufs["rm_g"][:T1])
+                self.weight_h2(("W_ih", ids["W_ih"]), d_gi, inp, by, bx, lambda g: split("W_ih", g, 0))
+                self.weight_h2(("W_hh", ids["W_hh"]), d_gh, h, by, bx, lambda g: split("W_hh", g, 0))
+            else:
+                self.weight(("W_ih", ids["W_ih"]), d_gi, inp, lambda g: split("W_ih", g, 0), tn)
+                self.weight(("W_hh", ids["W_hh"]), d_gh, h, lambda g: split("W_hh", g, 0), tn)
             if all(t in seq.gsum_steps for t in range(t0, t1)):
                 # the gate kernels of these steps left per-workgroup column sums d_r | d_z | d_n (input) | d_n (hidden): [., 4H]
                 gs = seq.bufs["gsum"][t0:t1]
@@ -992,6 +1039,8 @@ class _SequenceStage:
         self.t_fwd = 0
         self.bwd_steps = []
         self.gsum_steps = set()          # steps whose gate kernel wrote its column-sum partials ("gsum" slots)
+        self.rowmax_steps = set()        # steps whose message kernel left the row maxima of [x || c || h] ("rowmax" slots)
+        self.rm_g_steps = set()          # steps whose gate kernel left the row maxima of d_gi / d_gh ("rm_g" slots)
         self.split = self.ids = self.H = None
 
     def slot(self, name, t, cols, extra=0, rows=None):
@@ -1195,6 +1244,9 @@ class _TarmacStep(th.autograd.Function):
                     seq.slot("h", 0, H, extra=1).copy_(h)
             else:
                 inp = th.empty((N, H + M), dtype=th.float32, device=x.device)     # [x || c], both halves filled by K3b
+            if seq is not None and rowmax is not None:       # kept for the sequence: its maximum scales the weight-gradient products
+                rowmax = seq.slot("rowmax", seq_t, 1).view(N)
+                seq.rowmax_steps.add(seq_t)
             if msg is not None:     # proj, the attention weights and the x half of [x || c] are the launch's training outputs
                 proj = th.empty((N, ld), dtype=th.float32, device=x.device)
                 _launch_tarmac_msg(msg, x, h, bp, M, K, talk_off, talk_src, N, H, inp.data_ptr() + 4 * H, H + M, a_save.data_ptr(),
@@ -1273,7 +1325,8 @@ class _TarmacStep(th.autograd.Function):
                 seq.gsum_steps.add(t)
             rm_g = None
             if (sums is not None and H == 256 and W_hh.stride(1) == 1 and gemm_h2_supported(seq.slot("d_gh", t, 3 * H), H, 3 * H)):
-                rm_g = th.empty(N, dtype=th.float32, device=x.device)      # row maxima of d_gi / d_gh for the f16x2 products below
+                rm_g = seq.slot("rm_g", t, 1).view(N)      # row maxima of d_gi / d_gh for the f16x2 products below (and, over the whole
+                seq.rm_g_steps.add(t)                      # sequence, for the weight gradients)
             d_gi, d_gh, dh = _gru_gates_bwd_from_pre(gi, h, dh2_tot, seq.slot("d_gi", t, 3 * H), seq.slot("d_gh", t, 3 * H),
                                                      head=head, sums=sums, rowmax=rm_g)
         elif ctx.fused_gru:
