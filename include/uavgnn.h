@@ -495,6 +495,11 @@ int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const void* planes,
  * `planes` = uavgnn_split_bf16x3 of the stacked weight. */
 int uavgnn_gemm_nt_x3_cat(const float* X, int ldx, int K1, const float* X2, int ldx2, int M, int K, const void* planes, int N,
                           const float* bias, float* Y, int ldy, int epilogue, uavgnn_stream_t stream);
+/* uavgnn_gemm_nt_x3 (the 256 x 128-tile kernel only: UAVGNN_GEMM_TILE_* are UAVGNN_EUNSUPPORTED) that ALSO writes rowmax_out [M] = max |.|
+ * over every row of X, a by-product of its staging: the bound of an f16x2 product that reads the same operand later (the layer's weight
+ * gradient, uavgnn_gemm_tn_h2) at no extra traffic. */
+int uavgnn_gemm_nt_x3_rowmax(const float* X, int ldx, int M, int K, const void* planes, int N, const float* bias, float* Y, int ldy,
+                             int epilogue, float* rowmax_out, uavgnn_stream_t stream);
 
 /* Weight gradient of a dense layer on the bf16x3 arithmetic (csrc/gemm_tn_x3.hip): partials[s][Mo, Ko] (+)= dY[rows_s, :Mo]^T
  * X[rows_s, :Ko] for the S contiguous row chunks rows_s of the n_rows rows (chunk = ceil(n_rows / S) rounded up to 32 rows);

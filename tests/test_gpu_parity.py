@@ -3138,3 +3138,35 @@ def test_gemm_tn_f16x2_weight_gradient_vs_float64(n, Mo, Ko, views, bounds):
     L.check(lib.uavgnn_gemm_tn_h2(dy.data_ptr(), dy.stride(0), Mo, x.data_ptr(), x.stride(0), Ko, n, cy.data_ptr(), cx.data_ptr(), part2.data_ptr(),
                                   S, 0, L.stream()), "gemm_tn_h2")
     assert th.equal(part2.sum(0), got)
+
+
+def test_time_batched_linear_relu_weight_gradient_on_the_f16x2_kernel(monkeypatch):
+    """ops.linear_relu (f_aggr, gnn_agents.py:99-102) over 2^18 time-batched rows: the forward GEMM leaves the row maxima of its input, the
+    ReLU-backward kernel those of the masked gradient, dx and dW run on the f16x2 kernels (csrc/gemm_h2.hip, csrc/gemm_tn_h2.hip) - against
+    float64 under grad_close and against the bf16x3 / vendor path of rounds 3-5."""
+    from uav_bs_ctrl_amd import _lib as L
+    from uav_bs_ctrl_amd import ops
+    n, K, C = 1 << 18, 512, 256
+    gen = th.Generator().manual_seed(41)
+    x = th.relu(th.randn(n, K, generator=gen)).cuda().requires_grad_(True)
+    W = (0.05 * th.randn(C, K, generator=gen)).cuda().requires_grad_(True)
+    b = (0.1 * th.randn(C, generator=gen)).cuda().requires_grad_(True)
+    g = (th.randn(n, C, generator=gen) * 1e-3).cuda()
+    spy = _LibSpy(L.lib())
+    monkeypatch.setattr(L, "lib", lambda: spy)
+    y = ops.linear_relu(x, W, b)
+    dx, dW, db = th.autograd.grad(y, [x, W, b], g)
+    monkeypatch.undo()
+    assert {"uavgnn_gemm_nt_x3_rowmax", "uavgnn_relu_bwd_colsum_rowmax", "uavgnn_gemm_nt_h2", "uavgnn_gemm_tn_h2"} <= set(spy.names), sorted(set(spy.names))
+    m = 16384      # float64 reference of y and dx on a prefix of the rows; dW / db on all rows in float64 on the device
+    x64, W64, b64 = x.detach().double(), W.detach().double(), b.detach().double()
+    y64 = th.relu(x64 @ W64.t() + b64)
+    gm = g.double() * (y64 > 0)
+    assert_close(y[:m], y64[:m], 1e-5, "y")
+    assert_close(dx[:m], (gm @ W64)[:m], 1e-5, "dx (f16x2)")
+    monkeypatch.setattr(ops, "GEMM_H2", False)
+    y2 = ops.linear_relu(x, W, b)
+    dx2, dW2, db2 = th.autograd.grad(y2, [x, W, b], g)
+    grad_close(dW, gm.t() @ x64, "f_aggr dW on the f16x2 kernel, 2^18 rows", ref32=dW2)
+    grad_close(db, gm.sum(0), "f_aggr db, 2^18 rows", ref32=db2)
+    assert th.equal(y, y2)

@@ -99,6 +99,7 @@ SIGNATURES = {
                                _c_int, _c_st]),
     "uavgnn_relu_bwd_colsum_rowmax": (_c_int, [_c_fp, ctypes.c_longlong, _c_fp, ctypes.c_longlong, _c_fp, ctypes.c_longlong, _c_int, _c_int,
                                                _c_fp, _c_int, _c_fp, _c_st]),
+    "uavgnn_gemm_nt_x3_rowmax": (_c_int, [_c_fp, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_int, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_st]),
     "uavgnn_col_absmax": (_c_int, [_c_fp, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_fp, _c_st]),
     "uavgnn_gemm_tn_h2_supported": (_c_int, [ctypes.c_longlong, _c_int, _c_int]),
     "uavgnn_gemm_tn_h2_chunks": (_c_int, [ctypes.c_longlong, _c_int, _c_int]),

@@ -160,7 +160,9 @@ __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __res
                                                               const unsigned short* __restrict__ Bp, int N,
                                                               const float* __restrict__ bias, float* __restrict__ Y, int ldy,
                                                               int row_blocks, int col_blocks, const float* __restrict__ X2, int ldx2,
-                                                              int ns1) {
+                                                              int ns1, float* __restrict__ rowmax_out) {
+  // rowmax_out != nullptr: max |.| over every row of X is written there by the workgroups of column block 0 (every element of the
+  // row passes through their staging registers): the producer-side bound of the f16x2 weight gradient behind this layer.
   // X2 != nullptr: the contraction runs over [X || X2] (two buffers, no concatenated copy): slices 0 .. ns1 - 1 come from X, the
   // rest from X2 (uavgnn_gemm_nt_x3_cat).  One source: ns1 = K / 32.
   using namespace w8;
@@ -219,9 +221,12 @@ __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __res
     gload_a(t);
     gload_w(t);
   };
+  const bool track = rowmax_out != nullptr && cb == 0;      // workgroup-uniform
+  float rmx[4] = {0.f, 0.f, 0.f, 0.f};
   auto lstore_a = [&](int buf, int i) {
     unsigned short* sa = reinterpret_cast<unsigned short*>(smem + buf * BUF) + sa_w;
     stage4(sa + 64 * i * 32, PA * 8, ra[i]);
+    if (track) rmx[i] = fmaxf(fmaxf(fmaxf(rmx[i], fabsf(ra[i].x)), fmaxf(fabsf(ra[i].y), fabsf(ra[i].z))), fabsf(ra[i].w));
   };
   auto lstore_b = [&](int buf) {
     u32x4* sb = smem + buf * BUF;
@@ -329,6 +334,16 @@ __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __res
 #undef UAVGNN_X3_MFMA
 #undef UAVGNN_X3_TERM
 #undef UAVGNN_X3_READ
+  if (track) {      // the eight threads of a row (consecutive lanes) hold the maxima of their 4-float pieces
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float m = rmx[i];
+      m = fmaxf(m, __shfl_xor(m, 1));
+      m = fmaxf(m, __shfl_xor(m, 2));
+      m = fmaxf(m, __shfl_xor(m, 4));
+      if (c4 == 0 && m0 + lr + 64 * i < M) rowmax_out[m0 + lr + 64 * i] = m;
+    }
+  }
   if (ACC && (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && n0 + BN <= N) {
     // Y += product through an LDS tile: the accumulators are parked in LDS (the slice buffers are free behind the loop's last
     // barrier), then every thread does a ROW-CONTIGUOUS float4 read-modify-write of Y - its 16 loads are issued back to back,
@@ -417,7 +432,8 @@ extern "C" int uavgnn_split_bf16x3(const float* W, int ld, int R, int C, int tra
 
 // K1 = columns taken from X (a multiple of 32), the remaining K - K1 from X2 (nullptr: one source, K1 = K)
 static int gemm_nt_x3_launch(const float* X, int ldx, int K1, const float* X2, int ldx2, int M, int K, const void* planes, int N,
-                             const float* bias, float* Y, int ldy, int epilogue, uavgnn_stream_t stream) {
+                             const float* bias, float* Y, int ldy, int epilogue, uavgnn_stream_t stream, float* rowmax_out = nullptr) {
+  if (rowmax_out != nullptr && (X2 != nullptr || (epilogue & (UAVGNN_GEMM_TILE_128 | UAVGNN_GEMM_TILE_64)))) return UAVGNN_EUNSUPPORTED;
   if (M < 0 || !X || !planes || !Y || ldx < K1 || ldy < N || K1 <= 0 || K1 > K || (X2 == nullptr) != (K1 == K) ||
       (X2 != nullptr && ldx2 < K - K1))
     return UAVGNN_EINVAL;
@@ -438,7 +454,7 @@ static int gemm_nt_x3_launch(const float* X, int ldx, int K1, const float* X2, i
     const dim3 grid(((row_blocks + 7) / 8) * 8 * col_blocks), block(w8::NT);
 #define UAVGNN_X3_GEMM(ACC, RELU, IL)                                                                                        \
   hipLaunchKernelGGL((gemm_nt_x3w8_kernel<ACC, RELU, IL>), grid, block, 0, st, X, ldx, M, K, bp, N, bias, Y, ldy, row_blocks, \
-                     col_blocks, X2, ldx2, ns1)
+                     col_blocks, X2, ldx2, ns1, rowmax_out)
 #define UAVGNN_X3_GEMM_IL(IL)                         \
   if (acc && relu) UAVGNN_X3_GEMM(true, true, IL);    \
   else if (acc) UAVGNN_X3_GEMM(true, false, IL);      \
@@ -472,6 +488,15 @@ extern "C" int uavgnn_gemm_nt_x3(const float* X, int ldx, int M, int K, const vo
                                  float* Y, int ldy, int epilogue, uavgnn_stream_t stream) {
   if (ldx < K) return UAVGNN_EINVAL;
   return gemm_nt_x3_launch(X, ldx, K, nullptr, 0, M, K, planes, N, bias, Y, ldy, epilogue, stream);
+}
+
+// uavgnn_gemm_nt_x3 (eight-wave kernel only: no tile variants) that ALSO writes rowmax_out [M] = max |.| over every row of X - every
+// element of a row passes through the staging registers of the row's first column block: the bound of an f16x2 product that reads the
+// same operand later (the weight gradient of the layer: uavgnn_gemm_tn_h2), at no extra traffic.
+extern "C" int uavgnn_gemm_nt_x3_rowmax(const float* X, int ldx, int M, int K, const void* planes, int N, const float* bias, float* Y,
+                                        int ldy, int epilogue, float* rowmax_out, uavgnn_stream_t stream) {
+  if (ldx < K || !rowmax_out) return UAVGNN_EINVAL;
+  return gemm_nt_x3_launch(X, ldx, K, nullptr, 0, M, K, planes, N, bias, Y, ldy, epilogue, stream, rowmax_out);
 }
 
 // Y = [X (K1 columns) || X2 (K - K1 columns)] B^T ...: the contraction over two buffers without a concatenated copy (the GRU

@@ -608,7 +608,7 @@ def gemm_x3_supported(a, n_out, k) -> bool:
                 and a.shape[0] * a.stride(0) < 2 ** 31 and L.lib().uavgnn_gemm_x3_supported(a.shape[0], n_out, k))
 
 
-def gemm_x3(a, W, transpose_w=False, bias=None, out=None, accumulate=False, relu=False):
+def gemm_x3(a, W, transpose_w=False, bias=None, out=None, accumulate=False, relu=False, rowmax_out=None):
     """out = a @ W.T (transpose_w=False, W [n_out, k]) or a @ W (transpose_w=True, W [k, n_out]) (+ bias) (+ out) (relu).
     `W` may be a strided view with unit inner stride; its bf16 planes are rebuilt on every call (3-5 us: nothing observable
     tells when a drop-in module's weights changed) unless the caller opened a frozen_weights() scope.  Caller checks gemm_x3_supported()."""
@@ -631,8 +631,15 @@ def gemm_x3(a, W, transpose_w=False, bias=None, out=None, accumulate=False, relu
             flags |= 8
             if ((M + 127) // 128) * ((n_out + 127) // 128) < GEMM_X3_SMALL_GRID:
                 flags = (flags & ~8) | 16         # still under half the CUs: 64 x 128 tiles (UAVGNN_GEMM_TILE_64)
-        rc = lib.uavgnn_gemm_nt_x3(a.data_ptr(), a.stride(0), M, K, planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(),
-                                   out.stride(0), (1 if accumulate else 0) | (2 if relu else 0) | flags, L.stream())
+        epi = (1 if accumulate else 0) | (2 if relu else 0) | flags
+        if rowmax_out is not None and not (flags & 24):      # ... + max |.| over every row of `a`, a by-product of the staging
+            rc = lib.uavgnn_gemm_nt_x3_rowmax(a.data_ptr(), a.stride(0), M, K, planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(),
+                                              out.stride(0), epi, rowmax_out.data_ptr(), L.stream())
+        else:
+            if rowmax_out is not None:
+                rowmax_out.copy_(a.abs().amax(1))
+            rc = lib.uavgnn_gemm_nt_x3(a.data_ptr(), a.stride(0), M, K, planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(),
+                                       out.stride(0), epi, L.stream())
     L.check(rc, "uavgnn_gemm_nt_x3")
     return out
 
@@ -809,12 +816,24 @@ class _LinearSplitK(th.autograd.Function):
         return _LinearSplitK._grads(ctx, x, W, dy, ctx.has_bias)
 
     @staticmethod
-    def _grads(ctx, x, W, dy, has_bias, rowmax=None):
+    def _grads(ctx, x, W, dy, has_bias, rowmax=None, x_rowmax=None):
         dy = dy.contiguous()
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = _mm_nn(dy, W, rowmax=rowmax)
-        if ctx.needs_input_grad[1] and gemm_tn_x3_supported(dy, x):
+        if ctx.needs_input_grad[1] and rowmax is not None and x_rowmax is not None and gemm_tn_h2_supported(dy, x):
+            # f16x2 weight gradient: the global maxima of the producers' row maxima bound every column (see WeightGradSink.end_sequence)
+            lib = L.lib()
+            n, Mo, Ko = dy.shape[0], dy.shape[1], x.shape[1]
+            S = lib.uavgnn_gemm_tn_h2_chunks(n, Mo, Ko)
+            part = th.empty((S, Mo, Ko), dtype=th.float32, device=x.device)
+            cy, cx = _max_two_stage(rowmax).expand(Mo).contiguous(), _max_two_stage(x_rowmax).expand(Ko).contiguous()
+            with KERNEL_TIMER.span("gemm_tn_h2", (n, Mo, Ko)):
+                rc = lib.uavgnn_gemm_tn_h2(dy.data_ptr(), dy.stride(0), Mo, x.data_ptr(), x.stride(0), Ko, n, cy.data_ptr(), cx.data_ptr(),
+                                           part.data_ptr(), S, 0, L.stream())
+            L.check(rc, "uavgnn_gemm_tn_h2")
+            dW = part.sum(0)
+        elif ctx.needs_input_grad[1] and gemm_tn_x3_supported(dy, x):
             dW = gemm_tn_x3(dy, x).sum(0)
         elif ctx.needs_input_grad[1]:
             n = x.shape[0]
@@ -846,7 +865,17 @@ class _LinearReLU(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b):
-        y = _mm_nt(x, W, b, relu=True)
+        ctx.x_rowmax = None
+        n_out = W.shape[0]
+        if (ctx.needs_input_grad[1] and n_out % 4 == 0 and gemm_x3_supported(x, n_out, W.shape[1]) and W.stride(1) == 1 and b is not None
+                and b.is_contiguous() and x.shape[0] >= GEMM_TN_MIN_ROWS and GEMM_TN_H2 and GEMM_H2 and n_out >= 256 and x.shape[1] >= 128
+                and L.lib().uavgnn_gemm_tn_h2_supported(x.shape[0], n_out, x.shape[1])):
+            # time-batched training forward: the layer's weight gradient will run on the f16x2 kernel - the bound of its X operand (this
+            # x) is a by-product of this GEMM's staging
+            ctx.x_rowmax = th.empty(x.shape[0], dtype=th.float32, device=x.device)
+            y = gemm_x3(x, W, False, bias=b, relu=True, rowmax_out=ctx.x_rowmax)
+        else:
+            y = _mm_nt(x, W, b, relu=True)
         ctx.save_for_backward(x, W, y)
         return y
 
@@ -873,7 +902,7 @@ class _LinearReLU(th.autograd.Function):
             else:
                 L.check(L.lib().uavgnn_relu_bwd_colsum(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), dym.data_ptr(), C, n, C,
                                                        part.data_ptr(), S, L.stream()), "uavgnn_relu_bwd_colsum")
-            dx, dW, _ = _LinearSplitK._grads(ctx, x, W, dym, False, rowmax=rowmax)
+            dx, dW, _ = _LinearSplitK._grads(ctx, x, W, dym, False, rowmax=rowmax, x_rowmax=ctx.x_rowmax)
             return dx, dW, part.sum(0)
         dy = th.ops.aten.threshold_backward(dy, y, 0.0)     # dy where y > 0 else 0, one pass (compare + where were two)
         return _LinearSplitK._grads(ctx, x, W, dy, True)
