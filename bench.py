@@ -112,11 +112,32 @@ def alg_k1_fwd(E_s, E_n, N, save_s, save_n):
     return b, 3360 * E_s + 2320 * E_n + 7168 * N
 
 
-K1_COUNTERS = os.path.join(ROOT, "profiles", "r04_k1_hetero_counters.json")
+# newest committed counter stamp of the K1 forward kernel (rocprofv3 --pmc passes of tools/k1_run.py, tools/k1_counters_json.py)
+K1_COUNTERS = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_k1_hetero_counters.json") for r in (6, 5, 4)) if os.path.exists(p)),
+                   os.path.join(ROOT, "profiles", "r04_k1_hetero_counters.json"))
+K1_COUNTERS_REL = os.path.relpath(K1_COUNTERS, ROOT)
+K1_ENV_ROCPROF = os.path.join(ROOT, "profiles", "r06_k1_env_standalone_by_grid.txt")
+
+
+def k1_env_rocprof(alg_bytes):
+    """SURVEY 8(d) prices the graded kernel on its rocprofv3 kernel-trace duration: the committed trace of 50 back-to-back D-env rollout
+    launches (tools/k1_run.py --dist env --reps 50 under rocprofv3 --kernel-trace; per-(kernel, grid) summary of tools/rocprof_by_grid.py)
+    -> kernel-only p50 duration, without the launch boundary an event pair carries.  None when the file is absent."""
+    if not os.path.exists(K1_ENV_ROCPROF):
+        return None
+    for ln in open(K1_ENV_ROCPROF):
+        f = ln.split()
+        if "gatv2_hetero_fwd_kernel" in ln and len(f) > 8 and f[0].isdigit() and int(f[0]) >= 40:
+            p50, mn = float(f[3]), float(f[4])
+            return {"source": os.path.relpath(K1_ENV_ROCPROF, ROOT) + " (committed; NOT collected inside this run - another box of the pool)",
+                    "launches": int(f[0]), "p50_us": p50, "min_us": mn, "alg_bytes_per_launch": alg_bytes,
+                    "achieved": alg_bytes / p50 / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / p50 / 1e3 / HBM_PEAK_GBS}
+    return None
+
 
 
 def measured_traffic(dist_name, n_inf, n_tr, B, n, M):
-    """HBM bytes per fused K1 launch from the committed rocprofv3 PMC passes (profiles/r04_k1_hetero_counters.json; method
+    """HBM bytes per fused K1 launch from the committed rocprofv3 PMC passes (K1_COUNTERS; method
     and gfx950 correction are documented there), averaged over the inference / training launches of a step like
     ``achieved``.  (None, None) when the workload is not the profiled one."""
     if not os.path.exists(K1_COUNTERS) or (B, n, M) != (4096, 8, 80):
@@ -126,7 +147,7 @@ def measured_traffic(dist_name, n_inf, n_tr, B, n, M):
         return None, None
     by = {k: (2.0 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0 for k, v in t.items()}
     src = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/k1_run.py on this workload, stamped in "
-           "profiles/r04_k1_hetero_counters.json (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not "
+           + K1_COUNTERS_REL + " (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not "
            "collected inside this run")
     return (n_inf * by["inference"] + n_tr * by["training"]) / (n_inf + n_tr), src
 
@@ -156,7 +177,7 @@ def pipe_bound(dist_name, avg_launch_ms_rollout, clock_mhz, B, n, M):
             "measured_us": 1e3 * avg_launch_ms_rollout,
             "frac_of_pipe_bound": 1e6 * floor_s / (1e3 * avg_launch_ms_rollout),
             "frac_of_additive_pipe_bound": 1e6 * sum_s / (1e3 * avg_launch_ms_rollout),
-            "counter_source": "profiles/r04_k1_hetero_counters.json (rocprofv3 --pmc passes of tools/k1_run.py, not collected inside this run)"}
+            "counter_source": K1_COUNTERS_REL + " (rocprofv3 --pmc passes of tools/k1_run.py, not collected inside this run)"}
 
 
 class ClockSampler:
@@ -946,15 +967,19 @@ def main():
                                  "TFLOP/s (bf16 MFMA: six products per fp32 product)" if x3 else "TFLOP/s"),
                         "frac": (mult * tf / BF16_PEAK_TFLOPS) if mult > 1 else tf / FP32_PEAK_TFLOPS,
                         "share_of_step": kc["total_ms"] / (1e3 * instr_s)})
-        kg = kfull.get("gemm_x3")
-        if kg and kg["work"]:
-            fl = sum(2.0 * M * N * K for (M, N, K) in kg["work"])
-            tf = fl / (kg["total_ms"] * 1e-3) / 1e12
-            sec.append({"kernel": "gemm_nt_x3w8_kernel + split_matrix_kernel (dense layers: forward / input gradient)",
-                        "bound": "mfma", "launches": kg["count"], "avg_launch_ms": kg["avg_ms"],
-                        "fp32_equivalent_tflops": tf, "achieved": 6.0 * tf, "peak": BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s (bf16 MFMA: six products per fp32 product)", "frac": 6.0 * tf / BF16_PEAK_TFLOPS,
-                        "share_of_step": kg["total_ms"] / (1e3 * instr_s)})
+        for span, label, mult, what in (("gemm_x3", "gemm_nt_x3w8_kernel + split_matrix_kernel (dense layers, bf16x3: the f_aggr forward)", 6.0, "bf16"),
+                                        ("gemm_h2", "gemm_nt_h2w8_kernel + split_h2_kernel (input-gradient products of the recurrent step and of f_aggr, "
+                                                    "f16x2: row maxima from the producing kernels)", 3.0, "f16"),
+                                        ("gemm_tn_h2", "gemm_tn_h2_kernel (weight gradients dW_ih, dW_hh, dW_aggr over the time-batched rows, f16x2 through "
+                                                       "LDS transposing reads; rounds 2-5: the vendor's fp32 split-K GEMM)", 3.0, "f16")):
+            kg = kfull.get(span)
+            if kg and kg["work"]:
+                fl = sum(2.0 * M * N * K for (M, N, K) in kg["work"])
+                tf = fl / (kg["total_ms"] * 1e-3) / 1e12
+                sec.append({"kernel": label, "bound": "mfma", "launches": kg["count"], "avg_launch_ms": kg["avg_ms"],
+                            "fp32_equivalent_tflops": tf, "achieved": mult * tf, "peak": BF16_PEAK_TFLOPS,
+                            "unit": f"TFLOP/s ({what} MFMA: {int(mult)} products per fp32 product)", "frac": mult * tf / BF16_PEAK_TFLOPS,
+                            "share_of_step": kg["total_ms"] / (1e3 * instr_s)})
         km = kfull.get("tarmac_msg_fwd")
         if km and km["work"]:
             # K3a + K3b in one launch (csrc/tarmac_msg.hip): x and h read once, c written (+ proj and the x half of [x || c] on
@@ -983,19 +1008,20 @@ def main():
                                      "note": "one extra cycle AFTER the timed steps with HIP events around every C-ABI launch: source of "
                                              "`roofline_secondary` and `kernel_ms_per_launch`.  The timed steps carry events around the "
                                              "graded kernel (`roofline`) only - timing every launch makes the rollout host-bound"}
-        res["arithmetic"] = ("fp32 in / out / accumulate everywhere.  K3b, K5 and all pointwise kernels: fp32 FMA.  The GRU cell of the TarMAC "
-                             "step (csrc/gru_h2.hip, round 6): every operand row scaled by an exact power of two into f16's range and "
-                             "split into hi + lo f16 terms (hi + lo = v to <= 2^-23 |v|), each fp32 product the fp32-accumulated sum of 3 "
-                             "exact f16 x f16 MFMA products (dropped term <= 2^-22 |a b|); measured error vs fp64 below the bf16x3 cell's "
-                             "and the vendor fp32 GEMM's on the same data (profiles/r06_h2_probe.txt, r06_h2_error_tables.txt; "
-                             "UAVGNN_GRU_H2=0: the bf16x3 cell).  The score GEMM of K1 "
-                             "(csrc/gatv2_hetero.hip), the other GRU cells (csrc/gru_x3.hip), the dense layers whose output tiles by 128 "
-                             "columns (csrc/gemm_x3.hip) and the time-batched encoder weight gradient (csrc/gemm_tn_x3.hip): each "
-                             "fp32 operand is split EXACTLY into 3 bf16 terms and each fp32 product is the fp32-accumulated sum of 6 "
-                             "exact bf16 x bf16 MFMA products (dropped terms <= 2^-23 |a b|); measured error vs fp64 is BELOW the "
-                             "vendor fp32 GEMM's on the same data (profiles/r02_gemm_x3_probe.txt, profiles/r03_gru_probe.txt, "
-                             "profiles/r03_gemm_tn_probe.txt).  `fp32_mfma_leg` is the same cycle with all of them switched to fp32 "
-                             "MFMA / vendor fp32 GEMMs (UAVGNN_GRU_X3=0 UAVGNN_GEMM_X3=0 UAVGNN_K1_BF16Z=0).")
+        res["arithmetic"] = ("fp32 in / out / accumulate everywhere.  K3b, K5 and all pointwise kernels: fp32 FMA.  GEMM-shaped products run on the "
+                             "16-bit matrix cores at fp32 accuracy, in two exact-split schemes.  f16x2 (round 6; csrc/gru_h2.hip, gemm_h2.hip, "
+                             "gemm_tn_h2.hip): every row (column, for the weight gradients) of an operand is scaled by an exact power of two into "
+                             "f16's range and split into hi + lo f16 terms (hi + lo = v to <= 2^-23 |v|); an fp32 product is the fp32-accumulated "
+                             "sum of 3 exact f16 x f16 MFMA products (dropped term <= 2^-22 |a b|) - the GRU cell of the TarMAC step, the "
+                             "input-gradient products of the recurrent step and of f_aggr, the weight gradients dW_ih / dW_hh / dW_aggr; the "
+                             "scales come from row maxima that the producing kernels leave on their way.  bf16x3 (rounds 2-5; csrc/gemm_x3.hip, "
+                             "gatv2_hetero.hip, tarmac_msg.hip, gru_x3.hip): operands split EXACTLY into 3 bf16 terms, 6 exact bf16 x bf16 "
+                             "products per fp32 product (dropped terms <= 2^-23 |a b|) - the f_aggr forward, K1's score GEMM, the message "
+                             "projection, GRU cells without a row-maxima producer.  Measured error vs fp64 of both schemes is at or BELOW the "
+                             "vendor fp32 GEMM's on the same data (profiles/r06_h2_probe.txt, r06_h2_error_tables.txt, r06_gemm_tn_h2_probe.txt; "
+                             "r02_gemm_x3_probe.txt, r03_gru_probe.txt).  A/B switches: UAVGNN_GRU_H2=0 / UAVGNN_GEMM_H2=0 / "
+                             "UAVGNN_GEMM_TN_H2=0 fall back to bf16x3 / the vendor GEMM.  `fp32_mfma_leg` is the same cycle with ALL of them "
+                             "switched to fp32 MFMA / vendor fp32 GEMMs (UAVGNN_GRU_X3=0 UAVGNN_GEMM_X3=0 UAVGNN_K1_BF16Z=0).")
         if world == 1 and not a.no_fp32_leg:
             saved_flags = (ops.GRU_X3, ops.GEMM_X3, ops.K1_BF16Z)     # a run started with UAVGNN_*=0 keeps its own setting afterwards
             ops.GRU_X3 = ops.GEMM_X3 = ops.K1_BF16Z = False
@@ -1054,6 +1080,9 @@ def main():
                                           "one warm-up, K1 forward between HIP events as in the timed region"})
                 try:
                     r_env["standalone"] = k1_env_standalone(learner, env_batch["obs"][0].fresh(), a)
+                    rp = k1_env_rocprof(r_env["standalone"].get("alg_bytes_per_launch", 70315280))
+                    if rp is not None:
+                        r_env["rocprof"], r_env["rocprof_frac"] = rp, rp["frac"]
                 except Exception as e:   # noqa: BLE001 - a diagnostic leg never breaks the bench line
                     r_env["standalone"] = {"error": repr(e)}
                 res["roofline_env"] = r_env

@@ -313,14 +313,6 @@ int uavgnn_tarmac_msg_fwd_rowmax(const float* x, int ld_x, const float* h, int l
                                  const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src, float scale,
                                  float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p, float* x_copy, int ld_xc,
                                  float* row_absmax, uavgnn_stream_t stream);
-/* ... with a variant word: bits 0-3 are timing ablations of tools/msg_probe.py (parts of the GEMM loop skipped: the outputs are then
- * WRONG); bit 4 (16) selects the one-wavefront-per-row-tile kernel where uavgnn_tarmac_msg_fwd runs the wavefront-pair kernel (no
- * planes_out, M + 2K <= 96) - correct results, the A/B reference; the two kernels sum the x and h halves of the projection in
- * different orders and may differ in the last bit */
-int uavgnn_tarmac_msg_fwd_dbg(const float* x, int ld_x, const float* h, int ld_h, int N, int H, int n_ag, const void* tiles,
-                              const float* bias, int M, int K, const int32_t* talk_off, const int32_t* talk_src, float scale,
-                              float* c_out, int ld_c, float* a_save, float* proj_out, int ld_p, float* x_copy, int ld_xc,
-                              void* planes_out, int dbg, uavgnn_stream_t stream);
 
 /* ---- derived indexes of a batch --------------------------------------------------------------------------------
  * What the reference gets from DGL's lazy format materialisation (CSR/CSC created inside the first message-passing
@@ -446,22 +438,6 @@ int uavgnn_gru_cell_fwd_h2(const float* inp, int ld_inp, int K1, const float* in
 /* out [N] = max |.| per row over up to three row-major pieces (a2 / a3 may be NULL); Inf when the row holds Inf or NaN. */
 int uavgnn_row_absmax(const float* a1, int ld1, int K1, const float* a2, int ld2, int K2, const float* a3, int ld3, int K3, int N,
                       float* out, uavgnn_stream_t stream);
-/* The same cell from PREPARED operand planes (csrc/gru_x3p.hip): bit-identical results to uavgnn_gru_cell_fwd_x3 with no operand
- * split inside the kernel - staging a K slice is a linear LDS-DMA copy.  `planes`: the operand [inp || h] of the N rows as bf16
- * plane tiles, written by uavgnn_tarmac_msg_fwd (planes_out; K_in = H + M there); `h`: the same hidden state in fp32 (read by the
- * convex update); `tiles`: [W_ih | W_hh] as bf16 plane tiles per (64-unit column block, K slice), built once per weight version by
- * uavgnn_gru_split_weight_tiles (uavgnn_gru_weight_tiles_bytes(K_in, H) bytes, 16-byte aligned).  K_in % 32 == 0, H % 64 == 0. */
-long long uavgnn_gru_weight_tiles_bytes(int K_in, int H);
-int uavgnn_gru_split_weight_tiles(const float* W_ih, int K_in, const float* W_hh, int H, void* tiles, uavgnn_stream_t stream);
-int uavgnn_gru_cell_fwd_planes(const void* planes, int K_in, const float* h, int N, int H, const void* tiles, const float* b_ih,
-                               const float* b_hh, float* h_out, float* pre_save, uavgnn_stream_t stream);
-/* ... with a per-call variant word `opt` (0 = uavgnn_gru_cell_fwd_planes; the schedules tools/cell_probe.py compares - bit 0:
- * second-half fragment reads behind the first MFMAs, bit 1: activation DMA two slices ahead (three LDS buffers), bit 2: the
- * epilogue's h tile requested inside the last slice, bit 3 (not with bit 1): the DMA of slice t + 2 issued behind the barrier of
- * slice t; results are bit-identical for every value; UAVGNN_EINVAL outside 0 .. 9, 12, 13). */
-int uavgnn_gru_cell_fwd_planes_opts(const void* planes, int K_in, const float* h, int N, int H, const void* tiles,
-                                    const float* b_ih, const float* b_hh, float* h_out, float* pre_save, int opt,
-                                    uavgnn_stream_t stream);
 /* The Q head for n_actions <= 16 (csrc/head.hip; reference: nn.Linear(H, n_actions) at algos/madrqn/agents/gnn_agents.py:43-46,:56):
  * q [N, A] (row stride ld_q) = h [N, H] (row stride ld_h) W [A, H]^T (row stride ld_w) + b [A].  fp32 in / out, exact fp32 products
  * on the matrix cores (v_mfma_f32_16x16x4_f32), one pass over h.  H in {64, 128, 256}, A <= 16, ld_h % 4 == 0, ld_w % 4 == 0, h and W

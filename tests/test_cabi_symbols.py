@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/uavgnn.h declares (no compute calls without a GPU)."""
+"""The C-ABI library loads and exports every symbol include/uavgnn.h (the drop-in boundary) and include/uavgnn_probe.h (probe-only
+building blocks of tools/) declare (no compute calls without a GPU)."""
 import ctypes
 import os
 import re
@@ -7,8 +8,8 @@ from uav_bs_ctrl_amd import _lib
 from uav_bs_ctrl_amd.build import build_lib
 
 
-def _declared(root):
-    src = open(os.path.join(root, "include", "uavgnn.h")).read()
+def _declared(root, header="uavgnn.h"):
+    src = open(os.path.join(root, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(uavgnn_[a-z0-9_]+)\s*\(", src)))
 
@@ -17,7 +18,10 @@ def test_library_builds_loads_and_exports_every_declared_symbol(repo_root):
     path = build_lib()
     assert os.path.exists(path)
     handle = ctypes.CDLL(path)
-    names = _declared(repo_root)
+    public, probe = _declared(repo_root), _declared(repo_root, "uavgnn_probe.h")
+    assert probe and not set(public) & set(probe), "a symbol is declared in both headers"
+    assert not any("_dbg" in n for n in public), "debug entries belong to include/uavgnn_probe.h"
+    names = sorted(public + probe)
     assert "uavgnn_gatv2_fwd" in names and "uavgnn_talk_attn_bwd" in names
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/uavgnn.h but not exported"

@@ -17,6 +17,7 @@
 // `s_waitcnt vmcnt(0)` of the barrier that ends it.
 #include "bf16x3.h"
 #include "common.h"
+#include "uavgnn_probe.h"
 
 namespace uavgnn {
 namespace {

@@ -30,6 +30,7 @@
 
 #include "bf16x3.h"
 #include "common.h"
+#include "uavgnn_probe.h"
 
 namespace uavgnn {
 namespace {

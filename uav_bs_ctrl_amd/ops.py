@@ -739,7 +739,7 @@ def gemm_h2(a, W, rowmax, transpose_w=False, bias=None, out=None, accumulate=Fal
         keep = (W,)
     if out is None:
         out = th.empty((M, n_out), dtype=th.float32, device=a.device)
-    with KERNEL_TIMER.span("gemm_x3", (M, n_out, K)):
+    with KERNEL_TIMER.span("gemm_h2", (M, n_out, K)):
         planes = _cached_planes(key, lib.uavgnn_split_h2_bytes(n_out, K), a.device, build, keep=keep)
         rc = lib.uavgnn_gemm_nt_h2(a.data_ptr(), a.stride(0), K1, L.ptr(a2), 0 if a2 is None else a2.stride(0), M, K, rowmax.data_ptr(),
                                    L.ptr(rowmax2), planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(), out.stride(0),
