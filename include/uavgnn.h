@@ -112,6 +112,16 @@ int uavgnn_gatv2_hetero_fwd_image(const float* x_gt, int E_seen, const int32_t* 
                                   const float* const* seen_params, const float* const* near_params, int nh, int D,
                                   float slope, const void* image, float* out, int ld_out, float* attn_save_seen,
                                   float* attn_save_near, int phases, uavgnn_stream_t stream);
+/* uavgnn_gatv2_hetero_fwd_image (image may be NULL: the in-kernel prologue) that ALSO writes rowmax_near / rowmax_seen [N]: the maximum
+ * over the `near` / the `seen` half of every output row (rows are >= 0 behind the ReLU; every element has exactly one writer:
+ * deterministic) - the two row bounds uavgnn_gemm_nt_h2 takes for the f_aggr product behind a TIME-BATCHED launch (gnn_agents.py:106).
+ * Costs +9 % on a time-batched launch and +1.9 us on a 20-us rollout launch (why the rollout does not use it).  Not with the fp32-MFMA
+ * build (phases bit 8): UAVGNN_EUNSUPPORTED. */
+int uavgnn_gatv2_hetero_fwd_rowmax(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order,
+                                   const float* x_ubs, int E_near, const int32_t* near_off, const float* x_dst, int N,
+                                   const float* const* seen_params, const float* const* near_params, int nh, int D, float slope,
+                                   const void* image, float* out, int ld_out, float* attn_save_seen, float* attn_save_near,
+                                   float* rowmax_near, float* rowmax_seen, int phases, uavgnn_stream_t stream);
 
 /* K1 backward: parameter gradients only (observations are leaves: the reference never needs d/dx, Appendix A.4).
  * out / d_out are the forward output and its gradient (same ld).  Gradients are OVERWRITTEN.  Deterministic: per

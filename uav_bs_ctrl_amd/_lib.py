@@ -43,6 +43,9 @@ SIGNATURES = {
     "uavgnn_gatv2_hetero_fwd_image": (_c_int, [_c_fp, _c_int, _c_ip, _c_ip, _c_fp, _c_int, _c_ip, _c_fp, _c_int,
                                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _c_int,
                                                _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_st]),
+    "uavgnn_gatv2_hetero_fwd_rowmax": (_c_int, [_c_fp, _c_int, _c_ip, _c_ip, _c_fp, _c_int, _c_ip, _c_fp, _c_int,
+                                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _c_int,
+                                                _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_st]),
     "uavgnn_gatv2_bwd_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
     "uavgnn_gatv2_bwd": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_ip, _c_ip, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
                                   _c_int, _c_int, _c_f32, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,

@@ -327,12 +327,19 @@ __global__ __launch_bounds__(kThreads) void gatv2_hetero_prepare_kernel(RelParam
 // IMG: the parameter image is copied from `image` (uavgnn_gatv2_hetero_prepare) instead of built (a template parameter, not a
 // branch: behind a run-time branch the compiler merges the load counts of the two sides pessimistically and the prologue waits
 // for its first round trip before it issues the second).
-template <bool SAVE, bool IMG>
+// RM: the maxima of the `near` half and of the `seen` half of every output row are written to rm_near / rm_seen [N] - the two row bounds
+// of the f16x2 f_aggr product behind a TIME-BATCHED launch (csrc/gemm_h2.hip takes the larger).  Every row's halves pass through registers
+// here and each element of the two arrays has exactly one writer (phase N: the near half of every destination and the residual-only seen
+// half of the isolated ones; phase S: the seen half of the others); rows are >= 0 behind the ReLU.  A template parameter: the plain
+// instantiations keep their register allocation (the rollout launch is store-bound and pays +1.9 us for the maxima: not used there).
+template <bool SAVE, bool IMG, bool RM = false>
 __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
     const float* __restrict__ x_gt, const int32_t* __restrict__ seen_off, const int32_t* __restrict__ seen_order,
     const float* __restrict__ x_ubs, const int32_t* __restrict__ near_off, const float* __restrict__ x_dst, int N,
     int E_seen, RelParams ps, RelParams pn, float slope, float* __restrict__ out, int ld_out, float* __restrict__ a_save_s_arg,
-    float* __restrict__ a_save_n_arg, int phases, const k1_u32x4* __restrict__ image) {
+    float* __restrict__ a_save_n_arg, int phases, const k1_u32x4* __restrict__ image, float* __restrict__ rm_near,
+    float* __restrict__ rm_seen) {
+  constexpr bool rm_on = RM;
   float* const a_save_n = SAVE ? a_save_n_arg : nullptr;
   float* a_save_s = SAVE ? a_save_s_arg : nullptr;   // (the host launches the SAVE instantiation when either buffer is given)
   // everything a workgroup needs from the parameters (K1Image, 61 KB): built here, or copied from a caller-provided image
@@ -512,6 +519,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
       // prefetches behind them are waited for with counted s_waitcnt).  Storing from the transposed product D[destination]
       // [channel] without LDS - 64-byte pieces per 16 lanes - was measured: four times the store instructions, 12 cycles
       // each in the memory pipeline, slower.
+      float nmx = 0.f;   // RM: running maximum of this lane's pieces of the `near` rows (lane (j, g): destination j)
       auto emit = [&](const int set, const int col0, const unsigned mask, const k1_bf16x8* bop, const bool per_head) {
 #pragma unroll
         for (int hp = 0; hp < 2; ++hp) {
@@ -527,6 +535,7 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
             d[1] = fmaxf(d[1], 0.f);
             d[2] = fmaxf(d[2], 0.f);
             d[3] = fmaxf(d[3], 0.f);
+            if (rm_on) nmx = fmaxf(fmaxf(nmx, d[0]), fmaxf(fmaxf(d[1], d[2]), d[3]));
             *reinterpret_cast<f32x4*>(rw + j * kBounceLd + c * 16 + 4 * g) = d;
           }
           wave_sync_lds();
@@ -572,6 +581,9 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
             const float4 br4 = reinterpret_cast<const float4*>(sBrs)[lane_s];
             const float4 wr_lo = reinterpret_cast<const float4*>(sWrs)[2 * lane_s], wr_hi = reinterpret_cast<const float4*>(sWrs)[2 * lane_s + 1];
             float* const rs = row0 + 4 * lane;
+            unsigned su[16];    // RM: maximum of the residual-only row of destination d (scalar registers)
+#pragma unroll
+            for (int d = 0; d < 16; ++d) su[d] = 0u;
 #pragma unroll
             for (int d = 0; d < 16; ++d) {
               if ((imask >> d) & 1u) {   // wave-uniform
@@ -582,7 +594,18 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
                 o[2] = fmaxf(fmaf(wr_hi.y, x1, fmaf(wr_hi.x, x0, br4.z)), 0.f);
                 o[3] = fmaxf(fmaf(wr_hi.w, x1, fmaf(wr_hi.z, x0, br4.w)), 0.f);
                 __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(rs + static_cast<size_t>(d) * ld_out));
+                if (rm_on) {   // 16-lane rows by DPP, the four rows on the scalar unit (values >= 0: integer max of the bit patterns)
+                  const unsigned mu = __float_as_uint(row16_max(fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3]))));
+                  su[d] = max(max(__builtin_amdgcn_readlane(mu, 0), __builtin_amdgcn_readlane(mu, 16)),
+                              max(__builtin_amdgcn_readlane(mu, 32), __builtin_amdgcn_readlane(mu, 48)));
+                }
               }
+            }
+            if (rm_on) {
+              unsigned sres = 0u;
+#pragma unroll
+              for (int d = 0; d < 16; ++d) sres = (lane == d) ? su[d] : sres;
+              if (lane < 16 && ((imask >> lane) & 1u)) rm_seen[v0 + lane] = __uint_as_float(sres);
             }
           }
           if (blk == it0) { K1_STAMP(3) }
@@ -676,6 +699,11 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
           for (int k = 0; k < NH; ++k) bop[k] = k1_b_operand(g < 2 ? ag[k] : xvg, one_epi);
           wave_sync_lds();   // cw is rewritten by the next block
           emit(kSetEpiNear, H, vmask, bop, true);
+          if (rm_on) {
+            float t = fmaxf(nmx, __shfl_xor(nmx, 16));
+            t = fmaxf(t, __shfl_xor(t, 32));
+            if (g == 0 && valid_v) rm_near[v0 + j] = t;
+          }
           if (blk == it0) { K1_STAMP(5) }
         }
       }
@@ -806,6 +834,12 @@ __global__ __launch_bounds__(kThreads, 2) void gatv2_hetero_fwd_kernel(
         op[r] = fmaxf(agg + res[r], 0.f);
       }
       *reinterpret_cast<float4*>(out + static_cast<size_t>(v) * ld_out + 4 * lane) = o;
+      if (rm_on) {
+        float t = row16_max(fmaxf(fmaxf(op[0], op[1]), fmaxf(op[2], op[3])));
+        t = fmaxf(t, __shfl_xor(t, 16));
+        t = fmaxf(t, __shfl_xor(t, 32));
+        if (lane == 0) rm_seen[v] = t;
+      }
       wave_sync_lds();   // cw is rewritten by the next destination
     };
 
@@ -878,7 +912,9 @@ static int check_params(const float* const* seen_params, const float* const* nea
 static int k1_launch(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order, const float* x_ubs,
                      int E_near, const int32_t* near_off, const float* x_dst, int N, const float* const* seen_params,
                      const float* const* near_params, int nh, int D_, float slope, float* out, int ld_out,
-                     float* attn_save_seen, float* attn_save_near, const void* image, int phases, uavgnn_stream_t stream) {
+                     float* attn_save_seen, float* attn_save_near, const void* image, int phases, uavgnn_stream_t stream,
+                     float* rm_near = nullptr, float* rm_seen = nullptr) {
+  if ((rm_near == nullptr) != (rm_seen == nullptr)) return UAVGNN_EINVAL;
   if (N < 0 || E_seen < 0 || E_near < 0 || (E_seen > 0 && !x_gt) || (E_near > 0 && !x_ubs) || !seen_off || !near_off ||
       !x_dst || !out || ld_out < 2 * nh * D_)
     return UAVGNN_EINVAL;
@@ -892,6 +928,7 @@ static int k1_launch(const float* x_gt, int E_seen, const int32_t* seen_off, con
   if (E_near == 0) x_ubs = x_dst;   // masked slots read row 0 of x_ubs: any valid address will do when there are no edges
   hipStream_t st = static_cast<hipStream_t>(stream);
 #if !defined(K1_STANDALONE)
+  if ((phases & 256) && rm_near != nullptr) return UAVGNN_EUNSUPPORTED;   // the fp32-MFMA build writes no row maxima
   if (phases & 256)
     return gatv2_hetero_launch_f32(x_gt, E_seen, seen_off, seen_order, x_ubs, near_off, x_dst, N, seen_params, near_params,
                                    slope, out, ld_out, attn_save_seen, attn_save_near, phases, st);
@@ -906,9 +943,16 @@ static int k1_launch(const float* x_gt, int E_seen, const int32_t* seen_off, con
   const int ph = K1_ABLATE ? phases : (phases & 3);
   auto launch = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, st, x_gt, seen_off, seen_order, x_ubs, near_off, x_dst, N, E_seen, ps,
-                       pn, slope, out, ld_out, attn_save_seen, attn_save_near, ph, img);
+                       pn, slope, out, ld_out, attn_save_seen, attn_save_near, ph, img, rm_near, rm_seen);
   };
-  if (attn_save_near != nullptr || (attn_save_seen != nullptr && !(K1_ABLATE && (phases & 1024)))) {
+  const bool save = attn_save_near != nullptr || (attn_save_seen != nullptr && !(K1_ABLATE && (phases & 1024)));
+  if (rm_near != nullptr) {
+    if (save) {
+      if (img != nullptr) launch(gatv2_hetero_fwd_kernel<true, true, true>); else launch(gatv2_hetero_fwd_kernel<true, false, true>);
+    } else {
+      if (img != nullptr) launch(gatv2_hetero_fwd_kernel<false, true, true>); else launch(gatv2_hetero_fwd_kernel<false, false, true>);
+    }
+  } else if (save) {
     if (img != nullptr) launch(gatv2_hetero_fwd_kernel<true, true>); else launch(gatv2_hetero_fwd_kernel<true, false>);
   } else {
     if (img != nullptr) launch(gatv2_hetero_fwd_kernel<false, true>); else launch(gatv2_hetero_fwd_kernel<false, false>);
@@ -958,6 +1002,20 @@ extern "C" int uavgnn_gatv2_hetero_fwd_image(const float* x_gt, int E_seen, cons
   if (!image) return UAVGNN_EINVAL;
   return k1_launch(x_gt, E_seen, seen_off, seen_order, x_ubs, E_near, near_off, x_dst, N, seen_params, near_params, nh, D_,
                    slope, out, ld_out, attn_save_seen, attn_save_near, image, phases, stream);
+}
+
+// uavgnn_gatv2_hetero_fwd_image (image may be NULL: the in-kernel prologue) that ALSO writes rowmax_near / rowmax_seen [N]: the
+// maximum over the `near` / `seen` half of every output row (rows are >= 0) - the two row bounds uavgnn_gemm_nt_h2 takes for the
+// f_aggr product behind this launch (gnn_agents.py:106).  Not with the fp32-MFMA build (phases bit 8): UAVGNN_EUNSUPPORTED.
+extern "C" int uavgnn_gatv2_hetero_fwd_rowmax(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order,
+                                              const float* x_ubs, int E_near, const int32_t* near_off, const float* x_dst, int N,
+                                              const float* const* seen_params, const float* const* near_params, int nh, int D_,
+                                              float slope, const void* image, float* out, int ld_out, float* attn_save_seen,
+                                              float* attn_save_near, float* rowmax_near, float* rowmax_seen, int phases,
+                                              uavgnn_stream_t stream) {
+  if (!rowmax_near || !rowmax_seen) return UAVGNN_EINVAL;
+  return k1_launch(x_gt, E_seen, seen_off, seen_order, x_ubs, E_near, near_off, x_dst, N, seen_params, near_params, nh, D_, slope, out,
+                   ld_out, attn_save_seen, attn_save_near, image, phases, stream, rowmax_near, rowmax_seen);
 }
 
 extern "C" int uavgnn_gatv2_hetero_fwd(const float* x_gt, int E_seen, const int32_t* seen_off, const int32_t* seen_order,

@@ -16,6 +16,9 @@ HETERO_FUSED = True   # K1 forward of both encoder relations in one launch (csrc
 # K1's score GEMM on the bf16 matrix cores (exact three-way splits: fp32-level accuracy); False: the fp32-MFMA build of the same
 # kernel (csrc/gatv2_hetero_f32.hip) - the A/B reference and the K1 part of bench.py's strict-fp32 leg
 K1_BF16Z = os.environ.get("UAVGNN_K1_BF16Z", "1") != "0"
+# row maxima out of the time-batched K1 launches (more than K1_ROWMAX_MIN_ROWS destinations) for an f16x2 f_aggr forward (A/B switch)
+K1_ROWMAX = os.environ.get("UAVGNN_K1_ROWMAX", "1") != "0"
+K1_ROWMAX_MIN_ROWS = 1 << 17
 
 
 class _KernelTimer:
@@ -76,6 +79,7 @@ class _HeteroGATv2(th.autograd.Function):
     x_src, seg_off, dst_order, attn, W_s, b_s, W_d, b_d, W_r, b_r  (b_r and dst_order may be None)."""
 
     PER_REL = 10
+    last_rowmax = None      # (address of the output, rowmax_near, rowmax_seen) of the forward that just ran, for hetero_gatv2()
 
     @staticmethod
     def forward(ctx, x_dst, nh, train, *rel_args):
@@ -123,7 +127,15 @@ class _HeteroGATv2(th.autograd.Function):
                 head = (L.ptr(xs), xs.shape[0], L.ptr(so), L.ptr(oo), L.ptr(xn), xn.shape[0], L.ptr(no), L.ptr(x_dst), N, pa_s, pa_n,
                         nh, D, NEG_SLOPE)
                 tail = (out.data_ptr(), R * H, L.ptr(aS), L.ptr(aN), phases, L.stream())
-                if image is not None:
+                _HeteroGATv2.last_rowmax = None
+                if K1_ROWMAX and K1_BF16Z and GEMM_H2 and GEMM_X3 and N > K1_ROWMAX_MIN_ROWS:
+                    # time-batched launch: the maxima of the two halves of every output row on the way (+9 % on this launch) - the f_aggr
+                    # product behind it runs on the f16x2 kernel (-25 %); the store-bound rollout launch would pay +1.9 us of 20: plain there
+                    rmA, rmB = th.empty(N, dtype=th.float32, device=x_dst.device), th.empty(N, dtype=th.float32, device=x_dst.device)
+                    rc = lib.uavgnn_gatv2_hetero_fwd_rowmax(*head, L.ptr(image), out.data_ptr(), R * H, L.ptr(aS), L.ptr(aN), rmA.data_ptr(),
+                                                            rmB.data_ptr(), phases, L.stream())
+                    _HeteroGATv2.last_rowmax = (out.data_ptr(), rmA, rmB)
+                elif image is not None:
                     rc = lib.uavgnn_gatv2_hetero_fwd_image(*head, image.data_ptr(), *tail)
                 else:
                     rc = lib.uavgnn_gatv2_hetero_fwd_phases(*head, *tail)
@@ -184,7 +196,12 @@ def hetero_gatv2(x_dst, nh, relations):
     for x_src, seg_off, order, conv in relations:
         flat += [x_src, seg_off, order, conv.attn, conv.fc_src.weight, conv.fc_src.bias, conv.fc_dst.weight,
                  conv.fc_dst.bias, conv.res_fc.weight, conv.res_fc.bias]
-    return _HeteroGATv2.apply(x_dst, nh, th.is_grad_enabled(), *flat)
+    _HeteroGATv2.last_rowmax = None
+    out = _HeteroGATv2.apply(x_dst, nh, th.is_grad_enabled(), *flat)
+    rm, _HeteroGATv2.last_rowmax = _HeteroGATv2.last_rowmax, None
+    if rm is not None and rm[0] == out.data_ptr():
+        out._uavgnn_rowmax = rm[1:]        # (row maxima of the `near` / `seen` halves: read by linear_relu right behind this call)
+    return out
 
 
 def _talk_transpose_if_needed(g, *tensors):
@@ -864,9 +881,18 @@ class _LinearReLU(th.autograd.Function):
     the forward.  Backward masks dy with (y > 0) and reuses the split-K weight-gradient path."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, rm_a=None, rm_b=None):
         ctx.x_rowmax = None
+        ctx.n_extra = 0 if rm_a is None else 2
         n_out = W.shape[0]
+        rm = None if rm_a is None else (rm_a, rm_b)
+        if (rm is not None and b is not None and b.is_contiguous() and W.stride(1) == 1 and gemm_h2_supported(x, n_out, W.shape[1])):
+            # the producer (the time-batched K1 launch) left the maxima of the two halves of every row: the layer on the f16x2 kernel
+            y = gemm_h2(x, W, rm[0], False, bias=b, relu=True, rowmax2=rm[1])
+            if ctx.needs_input_grad[1]:
+                ctx.x_rowmax = th.maximum(rm[0], rm[1])
+            ctx.save_for_backward(x, W, y)
+            return y
         if (ctx.needs_input_grad[1] and n_out % 4 == 0 and gemm_x3_supported(x, n_out, W.shape[1]) and W.stride(1) == 1 and b is not None
                 and b.is_contiguous() and x.shape[0] >= GEMM_TN_MIN_ROWS and GEMM_TN_H2 and GEMM_H2 and n_out >= 256 and x.shape[1] >= 128
                 and L.lib().uavgnn_gemm_tn_h2_supported(x.shape[0], n_out, x.shape[1])):
@@ -903,12 +929,15 @@ class _LinearReLU(th.autograd.Function):
                 L.check(L.lib().uavgnn_relu_bwd_colsum(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), dym.data_ptr(), C, n, C,
                                                        part.data_ptr(), S, L.stream()), "uavgnn_relu_bwd_colsum")
             dx, dW, _ = _LinearSplitK._grads(ctx, x, W, dym, False, rowmax=rowmax, x_rowmax=ctx.x_rowmax)
-            return dx, dW, part.sum(0)
+            return (dx, dW, part.sum(0)) + (None,) * ctx.n_extra
         dy = th.ops.aten.threshold_backward(dy, y, 0.0)     # dy where y > 0 else 0, one pass (compare + where were two)
-        return _LinearSplitK._grads(ctx, x, W, dy, True)
+        return tuple(_LinearSplitK._grads(ctx, x, W, dy, True)) + (None,) * ctx.n_extra
 
 
 def linear_relu(x, W, b):
+    rm = getattr(x, "_uavgnn_rowmax", None)      # left by hetero_gatv2 on a time-batched launch
+    if rm is not None:
+        return _LinearReLU.apply(x, W, b, rm[0], rm[1])
     return _LinearReLU.apply(x, W, b)
 
 
