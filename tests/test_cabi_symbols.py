@@ -21,6 +21,14 @@ def test_library_builds_loads_and_exports_every_declared_symbol(repo_root):
     public, probe = _declared(repo_root), _declared(repo_root, "uavgnn_probe.h")
     assert probe and not set(public) & set(probe), "a symbol is declared in both headers"
     assert not any("_dbg" in n for n in public), "debug entries belong to include/uavgnn_probe.h"
+    # the product (everything under uav_bs_ctrl_amd/ but the ctypes table) calls the public header only
+    pkg = os.path.join(repo_root, "uav_bs_ctrl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py") and f != "_lib.py":
+                text = open(os.path.join(dirpath, f)).read()
+                used = [n for n in probe if re.search(r"\b" + n + r"\b", text)]
+                assert not used, f"{os.path.join(dirpath, f)} calls probe-only entries {used}"
     names = sorted(public + probe)
     assert "uavgnn_gatv2_fwd" in names and "uavgnn_talk_attn_bwd" in names
     for n in names:

@@ -3160,8 +3160,18 @@ def test_time_batched_linear_relu_weight_gradient_on_the_f16x2_kernel(monkeypatc
     assert {"uavgnn_gemm_nt_x3_rowmax", "uavgnn_relu_bwd_colsum_rowmax", "uavgnn_gemm_nt_h2", "uavgnn_gemm_tn_h2"} <= set(spy.names), sorted(set(spy.names))
     m = 16384      # float64 reference of y and dx on a prefix of the rows; dW / db on all rows in float64 on the device
     x64, W64, b64 = x.detach().double(), W.detach().double(), b.detach().double()
-    y64 = th.relu(x64 @ W64.t() + b64)
-    gm = g.double() * (y64 > 0)
+    pre64 = x64 @ W64.t() + b64
+    y64 = th.relu(pre64)
+    # the ReLU mask is a discontinuity of the gradient: a pre-activation within rounding of zero may fall on either side in fp32 (a handful of
+    # 6.7e7 here, each moving one entry of dW by |g x| ~ 1e-3 of it).  The float64 reference takes the GPU's side after checking that every
+    # disagreement sits ON the kink (the rule of test_learner_update_at_exp3_sizes_vs_oracle)
+    mask = y.detach() > 0
+    flips = mask != (pre64 > 0)
+    assert int(flips.sum()) <= 1e-6 * flips.numel() + 2, int(flips.sum())
+    if bool(flips.any()):
+        assert float(pre64[flips].abs().max()) <= 1e-5 * float(pre64.abs().max())
+    del pre64
+    gm = g.double() * mask
     assert_close(y[:m], y64[:m], 1e-5, "y")
     assert_close(dx[:m], (gm @ W64)[:m], 1e-5, "dx (f16x2)")
     monkeypatch.setattr(ops, "GEMM_H2", False)
