@@ -32,6 +32,84 @@ def build():
         list(ex.map(one, VARIANTS))
 
 
+AB = {"persistent": ["-DUAVGNN_H2_PERSIST=1"], "one_tile_per_wg": ["-DUAVGNN_H2_PERSIST=0"]}
+
+
+def build_ab():
+    """A/B builds: the experimental kernel of tools/ubench/gru_h2_persistent.hip (persistent grid / one workgroup per tile) and `base`, the
+    shipped csrc/gru_h2.hip."""
+    os.makedirs(OUT, exist_ok=True)
+    src = os.path.join(ROOT, "tools", "ubench", "gru_h2_persistent.hip")
+    jobs = [(n, src, f) for n, f in AB.items()] + [("base", os.path.join(ROOT, "uav_bs_ctrl_amd", "csrc", "gru_h2.hip"), [])]
+    for n, f, flags in jobs:
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *flags,
+                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "uav_bs_ctrl_amd", "csrc"), f, "-o",
+                        os.path.join(OUT, f"h2_ab_{n}.so")], check=True)
+
+
+def main_ab():
+    import torch as th
+    from uav_bs_ctrl_amd import _lib as L
+    from uav_bs_ctrl_amd import ops
+    N, H, M = 32768, 256, 64
+    dev = th.device("cuda")
+    lib = L.lib()
+    th.manual_seed(3)
+    x, c, h = th.relu(th.randn(N, H, device=dev)), 0.5 * th.randn(N, M, device=dev), th.tanh(th.randn(N, H, device=dev))
+    W_ih, W_hh = th.randn(3 * H, H + M, device=dev) / 18, th.randn(3 * H, H, device=dev) / 16
+    b = 0.1 * th.randn(3 * H, device=dev)
+    planes = th.empty(lib.uavgnn_gru_cell_h2_workspace_bytes(H + M, H), dtype=th.uint8, device=dev)
+    L.check(lib.uavgnn_gru_split_weights_h2(W_ih.data_ptr(), H + M, W_hh.data_ptr(), H, planes.data_ptr(), L.stream()), "split")
+    rm = ops.row_absmax(x, c, h)
+    names = [n for n in list(AB) + ["base"] if os.path.exists(os.path.join(OUT, f"h2_ab_{n}.so"))]
+    outs = {}
+
+    def timeit(fn, reps=40):
+        for _ in range(5):
+            fn()
+        th.cuda.synchronize()
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / reps
+
+    print(f"# f16x2 GRU cell, N = {N}, K_in = {H + M}, H = {H}, two-piece call: us per call (min of 3 x 40 back-to-back calls), 2 passes")
+    fns = {}
+    for n in names:
+        dl = ctypes.CDLL(os.path.join(OUT, f"h2_ab_{n}.so"))
+        f = dl.uavgnn_gru_cell_fwd_h2
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                      ctypes.c_void_p]
+        fns[n] = f
+    for ps in range(2):
+        for n in names:
+            f = fns[n]
+            h2, pre = th.empty(N, H, device=dev), th.empty(N, 4 * H, device=dev)
+            call = lambda pre_=None: f(x.data_ptr(), H, H, c.data_ptr(), M, M, h.data_ptr(), N, H, rm.data_ptr(), planes.data_ptr(),  # noqa: E731
+                                       b.data_ptr(), b.data_ptr(), h2.data_ptr(), pre_, L.stream())
+            assert call() == 0
+            t0 = min(timeit(call) for _ in range(3))
+            t1 = min(timeit(lambda: call(pre.data_ptr())) for _ in range(3))
+            th.cuda.synchronize()
+            outs[n] = (h2.clone(), pre.clone())
+            # ragged row count (not a multiple of 128, padding tiles in the last group of row blocks)
+            Nr = 32768 - 128 * 5 - 37
+            h3 = th.zeros(N, H, device=dev)
+            assert f(x.data_ptr(), H, H, c.data_ptr(), M, M, h.data_ptr(), Nr, H, rm.data_ptr(), planes.data_ptr(), b.data_ptr(), b.data_ptr(),
+                     h3.data_ptr(), None, L.stream()) == 0
+            th.cuda.synchronize()
+            ok = bool(th.equal(h3[:Nr], outs[n][0][:Nr])) and float(h3[Nr:].abs().max()) == 0.0
+            print(f"pass {ps + 1}  {n:16s} no-grad {t0:6.1f}   with saves {t1:6.1f}   ragged N ok: {ok}")
+    ref = outs[names[0]]
+    for n in names[1:]:
+        print(f"{n} == {names[0]}: h' {bool(th.equal(outs[n][0], ref[0]))}, pre {bool(th.equal(outs[n][1], ref[1]))}")
+
+
 def main():
     import torch as th
     from uav_bs_ctrl_amd import _lib as L
@@ -76,4 +154,7 @@ def main():
 
 
 if __name__ == "__main__":
-    build() if "--build" in sys.argv else main()
+    if "--ab" in sys.argv:
+        build_ab() if "--build" in sys.argv else main_ab()
+    else:
+        build() if "--build" in sys.argv else main()
