@@ -40,7 +40,8 @@ def build_ab():
     shipped csrc/gru_h2.hip."""
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(ROOT, "tools", "ubench", "gru_h2_persistent.hip")
-    jobs = [(n, src, f) for n, f in AB.items()] + [("base", os.path.join(ROOT, "uav_bs_ctrl_amd", "csrc", "gru_h2.hip"), [])]
+    jobs = [(n, src, f) for n, f in AB.items()] + [("base", os.path.join(ROOT, "uav_bs_ctrl_amd", "csrc", "gru_h2.hip"), []),
+                                                   ("w4_64x64", os.path.join(ROOT, "tools", "ubench", "gru_h2_w4.hip"), [])]
     for n, f, flags in jobs:
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *flags,
                         "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "uav_bs_ctrl_amd", "csrc"), f, "-o",
@@ -61,7 +62,7 @@ def main_ab():
     planes = th.empty(lib.uavgnn_gru_cell_h2_workspace_bytes(H + M, H), dtype=th.uint8, device=dev)
     L.check(lib.uavgnn_gru_split_weights_h2(W_ih.data_ptr(), H + M, W_hh.data_ptr(), H, planes.data_ptr(), L.stream()), "split")
     rm = ops.row_absmax(x, c, h)
-    names = [n for n in list(AB) + ["base"] if os.path.exists(os.path.join(OUT, f"h2_ab_{n}.so"))]
+    names = [n for n in list(AB) + ["base", "w4_64x64"] if os.path.exists(os.path.join(OUT, f"h2_ab_{n}.so"))]
     outs = {}
 
     def timeit(fn, reps=40):

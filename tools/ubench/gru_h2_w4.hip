@@ -1,9 +1,5 @@
-// EXPERIMENT, not part of libuavgnn.so (tools/h2_ablate.py --ab builds it beside the shipped kernel): csrc/gru_h2.hip with (i) persistent
-// workgroups - one per CU, the next tile's first two slices and row scales requested at the start of the epilogue -, (ii) the epilogue's h
-// tile fetched through the slice cursor under the last three iterations' MFMAs, (iii) the per-column constants requested in front of the
-// epilogue's first barrier.  Bit-identical results; measured on one box (profiles/r06_h2_cell_persistent_ab.txt): 103.6 / 111.2 us
-// (no-grad / with saves) against 103.1 / 111.8 us for the shipped kernel and 103.6 / 110.8 with -DUAVGNN_H2_PERSIST=0 (ii + iii only):
-// nothing.  The ~32 us the kernel spends outside its slice loop (profiles/r06_h2_cell_ablate.txt) are not exposed latency.
+// EXPERIMENT, not part of libuavgnn.so (tools/h2_ablate.py --ab): csrc/gru_h2.hip with workgroups of FOUR wavefronts on 64 x 64 tiles, two
+// workgroups per CU (64 KB of LDS each) - two independent barrier domains per CU instead of one, at 1.6 x the L2 -> LDS bytes per row.
 // K4 on the f16 matrix cores with an exactly scaled TWO-term split ("f16x2"): the whole GRU cell in one kernel, as gru_x3.hip, at
 // HALF the matrix-core work - three f16 products per fp32 product instead of bf16x3's six.
 // Replaces nn.GRUCell at /root/reference/algos/madrqn/agents/gnn_agents.py:246 (TarMAC's f_udt; gate order r, z, n):
@@ -51,8 +47,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int BM = 128, BK = 32, BJ = 64, NT = 512, ST = 68;
-constexpr int kCUs = 256;                            // MI355X: the persistent grid (one workgroup per CU)
+constexpr int BM = 64, BK = 32, BJ = 64, NT = 256, ST = 68;
+constexpr int NB = 2 * 3 * BJ * 4 / NT;              // weight chunks per thread and slice (6)
+constexpr int RS = NT / 8;                           // rows per pass of the A loader (32)
 constexpr int PA = BM * 4, PB = 3 * BJ * 4;            // 16-byte chunks per split plane of the A / B tile
 constexpr int BUF = 2 * PA + 2 * PB;                   // chunks per buffer (40 KB)
 
@@ -122,81 +119,56 @@ __global__ __launch_bounds__(256) void split_planes_h2_kernel(const float* __res
 
 // products of one fp32 product, smallest first: (a_hi b_lo) (a_lo b_hi) (a_hi b_hi)
 template <bool SAVE>
-__global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
+__global__ __launch_bounds__(NT, 2) void gru_cell_fwd_h2_kernel(
     const float* __restrict__ inp, int ld_inp, int K1, const float* __restrict__ inp2, int ld_inp2, int K2,
     const float* __restrict__ h, int N, int H, const float* __restrict__ row_absmax,
     const unsigned short* __restrict__ Wih_p, const float* __restrict__ b_ih, const unsigned short* __restrict__ Whh_p,
-    const float* __restrict__ b_hh, const float* __restrict__ winv, float* __restrict__ h_out, float* __restrict__ pre, int row_blocks,
-    int tiles) {
+    const float* __restrict__ b_hh, const float* __restrict__ winv, float* __restrict__ h_out, float* __restrict__ pre, int row_blocks) {
   __shared__ u32x4 smem[2 * BUF];   // buffer b: A planes [2][128][4] then B planes [2][192 = gate * 64 + unit][4]
   __shared__ float sInv[BM];        // 2^-e_row of the block's rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 32, wc = (wave & 1) * 32;
   const int CB = H / BJ;
-  // Persistent workgroups (one per CU: 80 KB of LDS, 234 VGPRs x 512 threads): workgroup b takes the tiles b, b + grid, ... (the grid is a
-  // multiple of 8, so a workgroup's tiles keep its XCD: tile -> XCD tile % 8, the column blocks of one row block on the same XCD).  With one
-  // workgroup per CU nothing covers a tile's first round trip or its epilogue, so the NEXT tile's first two slices are requested at the
-  // start of the epilogue and arrive under the gate math.
-  int m0 = 0, j0 = 0;
-  auto decode = [&](int tile) {      // -> false for the padding tiles of the last row-block group
-    const int xcd = tile & 7, slot = tile >> 3;
-    const int rb = (slot / CB) * 8 + xcd, cb = slot - (slot / CB) * CB;
-    m0 = rb * BM;
-    j0 = cb * BJ;
-    return rb < row_blocks;
-  };
-  auto next_valid = [&](int tile) {
-    while (tile < tiles && !decode(tile)) tile += gridDim.x;
-    return tile;
-  };
-  int tile = next_valid(blockIdx.x);
-  if (tile >= tiles) return;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int rb = (slot / CB) * 8 + xcd, cb = slot - (slot / CB) * CB;
+  if (rb >= row_blocks) return;
+  const int m0 = rb * BM, j0 = cb * BJ;
 
   f32x16 acc[4];     // 32 x 32 tile per set: r, z, gi_n, gh_n
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[s][i] = 0.f;
   const int l32 = lane & 31, lh = lane >> 5, sw = swz32(l32);
   // A loader: float4 q = tid + 512 i -> row tid / 8 + 64 i, k = 4 (tid % 8); rows past N are clamped (stores are masked)
   const int lr = tid >> 3, c4 = tid & 7;
   const int sa_w = lr * 32 + (((c4 >> 1) ^ swz32(lr)) * 8) + (c4 & 1) * 4;   // in f16 units inside an A plane
   // B loader: chunk q = tid + 512 i (i < 3, 1536 chunks): plane q / 768, row (q % 768) / 4 = gate * 64 + unit, chunk q % 4
-  unsigned rowa[2], wrow[3];
+  unsigned rowa[2], wrow[NB];
   float sca[2];
-  int sbw[3];
+  int sbw[NB];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 2; ++i) {
+    rowa[i] = static_cast<unsigned>(min(m0 + lr + RS * i, N - 1));
+    sca[i] = pow2f(scale_exp(row_absmax[rowa[i]]));
+  }
+  if (tid < BM) sInv[tid] = pow2f(-scale_exp(row_absmax[min(m0 + tid, N - 1)]));
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
     const int q = tid + NT * i, pl = q / PB, rem = q - pl * PB, row = rem >> 2, c = rem & 3;
+    wrow[i] = static_cast<unsigned>(pl * 3 * H + (row >> 6) * H + j0 + (row & 63));
     sbw[i] = 2 * PA + pl * PB + row * 4 + (c ^ swz32(row));
   }
-  auto tile_rows = [&]() {           // loader state of the tile (m0, j0): rows, row scales, weight rows
-    int tidl = tid;
-    asm volatile("" : "+v"(tidl));   // (as in the epilogue: nothing of this is to be carried through the slice loop)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      rowa[i] = static_cast<unsigned>(min(m0 + (tidl >> 3) + 64 * i, N - 1));
-      sca[i] = pow2f(scale_exp(row_absmax[rowa[i]]));
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int q = tidl + NT * i, pl = q / PB, rem = q - pl * PB, row = rem >> 2;
-      wrow[i] = static_cast<unsigned>(pl * 3 * H + (row >> 6) * H + j0 + (row & 63));
-    }
-  };
-  auto tile_inv = [&]() {            // 2^-e of the tile's rows for the epilogue (written behind a barrier that follows the previous tile's gate math)
-    int tidl = tid;
-    asm volatile("" : "+v"(tidl));
-    if (tidl < BM) sInv[tidl] = pow2f(-scale_exp(row_absmax[min(m0 + tidl, N - 1)]));
-  };
-  tile_rows();
-  tile_inv();
   const unsigned wc8 = 16u * (tid & 3);    // byte offset of the lane's 8-f16 chunk inside a weight slice
   const int n1 = K1 / BK, n12 = n1 + K2 / BK, ns = n12 + H / BK;   // slices of inp, of [inp || inp2], of everything
   // TWO register sets: the loads of slice t + 3 are issued while slice t computes (two iterations of latency cover; with one set -
   // one iteration - the staging waited for its loads: 26 of the kernel's 117 us in tools/h2_ablate.py)
   float4 ra[2][2];
-  u32x4 rw[2][3];
-  unsigned oa[2], ow[3];
+  u32x4 rwb[NB];             // ONE set for the weight chunks (L2 hits: one iteration of cover), two for the activations
+  unsigned oa[2], ow[NB];
   const char* __restrict__ Ab = reinterpret_cast<const char*>(inp);
   const char* __restrict__ Wb = reinterpret_cast<const char*>(Wih_p);
-  int lt = 0;                                                // the slice the next load fetches
+  int lt = 0, ltw = 0;                                       // the slice the next activation / weight load fetches
   auto set_a = [&](const float* base, int ld) {
     Ab = reinterpret_cast<const char*>(base);
 #pragma unroll
@@ -205,70 +177,48 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
   auto set_w = [&](const unsigned short* base, int K) {
     Wb = reinterpret_cast<const char*>(base);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) ow[i] = 2u * wrow[i] * static_cast<unsigned>(K) + wc8;
+    for (int i = 0; i < NB; ++i) ow[i] = 2u * wrow[i] * static_cast<unsigned>(K) + wc8;
   };
-  auto rewind = [&]() {              // cursor to slice 0 of the tile whose loader state tile_rows() has set
-    lt = 0;
-    set_a(inp, ld_inp);
-    set_w(Wih_p, K1 + K2);
-  };
-  rewind();
+  set_a(inp, ld_inp);
+  set_w(Wih_p, K1 + K2);
   auto gload_a = [&](auto set) {
     constexpr int S = decltype(set)::value;
 #pragma unroll
     for (int i = 0; i < 2; ++i) ra[S][i] = *reinterpret_cast<const float4*>(Ab + oa[i]);
   };
-  auto gload_w = [&](auto set) {
-    constexpr int S = decltype(set)::value;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) rw[S][i] = *reinterpret_cast<const u32x4*>(Wb + ow[i]);
-  };
-  // Past the last slice the A cursor moves on to the EPILOGUE's operand: the block's [128 x 64] tile of h in the epilogue's layout
-  // (float4 q = tid + 512 i -> row q / 16, columns 4 (q % 16)), "slice" ns = its first half (i < 2), ns + 1 = the second, ns + 2 = the
-  // first again.  The loop issues the loads of slice t + 3 in iteration t, so the tile arrives in the two register sets under the MFMAs of
-  // the last three iterations instead of as an exposed round trip in front of the gate math (one workgroup per CU: nothing else would
-  // cover it).  The weight cursor stays on the last slice (three redundant loads of L2-resident lines).
-  auto set_h_tile = [&](int half) {
-    Ab = reinterpret_cast<const char*>(h);
-    int tidl = tid;
-    asm volatile("" : "+v"(tidl));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tidl + NT * (2 * half + i);
-      oa[i] = 4u * (static_cast<unsigned>(min(m0 + (idx >> 4), N - 1)) * static_cast<unsigned>(H) + static_cast<unsigned>(j0 + 4 * (idx & 15)));
-    }
-  };
-  auto advance = [&]() {      // after both loads of slice lt were issued
-    ++lt;
-    if (lt >= ns) {
-      set_h_tile((lt - ns) & 1);
-      return;
-    }
-    Ab += 4 * BK;
+  auto advance_w = [&]() {
+    if (ltw + 1 >= ns) return;
+    ++ltw;
     Wb += 2 * BK;
+    if (ltw == n12) set_w(Whh_p, H);
+  };
+  auto gload_w = [&](auto) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rwb[i] = *reinterpret_cast<const u32x4*>(Wb + ow[i]);
+    advance_w();
+  };
+  auto advance = [&]() {      // after the activation loads of slice lt were issued; past the last slice the cursor stays on it
+    if (lt + 1 >= ns) return;
+    ++lt;
+    Ab += 4 * BK;
     if (lt == n1 && n12 > n1) set_a(inp2, ld_inp2);
-    if (lt == n12) {
-      set_a(h, H);
-      set_w(Whh_p, H);
-    }
+    if (lt == n12) set_a(h, H);
   };
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, 1>;
   auto gload = [&](auto set) {
     gload_a(set);
-    gload_w(set);
     advance();
   };
-  auto lstore_b = [&](int buf, auto set) {
-    constexpr int S = decltype(set)::value;
+  auto lstore_b = [&](int buf, auto) {
     u32x4* sb = smem + buf * BUF;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) sb[sbw[i]] = rw[S][i];
+    for (int i = 0; i < NB; ++i) sb[sbw[i]] = rwb[i];
   };
   auto lstore_a = [&](int buf, int i, auto set) {
     constexpr int S = decltype(set)::value;
     unsigned short* sa = reinterpret_cast<unsigned short*>(smem + buf * BUF) + sa_w;
-    stage4(sa + 64 * i * 32, PA * 8, ra[S][i], sca[i]);
+    stage4(sa + RS * i * 32, PA * 8, ra[S][i], sca[i]);
   };
   auto lstore = [&](int buf, auto set) {
     lstore_a(buf, 0, set);
@@ -304,14 +254,11 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
   }
 
   gload(Set0{});          // slice 0
-  gload(Set1{});          // slice 1
-  for (;;) {              // ---- one tile per trip; slices 0 and 1 of the tile are in flight or in the register sets ----------------------
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[s][i] = 0.f;
+  gload_w(Set0{});
   lstore(0, Set0{});
+  gload(Set1{});          // slice 1
   gload(Set0{});          // slice 2
+  gload_w(Set0{});        // weights of slice 1
   __syncthreads();
   // Software pipeline as in gru_x3.hip: the fragment reads of a half are issued one MFMA group (9 MFMAs) before their use; iteration
   // t stages slice t + 1 into the other buffer INSIDE its first MFMA group (an independent VALU / LDS / memory instruction issues in
@@ -333,8 +280,8 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
     UAVGNN_H2_TERM(0, 1)                                   \
     _Pragma("unroll") for (int sg = 0; sg < 3; ++sg) {     \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   \
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   \
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);   \
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   \
     }                                                      \
     __builtin_amdgcn_sched_barrier(0);                     \
     if (!(UAVGNN_H2_DBG & 2)) { lstore_a((t + 1) & 1, 0, SET_{}); lstore_a((t + 1) & 1, 1, SET_{}); } \
@@ -386,51 +333,30 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
 #undef UAVGNN_H2_MFMA
 #undef UAVGNN_H2_READ
 #undef UAVGNN_H2_TERM
-  // (the epilogue's address arithmetic starts from an opaque copy of the thread id: otherwise the compiler hoists it out of the tile loop and
-  // carries ~25 registers through the slice loop, which then spills)
-  int tide = tid;
-  asm volatile("" : "+v"(tide));
-  const int l32e = tide & 31, lhe = (tide >> 5) & 1, wme = (tide >> 7) * 32, wce = ((tide >> 6) & 1) * 32;
-  // the per-column constants of the gate math: requested in front of the barrier, they arrive under it and the tile's LDS pass
-  const int c = j0 + wce + l32e;   // (m0, j0: still this tile's)
-  const float b_r = b_ih[c] + b_hh[c], b_z = b_ih[H + c] + b_hh[H + c], b_in = b_ih[2 * H + c], b_hn = b_hh[2 * H + c];
-  const float ci_r = winv[c], ci_z = winv[H + c], ci_n = winv[2 * H + c];   // 2^-e of the three weight rows of this hidden unit
   __syncthreads();   // the last iteration's read of the stale buffer must not race the epilogue's tile
   // ---- epilogue on the D layout: lane l holds column l % 32, register i holds row 8 (i / 4) + 4 (l / 32) + i % 4 ----------------
   float* sH = reinterpret_cast<float*>(smem);             // [128][ST] fp32 tile: h in, h' out, 16-byte row-contiguous HBM accesses
-  {
-    // the h tile sits in the register sets: "slice" ns in set ns % 2, ns + 1 in the other (see advance())
-    auto park = [&](auto first) {                           // half q / 2 lives in set (ns + q / 2) % 2
-      constexpr int S0 = decltype(first)::value;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int idx = tide + NT * q, row = idx >> 4, cc = idx & 15;
-        *reinterpret_cast<float4*>(sH + row * ST + 4 * cc) = ra[(S0 + (q >> 1)) & 1][q & 1];
-      }
-    };
-    if (ns & 1) park(Set1{}); else park(Set0{});            // (uniform branch: a select between register sets goes through scratch)
-  }
-  // the register sets are free: the next tile's first two slices (and its row scales) go out now and arrive under the gate math
-  const int m0e = m0, j0e = j0;
-  const int next = next_valid(tile + static_cast<int>(gridDim.x));   // (moves m0, j0 on to that tile)
-  if (next < tiles) {
-    tile_rows();
-    rewind();
-    gload(Set0{});
-    gload(Set1{});
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + NT * q, row = idx >> 4, cc = idx & 15;
+    *reinterpret_cast<float4*>(sH + row * ST + 4 * cc) =
+        *reinterpret_cast<const float4*>(h + static_cast<size_t>(min(m0 + row, N - 1)) * H + j0 + 4 * cc);
   }
   __syncthreads();
+  const int c = j0 + wc + l32;
+  const float b_r = b_ih[c] + b_hh[c], b_z = b_ih[H + c] + b_hh[H + c], b_in = b_ih[2 * H + c], b_hn = b_hh[2 * H + c];
+  const float ci_r = winv[c], ci_z = winv[H + c], ci_n = winv[2 * H + c];   // 2^-e of the three weight rows of this hidden unit
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const int lrow = wme + 8 * (i >> 2) + 4 * lhe + (i & 3);
-    const int row = m0e + lrow;
+    const int lrow = wm + 8 * (i >> 2) + 4 * lh + (i & 3);
+    const int row = m0 + lrow;
     const float ri = sInv[lrow];
     // two exact power-of-two factors (their product alone may leave the fp32 range), then the bias: one rounding, as before
     const float pr = acc[0][i] * ri * ci_r + b_r, pz = acc[1][i] * ri * ci_z + b_z;
     const float gin = acc[2][i] * ri * ci_n + b_in, ghn = acc[3][i] * ri * ci_n + b_hn;
     const float rr = sigmoidf_(pr), zz = sigmoidf_(pz);
     const float nn = tanhf_(fmaf(rr, ghn, gin));
-    float* hp = sH + lrow * ST + wce + l32e;
+    float* hp = sH + lrow * ST + wc + l32;
     *hp = fmaf(zz, *hp - nn, nn);                          // every element of the tile has exactly one owner lane
     if (SAVE && row < N) {
       float* p = pre + static_cast<size_t>(row) * 4 * H + c;
@@ -443,15 +369,10 @@ __global__ __launch_bounds__(NT) void gru_cell_fwd_h2_kernel(
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int idx = tide + NT * q, row = idx >> 4, cc = idx & 15;
-    if (m0e + row < N)
-      *reinterpret_cast<float4*>(h_out + static_cast<size_t>(m0e + row) * H + j0e + 4 * cc) =
+    const int idx = tid + NT * q, row = idx >> 4, cc = idx & 15;
+    if (m0 + row < N)
+      *reinterpret_cast<float4*>(h_out + static_cast<size_t>(m0 + row) * H + j0 + 4 * cc) =
           *reinterpret_cast<const float4*>(sH + row * ST + 4 * cc);
-  }
-  if (next >= tiles) break;
-  tile = next;
-  tile_inv();        // (every wavefront is past its reads of the previous tile's values: the barrier above)
-  __syncthreads();   // the tile parked in buffer 0 has been read: the next trip's staging may overwrite it
   }
 }
 
@@ -509,18 +430,15 @@ extern "C" int uavgnn_gru_cell_fwd_h2(const float* inp, int ld_inp, int K1, cons
   const unsigned short* p0 = static_cast<const unsigned short*>(planes);
   const unsigned short* p1 = p0 + 6LL * H * K_in;
   const float* winv = reinterpret_cast<const float*>(p1 + 6LL * H * H);
-  const int row_blocks = (N + BM - 1) / BM, rb8 = ((row_blocks + 7) / 8) * 8, tiles = rb8 * (H / BJ);
+  const int row_blocks = (N + BM - 1) / BM, rb8 = ((row_blocks + 7) / 8) * 8;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#ifndef UAVGNN_H2_PERSIST
-#define UAVGNN_H2_PERSIST 1     /* 0: one workgroup per tile (the A/B reference of tools/h2_ablate.py) */
-#endif
-  const dim3 grid(UAVGNN_H2_PERSIST ? (tiles < kCUs ? tiles : kCUs) : tiles), block(NT);   // (tiles and kCUs are multiples of 8)
+  const dim3 grid(rb8 * (H / BJ)), block(NT);
   if (pre_save != nullptr)
     hipLaunchKernelGGL(gru_cell_fwd_h2_kernel<true>, grid, block, 0, st, inp, ld_inp, K1, inp2, ld_inp2, K2, h, N, H, row_absmax, p0, b_ih,
-                       p1, b_hh, winv, h_out, pre_save, row_blocks, tiles);
+                       p1, b_hh, winv, h_out, pre_save, row_blocks);
   else
     hipLaunchKernelGGL(gru_cell_fwd_h2_kernel<false>, grid, block, 0, st, inp, ld_inp, K1, inp2, ld_inp2, K2, h, N, H, row_absmax, p0, b_ih,
-                       p1, b_hh, winv, h_out, pre_save, row_blocks, tiles);
+                       p1, b_hh, winv, h_out, pre_save, row_blocks);
   return launch_status();
 }
 
