@@ -13,7 +13,8 @@
 //     TFLOP/s).  Here the tiles are staged as they come - float4 loads of whole rows, scaled, split, 8-byte LDS writes - into [16 columns]
 //     x [32 rows] sub-tiles, and the fragments are read with gfx950's transposing LDS read (ds_read_b64_tr_b16: the 16 lanes of a group
 //     name a 4-row x 16-column block, lane c receives column c's four k values): two of them per fragment, no VALU.
-// One workgroup: 256 x 128 output tile, eight wavefronts of 64 x 64 (2 x 2 tiles of v_mfma_f32_32x32x16_f16), LDS double-buffered with
+// One workgroup: 256 x 128 output tile, eight wavefronts of 64 x 64 (2 x 2 tiles of v_mfma_f32_32x32x16_f16; the 16-column sub-tiles of a
+// wavefront are interleaved over the tile so that the transposing reads are free of bank conflicts - see `fo`), LDS double-buffered with
 // ONE barrier per 32-row slice, the loads of slice t + 2 in flight while slice t computes (the schedule of csrc/gemm_h2.hip); the rows are
 // cut into S chunks, all tiles of a chunk on one XCD (a row slice is fetched from HBM once per chunk), one partial product per chunk (the
 // caller sums the S partials in a fixed order: deterministic).
@@ -113,7 +114,6 @@ __global__ __launch_bounds__(NT) void gemm_tn_h2_kernel(const float* __restrict_
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];   // buffer b: dY planes [2][16 sub-tiles] then X planes [2][8 sub-tiles]
   __shared__ float sInvA[TI], sInvB[TJ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
   // workgroup -> (output tile, row chunk): consecutive ids go to consecutive XCDs; all tiles of chunk s sit on XCD s % 8
   int tile, s;
   {
@@ -175,8 +175,14 @@ __global__ __launch_bounds__(NT) void gemm_tn_h2_kernel(const float* __restrict_
     for (int q = 0; q < 2; ++q) stage4(sb + 2 * PA + wx + q * 16 * 16, PB, rx[q], scx);
   };
   // fragment addresses: lane l of a 16-lane group names row (l & 15) / 4 and columns 4 (l & 3) .. + 3 of a 4 x 16 block; the group is
-  // sub-tile ((l >> 4) & 1) of the 32-column MFMA tile and k group (l >> 5)
-  const int fo = ((lane >> 4) & 1) * SUBE + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 16 + 4 * (lane & 3);
+  // half ((l >> 4) & 1) of the 32-column MFMA tile and k group (l >> 5).  The two halves of an MFMA tile are sub-tiles FOUR apart: the
+  // transposing read serves lanes 0-31 in one LDS cycle only if their two 128-byte blocks fall on disjoint halves of the 64 banks, and
+  // 4 x 264 dwords = 32 banks (mod 64), where adjacent sub-tiles - 8 banks apart, the spacing the 8-byte WRITES need - overlap on 24 of
+  // 32 banks (measured before this: SQ_LDS_BANK_CONFLICT = 36 % of the kernel's LDS cycles).  So a wavefront's 64 x 64 output is not a
+  // contiguous block: its dY columns are sub-tiles {wr + 8 a + 4 half}, its X columns {wc + 2 b + 4 half} (wr = wave / 2, wc = wave % 2,
+  // a / b = MFMA tile); the epilogue stores by the same map.
+  const int fo = ((lane >> 4) & 1) * 4 * SUBE + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 16 + 4 * (lane & 3);
+  const int wr = wave >> 1, wcx = wave & 1;
   struct Half {
     f16x8 a[2][2], b[2][2];   // [tile][plane]
   };
@@ -184,8 +190,8 @@ __global__ __launch_bounds__(NT) void gemm_tn_h2_kernel(const float* __restrict_
   {                                                                                                           \
     const unsigned short* sb = smem + (buf) * BUF + fo + (kh) * 16 * 16;                                      \
     _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {          \
-      F.a[a][pl] = tr_frag(sb + pl * PA + ((wi + a * 32) >> 4) * SUBE);                                       \
-      F.b[a][pl] = tr_frag(sb + 2 * PA + pl * PB + ((wj + a * 32) >> 4) * SUBE);                              \
+      F.a[a][pl] = tr_frag(sb + pl * PA + (wr + 8 * a) * SUBE);                                               \
+      F.b[a][pl] = tr_frag(sb + 2 * PA + pl * PB + (wcx + 2 * a) * SUBE);                                     \
     }                                                                                                         \
   }
 #define UAVGNN_TNH2_TERM(ia, ib)                                                                    \
@@ -234,14 +240,15 @@ __global__ __launch_bounds__(NT) void gemm_tn_h2_kernel(const float* __restrict_
   const int l32 = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    const int lcol = wj + b * 32 + l32, col = n0 + lcol;
+    const int lcol = 16 * (wcx + 2 * b + 4 * (l32 >> 4)) + (l32 & 15), col = n0 + lcol;
     if (col >= Ko) continue;
     const float cj = sInvB[lcol];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int lrow = wi + a * 32 + 8 * (i >> 2) + 4 * lh + (i & 3), row = m0 + lrow;
+        const int i32 = 8 * (i >> 2) + 4 * lh + (i & 3);                                   // the MFMA tile's row
+        const int lrow = 16 * (wr + 8 * a + 4 * (i32 >> 4)) + (i32 & 15), row = m0 + lrow;
         if (row < Mo) {
           float* p = Ps + static_cast<size_t>(row) * Ko + col;
           const float v = acc[a][b][i] * cj * sInvA[lrow];      // two exact power-of-two factors
@@ -279,8 +286,12 @@ extern "C" int uavgnn_gemm_tn_h2_supported(long long n_rows, int Mo, int Ko) {
 extern "C" int uavgnn_gemm_tn_h2_chunks(long long n_rows, int Mo, int Ko) {
   if (!uavgnn_gemm_tn_h2_supported(n_rows, Mo, Ko)) return 0;
   const int tiles = ((Mo + TI - 1) / TI) * ((Ko + TJ - 1) / TJ);
-  long long S = (512 + tiles - 1) / tiles;             // two rounds of 256 workgroups
-  if (S >= 8) S = (S + 7) / 8 * 8;                     // whole rounds over the 8 XCDs
+  // One workgroup per CU (101 KB of LDS), every workgroup the same length: the grid is cut for TWO FULL rounds of the 256 CUs - the largest
+  // chunk count, in whole rounds over the 8 XCDs, with tiles x S <= 512.  (Rounding S UP - 9 tiles x 64 = 576, 6 x 88 = 528 workgroups - left
+  // a third round for 16 .. 64 workgroups: dW_ih 4.45 -> 3.9 ms, dW_hh 3.34 -> 2.9 ms with the cut below.)
+  long long S = 512 / tiles;
+  if (S >= 8) S = S / 8 * 8;
+  if (S < 1) S = 1;
   const long long max_s = n_rows / 512 > 0 ? n_rows / 512 : 1;     // chunks of at least 512 rows
   if (S > max_s) S = max_s;
   return static_cast<int>(S);
