@@ -2718,8 +2718,14 @@ def test_learner_update_at_exp3_sizes_vs_oracle(label, B, n, M, T, dist, monkeyp
     expect = {"uavgnn_gatv2_hetero_fwd_image", "uavgnn_gru_cell_fwd_h2", "uavgnn_tarmac_msg_fwd_rowmax", "uavgnn_head_fwd",
               "uavgnn_gru_gates_bwd_fused_sums", "uavgnn_talk_attn_env_bwd", "uavgnn_gatv2_bwd", "uavgnn_colsum_acc",
               "uavgnn_relu_bwd_colsum"}
-    if N >= 4096:       # f_aggr on the bf16x3 kernel; its input gradient over the (T + 1) N time-batched rows on the f16x2 kernel
-        expect |= {"uavgnn_gemm_nt_x3", "uavgnn_gemm_nt_h2", "uavgnn_relu_bwd_colsum_rowmax"}
+    # K1 leaves the row maxima of its output - and f_aggr's forward runs on the f16x2 kernel instead of bf16x3 - on time-batched launches of
+    # more than 2^17 destinations and on any launch from 16 384 destinations whose `seen` relation is dense (ops.K1_ROWMAX_DENSE_DEG)
+    k1_rowmax = (T + 1) * N > (1 << 17) or (dist == "dense" and M >= 16 and (T + 1) * N >= 16384)    # (D-dense: every agent sees ~M GTs)
+    if k1_rowmax:
+        expect |= {"uavgnn_gatv2_hetero_fwd_rowmax", "uavgnn_gemm_nt_h2"}
+        expect -= {"uavgnn_gatv2_hetero_fwd_image"}
+    if N >= 4096:       # f_aggr on the bf16x3 kernel (f16x2 behind a K1 launch with row maxima); its input gradient over the (T + 1) N time-batched rows on the f16x2 kernel
+        expect |= {"uavgnn_gemm_nt_h2", "uavgnn_relu_bwd_colsum_rowmax"} | (set() if k1_rowmax else {"uavgnn_gemm_nt_x3"})
         expect -= {"uavgnn_relu_bwd_colsum"}
     if N >= 16384:      # d x of the recurrent step as ONE f16x2 product over [d_gi || d_proj] and d h += d_gh W_hh: from 128 tiles of 256 x 128
         expect |= {"uavgnn_gru_gates_bwd_fused_sums_rowmax", "uavgnn_row_absmax"}

@@ -19,6 +19,10 @@ K1_BF16Z = os.environ.get("UAVGNN_K1_BF16Z", "1") != "0"
 # row maxima out of the time-batched K1 launches (more than K1_ROWMAX_MIN_ROWS destinations) for an f16x2 f_aggr forward (A/B switch)
 K1_ROWMAX = os.environ.get("UAVGNN_K1_ROWMAX", "1") != "0"
 K1_ROWMAX_MIN_ROWS = 1 << 17
+# ... and out of ANY launch whose `seen` relation has this mean in-degree (a compute-bound launch) from the row count at which the f_aggr
+# product behind it takes the f16x2 kernel (GEMM_X3_SMALL_GRID tiles of 256 x 128 for H = 256 output columns)
+K1_ROWMAX_DENSE_DEG = int(os.environ.get("UAVGNN_K1_ROWMAX_DENSE_DEG", "16"))
+K1_ROWMAX_DENSE_MIN_ROWS = 16384
 
 
 class _KernelTimer:
@@ -128,9 +132,12 @@ class _HeteroGATv2(th.autograd.Function):
                         nh, D, NEG_SLOPE)
                 tail = (out.data_ptr(), R * H, L.ptr(aS), L.ptr(aN), phases, L.stream())
                 _HeteroGATv2.last_rowmax = None
-                if K1_ROWMAX and K1_BF16Z and GEMM_H2 and GEMM_X3 and N > K1_ROWMAX_MIN_ROWS:
+                if K1_ROWMAX and K1_BF16Z and GEMM_H2 and GEMM_X3 and (N > K1_ROWMAX_MIN_ROWS or
+                                                                       (N >= K1_ROWMAX_DENSE_MIN_ROWS and xs.shape[0] >= K1_ROWMAX_DENSE_DEG * N)):
                     # time-batched launch: the maxima of the two halves of every output row on the way (+9 % on this launch) - the f_aggr
-                    # product behind it runs on the f16x2 kernel (-25 %); the store-bound rollout launch would pay +1.9 us of 20: plain there
+                    # product behind it runs on the f16x2 kernel (-25 %); the store-bound rollout launch on env-realistic degrees would pay
+                    # +1.9 us of 18: plain there.  A rollout launch on DENSE degrees (mean in-degree of `seen` >= 16, known from the shapes:
+                    # every `gt` source has one out-edge) is compute-bound at 85-90 us: +2 % there, -17 us on the 58-us GEMM behind it
                     rmA, rmB = th.empty(N, dtype=th.float32, device=x_dst.device), th.empty(N, dtype=th.float32, device=x_dst.device)
                     rc = lib.uavgnn_gatv2_hetero_fwd_rowmax(*head, L.ptr(image), out.data_ptr(), R * H, L.ptr(aS), L.ptr(aN), rmA.data_ptr(),
                                                             rmB.data_ptr(), phases, L.stream())
