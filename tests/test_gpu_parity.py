@@ -2596,11 +2596,18 @@ class _LibSpy:
     """Records the name of every C-ABI entry the product fetches from the library (ops.py calls ``L.lib().<entry>(...)``)."""
 
     def __init__(self, real):
-        self._real, self.names = real, []
+        self._real, self.names, self.calls = real, [], []      # calls: (name, positional arguments) of every call made through the spy
 
     def __getattr__(self, name):
         self.names.append(name)
-        return getattr(self._real, name)
+        f = getattr(self._real, name)
+        if not callable(f):
+            return f
+
+        def call(*a):
+            self.calls.append((name, a))
+            return f(*a)
+        return call
 
 
 def _exp3_learner_and_sequence(B, n, M, T, dist, seed):
@@ -2709,11 +2716,19 @@ def test_learner_update_at_exp3_sizes_vs_oracle(label, B, n, M, T, dist, monkeyp
         staged.append(0 if self.seq is None else len(self.seq.bwd_steps))
         return orig_end(self)
     monkeypatch.setattr(ops.WeightGradSink, "end_sequence", end_spy)
+    if N >= 16384:
+        # the benchmark's sequence has 1.67 M time-batched rows: its weight gradients run on csrc/gemm_tn_h2.hip (taken from 2^18 rows).  This
+        # case has (T + 1) N = 114 688: the threshold is lowered so that the SAME kernels reduce the sequence here (dW_ih, dW_hh, dW_aggr,
+        # and dWp with swapped operands, column bounds from the per-step row maxima)
+        monkeypatch.setattr(ops, "GEMM_TN_MIN_ROWS", 4096)
     out = learner.accumulate(dict(batch))
     flat = learner.grads.flat.clone()
     monkeypatch.undo()
     # --- the dispatch is the benchmark's
     called = set(spy.names)
+    if N >= 16384:
+        tn_shapes = {(a[2], a[5]) for nm, a in spy.calls if nm == "uavgnn_gemm_tn_h2"}      # (Mo, Ko) of every weight-gradient launch
+        assert {(768, 320), (768, 256), (256, 96), (256, 512)} <= tn_shapes, tn_shapes
     assert max(staged) == T + 1, f"time-batched staging not taken: {staged}"
     expect = {"uavgnn_gatv2_hetero_fwd_image", "uavgnn_gru_cell_fwd_h2", "uavgnn_tarmac_msg_fwd_rowmax", "uavgnn_head_fwd",
               "uavgnn_gru_gates_bwd_fused_sums", "uavgnn_talk_attn_env_bwd", "uavgnn_gatv2_bwd", "uavgnn_colsum_acc",
@@ -2767,6 +2782,8 @@ def test_learner_update_at_exp3_sizes_vs_oracle(label, B, n, M, T, dist, monkeyp
     # --- the same accumulate as ONE replayed hipGraph (what `bench.py --graphed-cycle` and a production loop replay): the flat
     # gradient buffer the replay leaves is the eager one, i.e. the oracle comparison above covers the graphed path too
     from uav_bs_ctrl_amd.graphs import GraphedCycle
+    if N >= 16384:
+        monkeypatch.setattr(ops, "GEMM_TN_MIN_ROWS", 4096)      # (the dispatch of the eager run above)
     cyc = GraphedCycle(learner, lambda: learner.accumulate(batch))
     learner.grads.flat.fill_(float("nan"))
     out_g = cyc()

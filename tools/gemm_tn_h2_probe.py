@@ -85,4 +85,8 @@ for name, Mo, Ko in (("dW_ih  [768 x 320]", 768, 320), ("dW_hh  [768 x 256]", 76
     print(f"{name}: f16x2 {t_h2:8.1f} us ({fl / t_h2 * 1e-6:6.1f} TF) | vendor {t_v:8.1f} us ({fl / t_v * 1e-6:6.1f} TF) | bf16x3 {t_x3:8.1f} us "
           f"({fl / t_x3 * 1e-6:6.1f} TF) | column maxima of both operands (a pass of their own) {t_cm:7.1f} us")
     print("    " + " | ".join(rows))
+    if Mo < 128:      # a narrow dY: the product the shipped path runs is the TRANSPOSE, X^T dY (ops.WeightGradSink.end_sequence): one tile 3/4 full
+        t_sw = time_us(lambda: tn_h2(x, dy, cx, cy))
+        e = (tn_h2(x[:m], dy[:m], cx, cy).sum(0).t().double() - ref).abs() / den
+        print(f"    operands swapped (X^T dY = dW^T [{Ko} x {Mo}]): f16x2 {t_sw:8.1f} us ({fl / t_sw * 1e-6:6.1f} TF)   max {e.max().item():.2e} mean {e.mean().item():.2e}")
     del dy, x

@@ -557,12 +557,13 @@ class _GruCellFused(th.autograd.Function):
         return d_inp, dh, gWih, gbih, gWhh, gbhh, None, None
 
 
-def row_absmax(*pieces):
+def row_absmax(*pieces, out=None):
     """[N] = max |.| per row over up to three row-major fp32 matrices with N rows each (Inf for a row that holds Inf / NaN): the
     `rowmax` of the f16x2 GRU cell for callers whose producer does not hand it over (one extra pass over the operand)."""
     ps = [L.f32c(t) for t in pieces]
     N = ps[0].shape[0]
-    out = th.empty(N, dtype=th.float32, device=ps[0].device)
+    if out is None:
+        out = th.empty(N, dtype=th.float32, device=ps[0].device)
     args = []
     for i in range(3):
         t = ps[i] if i < len(ps) else None
@@ -792,11 +793,13 @@ def _max_two_stage(t):
     return t.reshape(S, n // S).max(1).values.max()
 
 
-def gemm_tn_h2_supported(dy, x) -> bool:
+def gemm_tn_h2_supported(dy, x, min_in=128) -> bool:
+    """dy^T x on csrc/gemm_tn_h2.hip (256 x 128 output tiles).  min_in: the narrowest `x` worth a 128-wide tile - 128 by default; the
+    96-column projections pass 96 with the operands SWAPPED (x^T d_proj = dWp^T: three quarters of a tile instead of three eighths)."""
     return bool(GEMM_X3 and GEMM_H2 and GEMM_TN_H2 and dy.is_cuda and dy.dtype == th.float32 and x.dtype == th.float32 and dy.dim() == 2
                 and x.dim() == 2 and dy.shape[0] == x.shape[0] and dy.shape[0] >= GEMM_TN_MIN_ROWS and dy.stride(1) == 1 and x.stride(1) == 1
                 and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
-                and dy.shape[1] >= 256 and x.shape[1] >= 128          # (a 96- or 9-row output leaves most of a 256 x 128 tile idle: the vendor GEMM)
+                and dy.shape[1] >= 256 and x.shape[1] >= min_in       # (a 9-row output leaves most of a 256 x 128 tile idle: the vendor GEMM)
                 and L.lib().uavgnn_gemm_tn_h2_supported(dy.shape[0], dy.shape[1], x.shape[1]))
 
 
@@ -1058,11 +1061,20 @@ class WeightGradSink:
             # 1.67 M rows - it runs at 135-141 TFLOP/s against 85-107 for csrc/gemm_tn_x3.hip (tools/gemm_tn_big_probe.py),
             # and 25-30 % above its own per-step rate (32 768 rows per call)
             tn = False
-            self.weight(("Wp_x", ids["Wp"]), d_proj, x, lambda g: split("Wp", g, 0), tn)
-            self.weight(("Wp_h", ids["Wp"]), d_proj, h, lambda g: split("Wp", g, H), tn)
+            h2_bounds = full and seq.rowmax_steps >= set(range(T1)) and seq.rm_g_steps >= set(range(T1))
+            if h2_bounds and seq.rm_p_steps >= set(range(T1)) and gemm_tn_h2_supported(x, d_proj, 96) and gemm_tn_h2_supported(h, d_proj, 96):
+                # dWp on the f16x2 kernel with the operands swapped - x^T d_proj = (dWp_x)^T, [H x 96]: one 256 x 128 tile three quarters full
+                # (d_proj^T x would fill three eighths of two: slower than the vendor) - 0.93 -> 0.5 ms each against the vendor's 0.74;
+                # column bounds: the message kernel's row maxima bound x and h, the per-step row maxima of d_proj (taken for the d x
+                # product of the step) bound d_proj
+                bxh, bpj = _max_two_stage(seq.bufs["rowmax"][:T1]), _max_two_stage(seq.bufs["rm_p"][:T1])
+                self.weight_h2(("Wp_x", ids["Wp"]), x, d_proj, bxh, bpj, lambda g: split("Wp", g.t(), 0))
+                self.weight_h2(("Wp_h", ids["Wp"]), h, d_proj, bxh, bpj, lambda g: split("Wp", g.t(), H))
+            else:
+                self.weight(("Wp_x", ids["Wp"]), d_proj, x, lambda g: split("Wp", g, 0), tn)
+                self.weight(("Wp_h", ids["Wp"]), d_proj, h, lambda g: split("Wp", g, H), tn)
             self.bias(("bp", ids["Wp"]), d_proj, lambda g: split("bp", g, 0))
-            if full and gemm_tn_h2_supported(d_gi, inp) and gemm_tn_h2_supported(d_gh, h) and seq.rowmax_steps >= set(range(T1)) \
-                    and seq.rm_g_steps >= set(range(T1)):
+            if h2_bounds and gemm_tn_h2_supported(d_gi, inp) and gemm_tn_h2_supported(d_gh, h):
                 # dW_ih / dW_hh on the f16x2 kernel (177-187 TFLOP/s against the vendor's 131-143 at C3): the column scales of the split
                 # come for free - the row maxima the message kernel (max over [x || c || h] per agent) and the gate kernel (d_gi / d_gh) left
                 # for the f16x2 cell / input-gradient products bound every column; a column far below the global maximum is held with fewer
@@ -1106,6 +1118,7 @@ class _SequenceStage:
         self.gsum_steps = set()          # steps whose gate kernel wrote its column-sum partials ("gsum" slots)
         self.rowmax_steps = set()        # steps whose message kernel left the row maxima of [x || c || h] ("rowmax" slots)
         self.rm_g_steps = set()          # steps whose gate kernel left the row maxima of d_gi / d_gh ("rm_g" slots)
+        self.rm_p_steps = set()          # steps whose backward took the row maxima of d_proj ("rm_p" slots)
         self.split = self.ids = self.H = None
 
     def slot(self, name, t, cols, extra=0, rows=None):
@@ -1433,7 +1446,11 @@ class _TarmacStep(th.autograd.Function):
                          ld)
         if dx_cat and rm_g is not None and gemm_h2_supported(d_gi, H, d_gi.shape[1] + d_proj.shape[1]):
             # f16x2: the row scale of [d_gi || d_proj] is the larger of the gate kernel's bound and d_proj's own (96 columns: a 4-us pass)
-            gemm_h2(d_gi, W_ih[:, :H], rm_g, True, out=dx, a2=d_proj, W2=Wp[:, :H], rowmax2=row_absmax(d_proj))
+            rm_p = None
+            if seq is not None:      # kept for the sequence: the column bound of d_proj in the weight gradient dWp (end_sequence)
+                rm_p = seq.slot("rm_p", ctx.seq_t, 1).view(N)
+                seq.rm_p_steps.add(ctx.seq_t)
+            gemm_h2(d_gi, W_ih[:, :H], rm_g, True, out=dx, a2=d_proj, W2=Wp[:, :H], rowmax2=row_absmax(d_proj, out=rm_p))
         elif dx_cat:
             gemm_x3_cat(d_gi, d_proj, W_ih[:, :H], Wp[:, :H], dx)
         elif split_dinp:
