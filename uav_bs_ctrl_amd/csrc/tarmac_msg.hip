@@ -452,9 +452,15 @@ __global__ __launch_bounds__(2 * kMsgThreads, 4) void tarmac_msg_fwd_k2_kernel(
   const bool ok = E <= EMAX && E >= 0;
   store_b(0);
   load_b(1);
+  // the sources of the tile's first 256 edges: requested here and carried through the GEMM loop - except by the RM instantiations, whose
+  // running row maximum takes the kernel over 128 VGPRs (20 bytes of scratch per lane): they request them behind the loop, where the two
+  // LDS passes of the pair's tile cover the round trip
   int fsrc[4];
+  auto load_fsrc = [&]() {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) fsrc[i] = (half == 0 && ok && lane + kWave * i < E) ? talk_src[e_lo + lane + kWave * i] : 0;
+    for (int i = 0; i < 4; ++i) fsrc[i] = (half == 0 && ok && lane + kWave * i < E) ? talk_src[e_lo + lane + kWave * i] : 0;
+  };
+  if (!RM) load_fsrc();
   lds_barrier();
 
 #define UAVGNN_MSG_TERM(FA, PB)                                                                                      \
@@ -496,6 +502,7 @@ __global__ __launch_bounds__(2 * kMsgThreads, 4) void tarmac_msg_fwd_k2_kernel(
   // ---- the pair's tile in LDS: (x part + bias) by the first wavefront, + h part by the second ------------------------------
   float* __restrict__ P = reinterpret_cast<float*>(smem_raw) + tile * (16 * LDP + kScratch);
   const int ncol = M + 2 * K;
+  if (RM) load_fsrc();
   if (RM) {   // lane (j, g) holds the maximum over its k of row j: combine the four lane groups
     amax = fmaxf(amax, __shfl_xor(amax, 16));
     amax = fmaxf(amax, __shfl_xor(amax, 32));
