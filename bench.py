@@ -1013,10 +1013,11 @@ def main():
                              "gemm_tn_h2.hip): every row (column, for the weight gradients) of an operand is scaled by an exact power of two into "
                              "f16's range and split into hi + lo f16 terms (hi + lo = v to <= 2^-23 |v|); an fp32 product is the fp32-accumulated "
                              "sum of 3 exact f16 x f16 MFMA products (dropped term <= 2^-22 |a b|) - the GRU cell of the TarMAC step, the "
-                             "input-gradient products of the recurrent step and of f_aggr, the weight gradients dW_ih / dW_hh / dW_aggr; the "
+                             "input-gradient products of the recurrent step and of f_aggr, the f_aggr forward behind a K1 launch that leaves row maxima "
+                             "(time-batched launches, rollout launches on dense degrees), the weight gradients dW_ih / dW_hh / dW_aggr / dWp; the "
                              "scales come from row maxima that the producing kernels leave on their way.  bf16x3 (rounds 2-5; csrc/gemm_x3.hip, "
                              "gatv2_hetero.hip, tarmac_msg.hip, gru_x3.hip): operands split EXACTLY into 3 bf16 terms, 6 exact bf16 x bf16 "
-                             "products per fp32 product (dropped terms <= 2^-23 |a b|) - the f_aggr forward, K1's score GEMM, the message "
+                             "products per fp32 product (dropped terms <= 2^-23 |a b|) - the f_aggr forward of rollout launches on env-realistic degrees, K1's score GEMM, the message "
                              "projection, GRU cells without a row-maxima producer.  Measured error vs fp64 of both schemes is at or BELOW the "
                              "vendor fp32 GEMM's on the same data (profiles/r06_h2_probe.txt, r06_h2_error_tables.txt, r06_gemm_tn_h2_probe.txt; "
                              "r02_gemm_x3_probe.txt, r03_gru_probe.txt).  A/B switches: UAVGNN_GRU_H2=0 / UAVGNN_GEMM_H2=0 / "
@@ -1092,19 +1093,24 @@ def main():
             # T act forwards on B environments + ONE optimizer step over rho chunks of B sequences (gradient accumulation)
             rho = a.rho
 
-            def step_rho():
+            def step_rho(chunks):
                 obs = [g.fresh() for g in batch["obs"]]
                 fb = dict(batch, obs=obs, obs_all=batch["obs_all"].fresh(), obs_all_next=batch["obs_all_next"].fresh())
                 h = learner.init_hidden(a.B)
                 for t in range(a.T):
                     _, h = learner.act(obs[t].fresh(), h, 0.05)
-                return learner.update([fb] * rho)
+                return learner.update([fb] * chunks)
             th.cuda.synchronize()
             gc.collect()
             th.cuda.empty_cache()   # like every leg after the headline: a clean caching allocator (the D-env leg's blocks and the pool of
             gc.disable()            # its captured graph cost this leg 30 % otherwise: 3.48 vs 2.65 s, profiles/r05_final_bench_dense.json)
+            # ... and, like the headline, ONE untimed warm-up - a cycle with a single chunk: the chunks of an update run one after the other
+            # through the same buffers, so this hands the empty allocator every block size of the timed cycle (timed cold, the leg measured
+            # the box's hipMalloc: 2.2 s on one box, 3.1 s on another, same build - profiles/r06_final_bench_dense_run2.json)
+            step_rho(1)
+            th.cuda.synchronize()
             t1 = time.perf_counter()
-            step_rho()
+            step_rho(rho)
             th.cuda.synchronize()
             e1 = time.perf_counter() - t1
             gc.enable()
