@@ -215,8 +215,15 @@ def ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
+_RAW_STREAM = getattr(th._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> int:
-    """The HIP stream PyTorch is currently recording on (so launches order with torch ops and graph capture works)."""
+    """The HIP stream PyTorch is currently recording on (so launches order with torch ops and graph capture works).  Through the raw
+    accessor where this PyTorch has it: ``torch.cuda.current_stream()`` builds a Stream object behind three layers of device-index
+    helpers (2.7 us against 0.3 - and a rollout step asks ten times)."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(th.cuda.current_device())
     return th.cuda.current_stream().cuda_stream
 
 
