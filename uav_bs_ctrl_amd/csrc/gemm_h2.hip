@@ -89,7 +89,11 @@ __global__ __launch_bounds__(NT) void gemm_nt_h2w8_kernel(const float* __restric
                                                           int ns1, const float* __restrict__ rm1, const float* __restrict__ rm2) {
   // buffer b: X planes [2][256][4] then B planes [2][128][4]; the accumulating instantiations park the 256 x 128 output tile here (132 KB)
   constexpr int kTileChunks = BM8 * (BN + 4) / 4;
-  __shared__ u32x4 smem[(ACC && kTileChunks > 2 * BUF) ? kTileChunks : 2 * BUF];
+#ifndef UAVGNN_GEMM_H2_TILE_STORE
+#define UAVGNN_GEMM_H2_TILE_STORE 1   /* 0: the non-accumulating instantiations store straight from the D layout (64 dword stores per lane) */
+#endif
+  constexpr bool kTileStore = ACC || UAVGNN_GEMM_H2_TILE_STORE;
+  __shared__ u32x4 smem[(kTileStore && kTileChunks > 2 * BUF) ? kTileChunks : 2 * BUF];
   __shared__ float sInv[BM8];       // 2^-e of the block's rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l32 = lane & 31, lh = lane >> 5, sw = swz32(l32);
@@ -259,9 +263,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_h2w8_kernel(const float* __restric
 #undef UAVGNN_H2_TERM
 #undef UAVGNN_H2_READ
   // un-scaling: two exact power-of-two factors per element (2^-e_col first: weights are small, it cannot overflow; then 2^-e_row)
-  if constexpr (ACC) {
+  if constexpr (kTileStore) {
   if ((ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && n0 + BN <= N) {
-    // Y += product through an LDS tile (see gemm_x3.hip: row-contiguous float4 read-modify-write, one exposed round trip per tile)
+    // Y (+)= product through an LDS tile (see gemm_x3.hip: row-contiguous float4 accesses - 16 per lane instead of 64 dword stores
+    // straight from the D layout; accumulating: a read-modify-write with one exposed round trip per tile)
     constexpr int LDT = BN + 4;
     float* sT = reinterpret_cast<float*>(smem);           // [256][LDT] fp32
     static_assert(BM8 * LDT * 4 <= static_cast<int>(sizeof(smem)), "the output tile fits the LDS array");
@@ -279,17 +284,20 @@ __global__ __launch_bounds__(NT) void gemm_nt_h2w8_kernel(const float* __restric
         }
       }
     float4 yv[16];
+    if constexpr (ACC) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int idx = tid + NT * q, row = idx >> 5, cc = idx & 31;
-      yv[q] = *reinterpret_cast<const float4*>(Y + static_cast<size_t>(min(m0 + row, M - 1)) * ldy + n0 + 4 * cc);
+      for (int q = 0; q < 16; ++q) {
+        const int idx = tid + NT * q, row = idx >> 5, cc = idx & 31;
+        yv[q] = *reinterpret_cast<const float4*>(Y + static_cast<size_t>(min(m0 + row, M - 1)) * ldy + n0 + 4 * cc);
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int idx = tid + NT * q, row = idx >> 5, cc = idx & 31;
       const float4 t = *reinterpret_cast<const float4*>(sT + row * LDT + 4 * cc);
-      float4 o = {yv[q].x + t.x, yv[q].y + t.y, yv[q].z + t.z, yv[q].w + t.w};
+      float4 o = t;
+      if constexpr (ACC) o = {yv[q].x + t.x, yv[q].y + t.y, yv[q].z + t.z, yv[q].w + t.w};
       if (RELU) o = {fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f)};
       if (m0 + row < M) *reinterpret_cast<float4*>(Y + static_cast<size_t>(m0 + row) * ldy + n0 + 4 * cc) = o;
     }
