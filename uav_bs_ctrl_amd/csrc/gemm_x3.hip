@@ -344,8 +344,10 @@ __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __res
       if (c4 == 0 && m0 + lr + 64 * i < M) rowmax_out[m0 + lr + 64 * i] = m;
     }
   }
-  if (ACC && (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && n0 + BN <= N) {
-    // Y += product through an LDS tile: the accumulators are parked in LDS (the slice buffers are free behind the loop's last
+  // (round 6: the NON-accumulating instantiations take the tile path too - 16 row-contiguous float4 stores per lane instead of 64 dword
+  // stores straight from the D layout: -3 us per tile, measured on the f16x2 twin of this kernel, csrc/gemm_h2.hip)
+  if ((ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && n0 + BN <= N) {
+    // Y (+)= product through an LDS tile: the accumulators are parked in LDS (the slice buffers are free behind the loop's last
     // barrier), then every thread does a ROW-CONTIGUOUS float4 read-modify-write of Y - its 16 loads are issued back to back,
     // one exposed round trip per tile.  Straight from the D layout (`v += *p` per element) the 64 dword loads of a lane are
     // issued in register-sized batches, each waiting for its own round trip: the accumulating launch of the GRU backward (dh +=
@@ -364,17 +366,20 @@ __global__ __launch_bounds__(w8::NT) void gemm_nt_x3w8_kernel(const float* __res
           sT[(wm + a * 32 + 8 * (i >> 2) + 4 * lh + (i & 3)) * LDT + wn + b * 32 + l32] = acc[a][b][i] + bv;
       }
     float4 yv[16];
+    if constexpr (ACC) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int idx = tid + NT * q, row = idx >> 5, c4 = idx & 31;
-      yv[q] = *reinterpret_cast<const float4*>(Y + static_cast<size_t>(min(m0 + row, M - 1)) * ldy + n0 + 4 * c4);
+      for (int q = 0; q < 16; ++q) {
+        const int idx = tid + NT * q, row = idx >> 5, c4 = idx & 31;
+        yv[q] = *reinterpret_cast<const float4*>(Y + static_cast<size_t>(min(m0 + row, M - 1)) * ldy + n0 + 4 * c4);
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int idx = tid + NT * q, row = idx >> 5, c4 = idx & 31;
       const float4 t = *reinterpret_cast<const float4*>(sT + row * LDT + 4 * c4);
-      float4 o = {yv[q].x + t.x, yv[q].y + t.y, yv[q].z + t.z, yv[q].w + t.w};
+      float4 o = t;
+      if constexpr (ACC) o = {yv[q].x + t.x, yv[q].y + t.y, yv[q].z + t.z, yv[q].w + t.w};
       if (RELU) o = {fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f)};
       if (m0 + row < M) *reinterpret_cast<float4*>(Y + static_cast<size_t>(m0 + row) * ldy + n0 + 4 * c4) = o;
     }
