@@ -257,6 +257,12 @@ long long uavgnn_split_h2_bytes(int n_out, int K);
 int uavgnn_split_h2(const float* W, int ld, int R, int C, int transpose, void* planes, uavgnn_stream_t stream);
 int uavgnn_gemm_nt_h2(const float* X, int ldx, int K1, const float* X2, int ldx2, int M, int K, const float* rowmax, const float* rowmax2,
                       const void* planes, int N, const float* bias, float* Y, int ldy, int epilogue, uavgnn_stream_t stream);
+/* uavgnn_gemm_nt_h2 for a second source WITHOUT a producer that bounds its rows (d_proj of the recurrent step: three kernels write its 96
+ * columns): the launch takes the row maxima of X2 [M, K - K1] itself - every workgroup reads its 256 rows of X2 once more in front of its
+ * first slice - uses max(rowmax, that) as the row's bound and writes the maxima to rowmax2_out [M] (Inf for a row that holds Inf / NaN:
+ * what uavgnn_row_absmax(X2) returns, bit for bit; a maximum is order-independent).  X2 must not be NULL. */
+int uavgnn_gemm_nt_h2_rm2(const float* X, int ldx, int K1, const float* X2, int ldx2, int M, int K, const float* rowmax, float* rowmax2_out,
+                          const void* planes, int N, const float* bias, float* Y, int ldy, int epilogue, uavgnn_stream_t stream);
 /* uavgnn_gru_gates_bwd_fused_sums / uavgnn_relu_bwd_colsum that ALSO write row_absmax [N] = max |.| over the rows of d_gi and d_gh /
  * of `out` (H = 256 / C = 256 only - one wavefront owns a row -, UAVGNN_EUNSUPPORTED otherwise; the second not in place). */
 int uavgnn_gru_gates_bwd_fused_sums_rowmax(const float* pre, const float* h, const float* d_hout, const float* dq, int n_out,

@@ -2743,7 +2743,7 @@ def test_learner_update_at_exp3_sizes_vs_oracle(label, B, n, M, T, dist, monkeyp
         expect |= {"uavgnn_gemm_nt_h2", "uavgnn_relu_bwd_colsum_rowmax"} | (set() if k1_rowmax else {"uavgnn_gemm_nt_x3"})
         expect -= {"uavgnn_relu_bwd_colsum"}
     if N >= 16384:      # d x of the recurrent step as ONE f16x2 product over [d_gi || d_proj] and d h += d_gh W_hh: from 128 tiles of 256 x 128
-        expect |= {"uavgnn_gru_gates_bwd_fused_sums_rowmax", "uavgnn_row_absmax"}
+        expect |= {"uavgnn_gru_gates_bwd_fused_sums_rowmax", "uavgnn_gemm_nt_h2_rm2"}      # (d_proj's row maxima inside the d x launch)
         expect -= {"uavgnn_gru_gates_bwd_fused_sums"}
     assert expect <= called, f"{label}: production kernels not dispatched: {sorted(expect - called)}"
     # --- oracle, float64.  The loss has two kinds of DISCONTINUITIES, at which an fp32 and a float64 evaluation may legitimately part:
@@ -3060,6 +3060,36 @@ def test_gemm_f16x2_vs_float64_and_the_other_gemms(M, K1, K2, N, acc, relu, tran
     assert rows[0]["max"] < 4e-7 and rows[0]["mean"] < 4e-8, rows          # the absolute bar of test_gemm_bf16x3_vs_float64
     assert rows[0]["mean"] <= 1.25 * max(rows[1]["mean"], rows[2]["mean"]), rows
     assert rows[0]["max"] <= 2.0 * max(rows[1]["max"], rows[2]["max"]), rows
+
+
+@pytest.mark.parametrize("M,K1,K2,N", [(33000, 768, 96, 256), (16385, 64, 32, 512), (65536, 256, 160, 128)])
+def test_gemm_f16x2_takes_the_row_maxima_of_its_second_source_itself(M, K1, K2, N):
+    """uavgnn_gemm_nt_h2_rm2: the row maxima of the second source taken inside the launch (d_proj of the recurrent step: no producer bounds
+    it) - the product is bit-identical to the launch that is handed uavgnn_row_absmax(X2), the maxima it writes ARE uavgnn_row_absmax(X2)
+    (rows past the last full 256-row block, a row holding Inf and one holding NaN included: Inf there, and only there), accumulate mode."""
+    from uav_bs_ctrl_amd import ops
+    gen = th.Generator().manual_seed(M + K2)
+    a = (th.randn(M, K1, generator=gen) * 0.3).cuda()
+    a2 = (th.randn(M, K2, generator=gen) * th.exp2(th.randint(-20, 6, (M, 1), generator=gen).float())).cuda()
+    a2[5, 3], a2[M - 1, K2 - 1] = float("inf"), float("nan")
+    W, W2 = (th.randn(K1, N, generator=gen) / K1 ** 0.5).cuda(), (th.randn(K2, N, generator=gen) / K2 ** 0.5).cuda()
+    rm = ops.row_absmax(a)
+    rm2 = ops.row_absmax(a2)
+    assert th.equal(rm2, a2.abs().amax(1).nan_to_num(nan=float("inf"), posinf=float("inf")))
+    assert ops.gemm_h2_supported(a, N, K1 + K2)
+    with ops.frozen_weights():
+        ref = ops.gemm_h2(a, W, rm, True, a2=a2, W2=W2, rowmax2=rm2)
+        out_rm = th.full((M,), -1.0, device="cuda")
+        got = ops.gemm_h2(a, W, rm, True, a2=a2, W2=W2, rowmax2_out=out_rm)
+        th.cuda.synchronize()
+        assert th.equal(out_rm, rm2)
+        assert th.equal(got.isnan(), ref.isnan()) and th.equal(got.nan_to_num(nan=0.0), ref.nan_to_num(nan=0.0))
+        assert bool(got[5].isnan().all()) and bool(got[M - 1].isnan().all()) and not bool(got[6:M - 1].isnan().any())
+        y0 = th.randn(M, N, generator=gen).cuda()
+        acc_ref, acc_got = y0.clone(), y0.clone()
+        ops.gemm_h2(a, W, rm, True, out=acc_ref, accumulate=True, a2=a2, W2=W2, rowmax2=rm2)
+        ops.gemm_h2(a, W, rm, True, out=acc_got, accumulate=True, a2=a2, W2=W2, rowmax2_out=th.empty(M, device="cuda"))
+        assert th.equal(acc_got.nan_to_num(nan=0.0), acc_ref.nan_to_num(nan=0.0))
 
 
 def test_row_maxima_of_the_gate_gradient_and_relu_backward_kernels_are_exact():

@@ -113,6 +113,8 @@ SIGNATURES = {
     "uavgnn_split_h2": (_c_int, [_c_fp, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_st]),
     "uavgnn_gemm_nt_h2": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp, ctypes.c_void_p, _c_int, _c_fp, _c_fp,
                                    _c_int, _c_int, _c_st]),
+    "uavgnn_gemm_nt_h2_rm2": (_c_int, [_c_fp, _c_int, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp, ctypes.c_void_p, _c_int, _c_fp, _c_fp,
+                                       _c_int, _c_int, _c_st]),
     "uavgnn_env_state_dim": (_c_int, [_c_int, _c_int, _c_int]),
     "uavgnn_env_step": (_c_int, [ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double), _c_int] + [_c_fp] * 22 + [_c_st]),
     "uavgnn_adamw_polyak": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, ctypes.c_longlong, _c_fp, ctypes.c_double,

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(NT) void gemm_nt_h2w8_kernel(const float* __restric
                                                           const unsigned short* __restrict__ Bp, int N, const float* __restrict__ winv,
                                                           const float* __restrict__ bias, float* __restrict__ Y, int ldy,
                                                           int row_blocks, int col_blocks, const float* __restrict__ X2, int ldx2,
-                                                          int ns1, const float* __restrict__ rm1, const float* __restrict__ rm2) {
+                                                          int ns1, const float* __restrict__ rm1, const float* __restrict__ rm2,
+                                                          float* __restrict__ rm2_out) {
   // buffer b: X planes [2][256][4] then B planes [2][128][4]; the accumulating instantiations park the 256 x 128 output tile here (132 KB)
   constexpr int kTileChunks = BM8 * (BN + 4) / 4;
 #ifndef UAVGNN_GEMM_H2_TILE_STORE
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_h2w8_kernel(const float* __restric
   constexpr bool kTileStore = ACC || UAVGNN_GEMM_H2_TILE_STORE;
   __shared__ u32x4 smem[(kTileStore && kTileChunks > 2 * BUF) ? kTileChunks : 2 * BUF];
   __shared__ float sInv[BM8];       // 2^-e of the block's rows
+  __shared__ float sRow2[BM8];      // rm2_out: the row maxima of X2 this workgroup computed itself
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l32 = lane & 31, lh = lane >> 5, sw = swz32(l32);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -119,14 +121,47 @@ __global__ __launch_bounds__(NT) void gemm_nt_h2w8_kernel(const float* __restric
     const float a = rm1[row];
     return rm2 != nullptr ? fmaxf(a, rm2[row]) : a;
   };
+  const bool own2 = rm2_out != nullptr;   // the second source has no producer that bounds it: this launch takes its row maxima itself
+  float m2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = min(m0 + lr + 64 * i, M - 1);
     xo[i] = static_cast<unsigned>(row) * ldx + 4 * c4;
     xo2[i] = static_cast<unsigned>(row) * ldx2 + 4 * c4;
-    sca[i] = pow2f(scale_exp(bound(row)));
   }
-  if (tid < BM8) sInv[tid] = pow2f(-scale_exp(bound(min(m0 + tid, M - 1))));
+  if (own2) {
+    // the eight threads of a row (consecutive lanes) read its K - K1 columns as float4 c4, c4 + 8, ...: 96 columns = three per thread and
+    // row, requested with the first slices of X; Inf / NaN make the bound infinite (the contract of uavgnn_row_absmax).  Every column
+    // block computes the same maxima (a maximum is order-independent: bit-identical); column block 0 writes them out.
+    const int nq = (K - ns1 * BK) / 4;
+    bool bad[4] = {false, false, false, false};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      for (int q = c4; q < nq; q += 8) {
+        const float4 v = *reinterpret_cast<const float4*>(X2 + xo2[i] + 4 * (q - c4));
+        const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
+        bad[i] |= !(a0 <= 3.4028234663852886e38f) | !(a1 <= 3.4028234663852886e38f) | !(a2 <= 3.4028234663852886e38f) |
+                  !(a3 <= 3.4028234663852886e38f);
+        m2[i] = fmaxf(fmaxf(m2[i], fmaxf(a0, a1)), fmaxf(a2, a3));
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (bad[i]) m2[i] = INFINITY;
+      m2[i] = fmaxf(m2[i], __shfl_xor(m2[i], 1));
+      m2[i] = fmaxf(m2[i], __shfl_xor(m2[i], 2));
+      m2[i] = fmaxf(m2[i], __shfl_xor(m2[i], 4));
+      if (c4 == 0) {
+        sRow2[lr + 64 * i] = m2[i];
+        if (cb == 0 && m0 + lr + 64 * i < M) rm2_out[m0 + lr + 64 * i] = m2[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = min(m0 + lr + 64 * i, M - 1);
+    sca[i] = pow2f(scale_exp(own2 ? fmaxf(rm1[row], m2[i]) : bound(row)));
+  }
+  if (!own2 && tid < BM8) sInv[tid] = pow2f(-scale_exp(bound(min(m0 + tid, M - 1))));
   const int sa_w = lr * 32 + (((c4 >> 1) ^ swz32(lr)) * 8) + (c4 & 1) * 4;   // f16 units inside an X plane
   // B loader: chunk q = tid + 512 i (i < 2): plane i, row tid / 4, chunk tid % 4
   unsigned bo[2];
@@ -194,6 +229,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_h2w8_kernel(const float* __restric
   lstore(0);
   gload(min(1, ns - 1));
   __syncthreads();
+  if (own2 && tid < BM8) sInv[tid] = pow2f(-scale_exp(fmaxf(rm1[min(m0 + tid, M - 1)], sRow2[tid])));   // (read behind the loop's barriers)
   const bool early = wave < 4;
   Half f0, f1;
   UAVGNN_H2_READ(f0, 0, 0)
@@ -358,11 +394,11 @@ extern "C" int uavgnn_split_h2(const float* W, int ld, int R, int C, int transpo
 // rowmax / rowmax2 (the second may be NULL): per row of the activation operand an upper bound of max |.| over the row - the larger of
 // the two is used - tight to within its power of two, from the kernels that produced the operand.  epilogue: UAVGNN_GEMM_ACCUMULATE,
 // UAVGNN_GEMM_RELU, UAVGNN_GEMM_STAGING_INTERLEAVED of uavgnn_gemm_nt_x3.  The eight-wave kernel only (no tile variants).
-extern "C" int uavgnn_gemm_nt_h2(const float* X, int ldx, int K1, const float* X2, int ldx2, int M, int K, const float* rowmax,
-                                 const float* rowmax2, const void* planes, int N, const float* bias, float* Y, int ldy, int epilogue,
-                                 uavgnn_stream_t stream) {
+static int gemm_nt_h2_launch(const float* X, int ldx, int K1, const float* X2, int ldx2, int M, int K, const float* rowmax,
+                             const float* rowmax2, float* rowmax2_out, const void* planes, int N, const float* bias, float* Y, int ldy,
+                             int epilogue, uavgnn_stream_t stream) {
   if (M < 0 || !X || !planes || !Y || !rowmax || ldx < K1 || ldy < N || K1 <= 0 || K1 > K || (X2 == nullptr) != (K1 == K) ||
-      (X2 != nullptr && ldx2 < K - K1))
+      (X2 != nullptr && ldx2 < K - K1) || (rowmax2_out != nullptr && (X2 == nullptr || rowmax2 != nullptr)))
     return UAVGNN_EINVAL;
   if (M == 0) return 0;
   if (!uavgnn_gemm_h2_supported(M, N, K) || (ldx & 3) || static_cast<long long>(M) * ldx >= (1LL << 31) ||
@@ -380,7 +416,7 @@ extern "C" int uavgnn_gemm_nt_h2(const float* X, int ldx, int K1, const float* X
   const dim3 grid(((row_blocks + 7) / 8) * 8 * col_blocks), block(NT);
 #define UAVGNN_H2_GEMM(ACC, RELU, IL)                                                                                              \
   hipLaunchKernelGGL((gemm_nt_h2w8_kernel<ACC, RELU, IL>), grid, block, 0, st, X, ldx, M, K, bp, N, winv, bias, Y, ldy, row_blocks, \
-                     col_blocks, X2, ldx2, ns1, rowmax, rowmax2)
+                     col_blocks, X2, ldx2, ns1, rowmax, rowmax2, rowmax2_out)
 #define UAVGNN_H2_GEMM_IL(IL)                         \
   if (acc && relu) UAVGNN_H2_GEMM(true, true, IL);    \
   else if (acc) UAVGNN_H2_GEMM(true, false, IL);      \
@@ -391,4 +427,20 @@ extern "C" int uavgnn_gemm_nt_h2(const float* X, int ldx, int K1, const float* X
 #undef UAVGNN_H2_GEMM_IL
 #undef UAVGNN_H2_GEMM
   return launch_status();
+}
+
+extern "C" int uavgnn_gemm_nt_h2(const float* X, int ldx, int K1, const float* X2, int ldx2, int M, int K, const float* rowmax,
+                                 const float* rowmax2, const void* planes, int N, const float* bias, float* Y, int ldy, int epilogue,
+                                 uavgnn_stream_t stream) {
+  return gemm_nt_h2_launch(X, ldx, K1, X2, ldx2, M, K, rowmax, rowmax2, nullptr, planes, N, bias, Y, ldy, epilogue, stream);
+}
+
+// ... for a second source WITHOUT a producer that bounds its rows: the launch takes the row maxima of X2 [M, K - K1] itself (its workgroups
+// read their 256 rows of X2 once more in front of the first slice - 96 columns at the recurrent step: a microsecond against the 8-us pass of
+// uavgnn_row_absmax) and writes them to rowmax2_out [M] (Inf for a row that holds Inf / NaN; what uavgnn_row_absmax(X2) returns, bit for bit).
+extern "C" int uavgnn_gemm_nt_h2_rm2(const float* X, int ldx, int K1, const float* X2, int ldx2, int M, int K, const float* rowmax,
+                                     float* rowmax2_out, const void* planes, int N, const float* bias, float* Y, int ldy, int epilogue,
+                                     uavgnn_stream_t stream) {
+  if (!rowmax2_out) return UAVGNN_EINVAL;
+  return gemm_nt_h2_launch(X, ldx, K1, X2, ldx2, M, K, rowmax, nullptr, rowmax2_out, planes, N, bias, Y, ldy, epilogue, stream);
 }

@@ -19,6 +19,7 @@ K1_BF16Z = os.environ.get("UAVGNN_K1_BF16Z", "1") != "0"
 # row maxima out of the time-batched K1 launches (more than K1_ROWMAX_MIN_ROWS destinations) for an f16x2 f_aggr forward (A/B switch)
 K1_ROWMAX = os.environ.get("UAVGNN_K1_ROWMAX", "1") != "0"
 K1_ROWMAX_MIN_ROWS = 1 << 17
+GEMM_H2_RM2 = os.environ.get("UAVGNN_GEMM_H2_RM2", "1") != "0"   # d x of the recurrent step takes the row maxima of d_proj inside its launch (A/B switch: a pass of uavgnn_row_absmax)
 # ... and out of ANY launch whose `seen` relation has this mean in-degree (a compute-bound launch) from the row count at which the f_aggr
 # product behind it takes the f16x2 kernel (GEMM_X3_SMALL_GRID tiles of 256 x 128 for H = 256 output columns)
 K1_ROWMAX_DENSE_DEG = int(os.environ.get("UAVGNN_K1_ROWMAX_DENSE_DEG", "16"))
@@ -737,10 +738,12 @@ def gemm_h2_supported(a, n_out, k) -> bool:
                 and ((a.shape[0] + 255) // 256) * ((n_out + 127) // 128) >= GEMM_X3_SMALL_GRID)
 
 
-def gemm_h2(a, W, rowmax, transpose_w=False, bias=None, out=None, accumulate=False, relu=False, a2=None, W2=None, rowmax2=None):
+def gemm_h2(a, W, rowmax, transpose_w=False, bias=None, out=None, accumulate=False, relu=False, a2=None, W2=None, rowmax2=None,
+            rowmax2_out=None):
     """out = a @ W.T (transpose_w=False) or a @ W (transpose_w=True) (+ bias) (+ out) (relu) on the f16x2 kernel; with a2 / W2:
     [a || a2] @ [W; W2] (W [K1, n_out], W2 [K2, n_out], transposed form only).  rowmax (and rowmax2): per row an upper bound of
-    max |.| over the row of the activation operand, from its producer(s).  Caller checks gemm_h2_supported()."""
+    max |.| over the row of the activation operand, from its producer(s); rowmax2_out [M] instead of rowmax2: the launch takes the row
+    maxima of a2 itself and leaves them there (uavgnn_gemm_nt_h2_rm2).  Caller checks gemm_h2_supported()."""
     lib = L.lib()
     M, K1 = a.shape
     if a2 is not None:
@@ -766,9 +769,10 @@ def gemm_h2(a, W, rowmax, transpose_w=False, bias=None, out=None, accumulate=Fal
         out = th.empty((M, n_out), dtype=th.float32, device=a.device)
     with KERNEL_TIMER.span("gemm_h2", (M, n_out, K)):
         planes = _cached_planes(key, lib.uavgnn_split_h2_bytes(n_out, K), a.device, build, keep=keep)
-        rc = lib.uavgnn_gemm_nt_h2(a.data_ptr(), a.stride(0), K1, L.ptr(a2), 0 if a2 is None else a2.stride(0), M, K, rowmax.data_ptr(),
-                                   L.ptr(rowmax2), planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(), out.stride(0),
-                                   (1 if accumulate else 0) | (2 if relu else 0) | (GEMM_X3_FLAGS & 4), L.stream())
+        fn, rm2 = (lib.uavgnn_gemm_nt_h2, rowmax2) if rowmax2_out is None else (lib.uavgnn_gemm_nt_h2_rm2, rowmax2_out)
+        rc = fn(a.data_ptr(), a.stride(0), K1, L.ptr(a2), 0 if a2 is None else a2.stride(0), M, K, rowmax.data_ptr(),
+                L.ptr(rm2), planes.data_ptr(), n_out, L.ptr(bias), out.data_ptr(), out.stride(0),
+                (1 if accumulate else 0) | (2 if relu else 0) | (GEMM_X3_FLAGS & 4), L.stream())
     L.check(rc, "uavgnn_gemm_nt_h2")
     return out
 
@@ -1445,12 +1449,17 @@ class _TarmacStep(th.autograd.Function):
                          d_c_ld, d_proj.data_ptr() + 4 * M, ld, d_proj.data_ptr() + 4 * (M + K), ld, d_proj.data_ptr(),
                          ld)
         if dx_cat and rm_g is not None and gemm_h2_supported(d_gi, H, d_gi.shape[1] + d_proj.shape[1]):
-            # f16x2: the row scale of [d_gi || d_proj] is the larger of the gate kernel's bound and d_proj's own (96 columns: a 4-us pass)
-            rm_p = None
+            # f16x2: the row scale of [d_gi || d_proj] is the larger of the gate kernel's bound and d_proj's own, which the launch takes
+            # itself (96 columns per row, read once more by its workgroups: a microsecond against a 7.8-us pass of uavgnn_row_absmax)
             if seq is not None:      # kept for the sequence: the column bound of d_proj in the weight gradient dWp (end_sequence)
                 rm_p = seq.slot("rm_p", ctx.seq_t, 1).view(N)
                 seq.rm_p_steps.add(ctx.seq_t)
-            gemm_h2(d_gi, W_ih[:, :H], rm_g, True, out=dx, a2=d_proj, W2=Wp[:, :H], rowmax2=row_absmax(d_proj, out=rm_p))
+            else:
+                rm_p = th.empty(N, dtype=th.float32, device=d_gi.device)
+            if GEMM_H2_RM2:
+                gemm_h2(d_gi, W_ih[:, :H], rm_g, True, out=dx, a2=d_proj, W2=Wp[:, :H], rowmax2_out=rm_p)
+            else:
+                gemm_h2(d_gi, W_ih[:, :H], rm_g, True, out=dx, a2=d_proj, W2=Wp[:, :H], rowmax2=row_absmax(d_proj, out=rm_p))
         elif dx_cat:
             gemm_x3_cat(d_gi, d_proj, W_ih[:, :H], Wp[:, :H], dx)
         elif split_dinp:
