@@ -836,16 +836,19 @@ def main():
     ops.KERNEL_TIMER.reset(enabled=True, only=GRADED)
     learner.grads.collective_events = []            # HIP events around the one collective of an update (when there is one)
     clock = ClockSampler(local)
+    alloc0 = th.cuda.memory_stats(device).get("num_device_alloc", 0)
     with clock:
         t0 = time.perf_counter()
-        marks = []
+        marks, enq = [], []
         for _ in range(a.steps):
             out = step()
             ev = th.cuda.Event(enable_timing=True)
             ev.record()
             marks.append(ev)
+            enq.append(time.perf_counter() - t0)     # when the launch thread had ENQUEUED the step (no synchronisation)
         barrier()
         elapsed = time.perf_counter() - t0
+    alloc1 = th.cuda.memory_stats(device).get("num_device_alloc", 0)
     ktimes = ops.KERNEL_TIMER.summary()
     coll_ms = [e0.elapsed_time(e1) for e0, e1 in learner.grads.collective_events]
     learner.grads.collective_events = None
@@ -937,6 +940,9 @@ def main():
                                                                 "HIP events on the compute stream"}),
             "params_checksum": [float(ck[0]), float(ck[1])],   # sum / sum of squares of the policy parameters after the timed steps
             "step_ms_device": [round(marks[i - 1].elapsed_time(marks[i]), 1) for i in range(1, len(marks))],
+            # diagnostics of the timed region: cumulative host time at which each step was enqueued (a launch thread that falls behind the
+            # device shows here, not in step_ms_device) and the device allocations (hipMalloc) the caching allocator made inside it
+            "step_enqueued_at_ms": [round(1e3 * t, 1) for t in enq], "device_allocs_in_timed_region": int(alloc1 - alloc0),
         }
         # ---- roofline of the dominant message-passing kernel: K1 forward, BOTH relations (one fused launch) ----------
         k = ktimes.get("gatv2_hetero_fwd") or kfull.get("gatv2_hetero_fwd")   # graphed cycle: from the eager instrumented cycle
