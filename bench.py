@@ -721,7 +721,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    # two warm-up cycles by default: after ONE the caching allocator still makes a device allocation in the next cycle (the free-block pool
+    # of cycle 2 differs from cycle 1's) - a hipMalloc inside the timed region that took 59 ms on boxes whose VRAM other processes had
+    # just used (profiles/r06_final_bench_dense_*_host_stall.json; `device_allocs_in_timed_region` in the line counts them: 1 / 0)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--B", type=int, default=4096, help="env graphs per GPU")
     ap.add_argument("--n", type=int, default=8)
     ap.add_argument("--M", type=int, default=80)
