@@ -1058,7 +1058,8 @@ class WeightGradSink:
         split, ids, H = seq.split, seq.ids, seq.H
         for (t0, t1) in spans:
             rows = lambda name, lo=0: seq.bufs[name][t0 + lo:t1 + lo].reshape((t1 - t0) * N, -1)   # noqa: E731
-            d_proj, d_gi, d_gh, dq = rows("d_proj"), rows("d_gi"), rows("d_gh"), rows("dq")
+            d_proj, d_gi, d_gh = rows("d_proj"), rows("d_gi"), rows("d_gh")
+            dq = seq.dq_rows(t0, t1)
             x = seq.x_all[t0 * N:t1 * N]
             h, h2, inp = rows("h"), rows("h", 1), rows("inp")
             # the vendor's batched split-K fp32 GEMM (64 row chunks): at these shapes - 768-, 96- and 9-row outputs over
@@ -1123,7 +1124,23 @@ class _SequenceStage:
         self.rowmax_steps = set()        # steps whose message kernel left the row maxima of [x || c || h] ("rowmax" slots)
         self.rm_g_steps = set()          # steps whose gate kernel left the row maxima of d_gi / d_gh ("rm_g" slots)
         self.rm_p_steps = set()          # steps whose backward took the row maxima of d_proj ("rm_p" slots)
+        self.dq_steps = {}               # step -> the gradient of the step's Q values as autograd handed it over
         self.split = self.ids = self.H = None
+
+    def dq_rows(self, t0, t1):
+        """[(t1 - t0) N, A] gradient of the Q values of steps t0 .. t1 - 1.  The per-step gradients autograd hands to the recurrent step are
+        normally consecutive [N, A] slices of ONE buffer (the backward of the learner's stack of the per-step Q values): then the rows are
+        a view of it - rounds 4-5 copied every step into a staging slot (51 launches of 4.7 us per update); anything else is gathered by
+        one torch.cat."""
+        parts = [self.dq_steps[t] for t in range(t0, t1)]
+        if len(parts) == 1:
+            return parts[0] if parts[0].is_contiguous() else parts[0].contiguous()
+        first, (N, A) = parts[0], parts[0].shape
+        if all(p.is_contiguous() and p.shape == (N, A) and p.dtype == first.dtype and
+               p.untyped_storage().data_ptr() == first.untyped_storage().data_ptr() and
+               p.storage_offset() == first.storage_offset() + i * N * A for i, p in enumerate(parts)):
+            return first.as_strided(((t1 - t0) * N, A), (A, 1), first.storage_offset())
+        return th.cat(parts, 0)
 
     def slot(self, name, t, cols, extra=0, rows=None):
         """[N, cols] slot t of the [T1 + extra, N, cols] buffer `name` (``rows``: another row count than N per step)."""
@@ -1471,7 +1488,7 @@ class _TarmacStep(th.autograd.Function):
             else:
                 dx = th.addmm(d_inp[:, :H], d_proj, Wp[:, :H])
         if seq is not None:      # reduced once per sequence (WeightGradSink.end_sequence)
-            seq.slot("dq", ctx.seq_t, dq.shape[1]).copy_(dq)
+            seq.dq_steps[ctx.seq_t] = dq      # (a reference, no copy: see _SequenceStage.dq_rows)
             seq.bwd_steps.append(ctx.seq_t)
             seq.split, seq.H = ctx.split, H
             seq.ids = {"Wp": id(Wp), "W_ih": id(W_ih), "W_hh": id(W_hh), "W_out": id(W_out)}
