@@ -895,16 +895,16 @@ class _LinearReLU(th.autograd.Function):
     the forward.  Backward masks dy with (y > 0) and reuses the split-K weight-gradient path."""
 
     @staticmethod
-    def forward(ctx, x, W, b, rm_a=None, rm_b=None):
+    def forward(ctx, x, W, b, rm_a=None, rm_b=None, train=True):
         ctx.x_rowmax = None
-        ctx.n_extra = 0 if rm_a is None else 2
+        ctx.n_extra = 0 if rm_a is None else 3
         n_out = W.shape[0]
         rm = None if rm_a is None else (rm_a, rm_b)
         if (rm is not None and b is not None and b.is_contiguous() and W.stride(1) == 1 and gemm_h2_supported(x, n_out, W.shape[1])):
             # the producer (the time-batched K1 launch) left the maxima of the two halves of every row: the layer on the f16x2 kernel
             y = gemm_h2(x, W, rm[0], False, bias=b, relu=True, rowmax2=rm[1])
-            if ctx.needs_input_grad[1]:
-                ctx.x_rowmax = th.maximum(rm[0], rm[1])
+            if ctx.needs_input_grad[1] and train:      # (needs_input_grad stays True for parameters under no_grad - `train` is the grad mode
+                ctx.x_rowmax = th.maximum(rm[0], rm[1])    # at the call site: a rollout step does not pay for the weight gradient's bound)
             ctx.save_for_backward(x, W, y)
             return y
         if (ctx.needs_input_grad[1] and n_out % 4 == 0 and gemm_x3_supported(x, n_out, W.shape[1]) and W.stride(1) == 1 and b is not None
@@ -951,7 +951,7 @@ class _LinearReLU(th.autograd.Function):
 def linear_relu(x, W, b):
     rm = getattr(x, "_uavgnn_rowmax", None)      # left by hetero_gatv2 on a time-batched launch
     if rm is not None:
-        return _LinearReLU.apply(x, W, b, rm[0], rm[1])
+        return _LinearReLU.apply(x, W, b, rm[0], rm[1], th.is_grad_enabled())
     return _LinearReLU.apply(x, W, b)
 
 
