@@ -721,9 +721,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    # two warm-up cycles by default: after ONE the caching allocator still makes a device allocation in the next cycle (the free-block pool
-    # of cycle 2 differs from cycle 1's) - a hipMalloc inside the timed region that took 59 ms on boxes whose VRAM other processes had
-    # just used (profiles/r06_final_bench_dense_*_host_stall.json; `device_allocs_in_timed_region` in the line counts them: 1 / 0)
+    # two warm-up cycles by default: the second cycle runs while the first one's outputs are still alive and needs one block more - with ONE
+    # warm-up cycle that device allocation (a hipMalloc: 59 ms on boxes whose VRAM other processes had just used,
+    # profiles/r06_final_bench_dense_*_host_stall.json) falls into the timed region (`device_allocs_by_step` in the line)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--B", type=int, default=4096, help="env graphs per GPU")
     ap.add_argument("--n", type=int, default=8)
@@ -828,27 +828,31 @@ def main():
     # The other kernels are timed in ONE extra, fully instrumented cycle after the timed region (`instrumented_cycle`).
     GRADED = ("gatv2_hetero_fwd",)
     ops.KERNEL_TIMER.reset(enabled=True, only=GRADED)   # warm-up runs instrumented the same way
-    for _ in range(a.warmup):
-        step()
-    barrier()
     # Python's cyclic GC is kept out of the timed region (a gen-2 pass over the autograd objects of a 101-forward
     # BPTT graph stalls the launch thread for 70-100 ms roughly every 8th step); memory is released by reference
-    # counting as usual.
+    # counting as usual.  It is switched off IN FRONT of the warm-up cycles, not between them and the timed ones: a collection at that
+    # point hands blocks back to the caching allocator that the cycles without GC then hold a little longer, and the second timed cycle
+    # could make a device allocation (a hipMalloc inside the timed region: `device_allocs_by_step` in the line)
     gc.collect()
     gc.disable()
+    out = None
+    for _ in range(a.warmup):
+        out = step()      # (kept, as the timed loop keeps it: the previous cycle's outputs are alive while the next one runs - with the result
+    barrier()             # dropped here the SECOND timed cycle needed one block more than any warm-up cycle: the same hipMalloc)
     ops.KERNEL_TIMER.reset(enabled=True, only=GRADED)
     learner.grads.collective_events = []            # HIP events around the one collective of an update (when there is one)
     clock = ClockSampler(local)
     alloc0 = th.cuda.memory_stats(device).get("num_device_alloc", 0)
     with clock:
         t0 = time.perf_counter()
-        marks, enq = [], []
+        marks, enq, allocs_by_step = [], [], []
         for _ in range(a.steps):
             out = step()
             ev = th.cuda.Event(enable_timing=True)
             ev.record()
             marks.append(ev)
             enq.append(time.perf_counter() - t0)     # when the launch thread had ENQUEUED the step (no synchronisation)
+            allocs_by_step.append(th.cuda.memory_stats(device).get("num_device_alloc", 0))
         barrier()
         elapsed = time.perf_counter() - t0
     alloc1 = th.cuda.memory_stats(device).get("num_device_alloc", 0)
@@ -946,6 +950,7 @@ def main():
             # diagnostics of the timed region: cumulative host time at which each step was enqueued (a launch thread that falls behind the
             # device shows here, not in step_ms_device) and the device allocations (hipMalloc) the caching allocator made inside it
             "step_enqueued_at_ms": [round(1e3 * t, 1) for t in enq], "device_allocs_in_timed_region": int(alloc1 - alloc0),
+            "device_allocs_by_step": [int(b - a_) for a_, b in zip([alloc0] + allocs_by_step[:-1], allocs_by_step)][:8],
         }
         # ---- roofline of the dominant message-passing kernel: K1 forward, BOTH relations (one fused launch) ----------
         k = ktimes.get("gatv2_hetero_fwd") or kfull.get("gatv2_hetero_fwd")   # graphed cycle: from the eager instrumented cycle
