@@ -15,6 +15,7 @@ python tools/h2_probe.py > gpurun_out/${R}_h2_probe.txt 2>&1
 python tools/gemm_tn_h2_probe.py > gpurun_out/${R}_gemm_tn_h2_probe.txt 2>&1
 python tools/h2_ablate.py > gpurun_out/${R}_h2_cell_ablate.txt 2>&1
 python tools/msg_probe.py > gpurun_out/${R}_final_msg_probe.txt 2>&1
+python tools/gemm_h2_shape_probe.py > gpurun_out/${R}_gemm_h2_shapes_now.txt 2>&1
 K1_IMAGE=1 tools/ubench/bin/k1_env_bench env 4096 50 > gpurun_out/${R}_k1_standalone.txt 2>&1
 K1_IMAGE=1 tools/ubench/bin/k1_env_bench dense 4096 50 | grep "phases  *[0-3]:" >> gpurun_out/${R}_k1_standalone.txt 2>&1
 K1_IMAGE=1 tools/ubench/bin/k1_env_bench env 208896 5 | grep "phases  *[23]:" >> gpurun_out/${R}_k1_standalone.txt 2>&1
@@ -42,3 +43,5 @@ python tools/k1_counters_json.py gpurun_out/${R}_k1_hetero_dense_pmc.txt gpurun_
 bash tools/pmc.sh /root/repo/gpurun_out/pmc_h2 "h2|tarmac_msg_fwd|gemm_tn" -- python /root/repo/tools/h2_pmc_run.py > /dev/null 2>&1
 cp gpurun_out/pmc_h2/pmc_summary.txt gpurun_out/${R}_h2_kernels_pmc.txt; rm -rf gpurun_out/pmc_h2
 tail -2 gpurun_out/${R}_final_tests.txt
+# the driver's own command line
+python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/${R}_bench_driver_cmd.json
